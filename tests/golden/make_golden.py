@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by RUNNING THE REFERENCE.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU
+box and nothing at test time reads it)::
+
+    python tests/golden/make_golden.py
+
+It imports ``/root/reference/src/{models,loss,utils}.py`` unmodified (CPU,
+fp64 unless noted), feeds them meshes from this repo's own generator, and
+stores inputs + outputs as ``.npz`` (data only).  The shadowed structured class
+(``src/models.py:93-212``) is obtained by exec'ing that line range of
+the reference file in a scratch namespace; example 3's energy needs
+``src.utils.gauss_legendre_points_weights`` (missing upstream), so the
+fixture uses ``interval_gauss_points`` and the body of ``examples/example3.py``
+(its first 70 lines: imports + ``b_force`` + ``energy_loss``) is exec'd with that alias injected.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from src.models import PiecewiseLinearShapeNN, PiecewiseLinearShapeNN2D as RefTri  # noqa: E402
+from src.loss import EnergyLoss2D as RefLoss  # noqa: E402
+from src.utils import triangle_gauss_points, interval_gauss_points  # noqa: E402
+import src.utils as ref_utils  # noqa: E402
+
+# REF stays first on sys.path: ``src`` means the reference's package in this script
+# (this repo's own drop-in ``src`` alias is never imported here).
+from hidenn_fem_amd.mesh import structured_tri_mesh  # noqa: E402
+
+F64 = torch.float64
+CPU = torch.device("cpu")
+
+
+def _structured_class():
+    text = open(os.path.join(REF, "src", "models.py")).read().split("\n")
+    ns = {}
+    exec("\n".join(text[:5] + text[92:212]), ns)
+    return ns["PiecewiseLinearShapeNN2D"]
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------- G5 quadrature
+def g5_quadrature(out):
+    for o in (1, 3, 4, 6, 7):
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            rs, w = triangle_gauss_points(o, device=CPU, dtype=dt)
+            out[f"tri{o}_{tag}_rs"], out[f"tri{o}_{tag}_w"] = np_(rs), np_(w)
+    for o in (1, 2, 3, 4, 5):
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            x, w = interval_gauss_points(o, device=CPU, dtype=dt)
+            out[f"gl{o}_{tag}_x"], out[f"gl{o}_{tag}_w"] = np_(x), np_(w)
+
+
+# ---------------------------------------------------------------- G1/G2 TRI3 + EDGE2
+def b_force_fn(x):
+    return torch.stack([1.0e6 * (1.0 + x[:, 0]), -2.0e6 * (0.5 + x[:, 1])], dim=1)
+
+
+def t_force_fn(xq):
+    return torch.stack([1.0e5 * (1.0 + xq[:, 1]), 2.0e4 * xq[:, 0]], dim=1)
+
+
+def tri_case(out, name, mesh6, gauss_order=4, gauss_order_1d=2, b_force=None, t_force=None,
+             no_boundary=False, u_scale=1.0, per_point=False, seed=0):
+    node_coords, conn, geom, bc, mn, edges = mesh6
+    torch.manual_seed(seed)
+    model = RefTri(node_coords.to(F64), conn,
+                   boundary_mask=None if no_boundary else geom,
+                   dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).double()
+    with torch.no_grad():
+        model.u_free.mul_(u_scale)
+    loss_fn = RefLoss(E=10e9, nu=0.3, gauss_order=gauss_order, gauss_order_1d=gauss_order_1d,
+                      device=CPU, dtype=F64)
+    dom = loss_fn.domain_energy(model, b_force)
+    edg = loss_fn.edge_energy(model, t_force)
+    loss = loss_fn(model, b_force=b_force, t_force=t_force)
+    loss.backward()
+    p = name + "/"
+    out[p + "node_coords"] = np_(node_coords.to(F64))
+    out[p + "conn"] = np_(conn)
+    out[p + "boundary_mask"] = np_(model.boundary_mask)
+    out[p + "dirichlet_mask"] = np_(bc)
+    out[p + "edges"] = np_(edges)
+    out[p + "u_free"] = np_(model.u_free)
+    out[p + "gauss_order"] = np.array([gauss_order, gauss_order_1d])
+    out[p + "loss"] = np_(loss)
+    out[p + "domain"] = np_(dom)
+    out[p + "edge"] = np_(edg)
+    out[p + "g_u_free"] = np_(model.u_free.grad)
+    out[p + "g_coords_free"] = np_(model.node_coords_free.grad)
+    if per_point:
+        ne, ng = conn.shape[0], loss_fn.ng
+        x_eval = loss_fn.xg.unsqueeze(0).expand(ne, ng, 2).reshape(-1, 2)
+        elem_id = torch.arange(ne).unsqueeze(1).repeat(1, ng).reshape(-1)
+        u_h, detJ, grad_u = model(x_eval, elem_id)
+        # cotangents for the unfused backward check
+        g = torch.Generator().manual_seed(123)
+        cu = torch.randn(u_h.shape, generator=g, dtype=F64)
+        cd = torch.randn(detJ.shape, generator=g, dtype=F64)
+        cg = torch.randn(grad_u.shape, generator=g, dtype=F64)
+        model.zero_grad()
+        ((u_h * cu).sum() + (detJ * cd).sum() + (grad_u * cg).sum()).backward()
+        out[p + "pp_x_eval"], out[p + "pp_elem_id"] = np_(x_eval), np_(elem_id)
+        out[p + "pp_u_h"], out[p + "pp_detJ"], out[p + "pp_grad_u"] = np_(u_h), np_(detJ), np_(grad_u)
+        out[p + "pp_cu"], out[p + "pp_cd"], out[p + "pp_cg"] = np_(cu), np_(cd), np_(cg)
+        out[p + "pp_g_u_free"] = np_(model.u_free.grad)
+        out[p + "pp_g_coords_free"] = np_(model.node_coords_free.grad)
+        # edge branch
+        n1 = loss_fn.ng1
+        xe = loss_fn.xg_1d[None, :].expand(edges.shape[0], n1).reshape(-1, 1)
+        eid = torch.repeat_interleave(torch.arange(edges.shape[0]), repeats=n1)
+        ue, ds = model(xe, eid, edge=True)
+        out[p + "pe_x_eval"], out[p + "pe_edge_id"] = np_(xe), np_(eid)
+        out[p + "pe_u_h"], out[p + "pe_ds"] = np_(ue), np_(ds)
+
+
+def g1_tri3(out):
+    base = structured_tri_mesh(9, 7, jitter=0.2, seed=1, dtype=F64)
+    for o in (1, 3, 4, 6, 7):
+        tri_case(out, f"order{o}", base, gauss_order=o, per_point=(o == 4))
+        tri_case(out, f"order{o}_body", base, gauss_order=o, b_force=b_force_fn, u_scale=3.0)
+    flipped = structured_tri_mesh(9, 7, jitter=0.2, seed=1, flip_fraction=0.5, dtype=F64)
+    tri_case(out, "flipped", flipped, b_force=b_force_fn, u_scale=2.0)
+    tri_case(out, "no_boundary_mask", base, no_boundary=True, u_scale=5.0)
+    tri_case(out, "traction_fn", base, t_force=t_force_fn, gauss_order_1d=3)
+    tri_case(out, "no_boundary_traction_order1", base, no_boundary=True, gauss_order_1d=1, u_scale=4.0)
+    perm = structured_tri_mesh(12, 9, jitter=0.3, seed=3, diagonal="random", permute=True, dtype=F64)
+    tri_case(out, "permuted_random_diag", perm, b_force=b_force_fn, u_scale=2.0)
+    big = structured_tri_mesh(41, 21, jitter=0.2, seed=0, dtype=F64)
+    tri_case(out, "mini_example4", big)
+
+
+# ---------------------------------------------------------------- G6 mini example-4 LBFGS
+def g6_lbfgs(out):
+    node_coords, conn, geom, bc, mn, edges = structured_tri_mesh(41, 21, jitter=0.0, seed=0, dtype=F64)
+    torch.manual_seed(0)
+    model = RefTri(node_coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                   neumann_edges=edges).double()
+    u0 = np_(model.u_free).copy()
+    loss_fn = RefLoss(E=10e9, nu=0.3, device=CPU, dtype=F64)
+    opt = torch.optim.LBFGS(model.parameters())          # examples/example4.py:68
+    trace = []
+
+    def closure():
+        opt.zero_grad()
+        loss = loss_fn(model)
+        loss.backward()
+        trace.append(loss.item())
+        return loss
+
+    for _ in range(2):
+        opt.step(closure)
+    out["lbfgs/node_coords"], out["lbfgs/conn"] = np_(node_coords), np_(conn)
+    out["lbfgs/boundary_mask"], out["lbfgs/dirichlet_mask"] = np_(geom), np_(bc)
+    out["lbfgs/edges"], out["lbfgs/u_free0"] = np_(edges), u0
+    out["lbfgs/closure_losses"] = np.array(trace)
+    out["lbfgs/u_free_final"] = np_(model.u_free)
+    out["lbfgs/coords_free_final"] = np_(model.node_coords_free)
+
+
+# ---------------------------------------------------------------- G3 1D
+def g3_line(out):
+    # example-1 configuration (examples/example1.py:25-42), fp64 and fp32
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        for r_adapt in (True, False):
+            x_grid = torch.linspace(0, 1, 100, dtype=dt)
+            x_train = torch.linspace(0, 1, 1000, dtype=dt)
+            u_true = torch.sin(2 * torch.pi * x_train)
+            model = PiecewiseLinearShapeNN(x_grid, r_adapt=r_adapt)
+            if dt == torch.float64:
+                model = model.double()
+            opt = torch.optim.Adam(model.parameters(), lr=0.005)
+            losses = []
+            for _ in range(20):
+                opt.zero_grad()
+                loss = ((model(x_train) - u_true) ** 2).mean()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            out[f"ex1_{tag}_r{int(r_adapt)}/adam_losses"] = np.array(losses)
+    # one fwd/bwd point with random u and perturbed increments, both BCs variants
+    g = torch.Generator().manual_seed(7)
+    for name, (u0, uN) in {"free": (None, None), "dir0": (0.25, None), "dirN": (None, -0.5),
+                           "dir": (0.0, 0.0)}.items():
+        x_grid = torch.linspace(0, 10, 41, dtype=F64)
+        model = PiecewiseLinearShapeNN(x_grid, r_adapt=True, u0=u0, uN=uN).double()
+        with torch.no_grad():
+            model.u.copy_(1e-2 * torch.randn(model.u.shape, generator=g, dtype=F64))
+            model.x_increments.mul_(1 + 0.05 * torch.randn(model.x_increments.shape, generator=g, dtype=F64))
+        x_eval = torch.rand(257, generator=g, dtype=F64) * 10
+        x_eval[:5] = model.grid.detach()[[0, 1, 7, 39, 40]]       # points exactly on nodes
+        x_eval = x_eval.requires_grad_(True)
+        u = model(x_eval)
+        c = torch.randn(u.shape, generator=g, dtype=F64)
+        (u * c).sum().backward()
+        p = f"line_{name}/"
+        out[p + "x_grid"], out[p + "u"], out[p + "incr"] = np_(x_grid), np_(model.u), np_(model.x_increments)
+        out[p + "bc"] = np.array([np.nan if u0 is None else u0, np.nan if uN is None else uN])
+        out[p + "grid"], out[p + "x_eval"], out[p + "pred"], out[p + "cot"] = \
+            np_(model.grid), np_(x_eval), np_(u), np_(c)
+        out[p + "g_u"], out[p + "g_incr"], out[p + "g_x_eval"] = \
+            np_(model.u.grad), np_(model.x_increments.grad), np_(x_eval.grad)
+    # fixed-node variant
+    x_grid = torch.linspace(0, 1, 33, dtype=F64) ** 1.3
+    model = PiecewiseLinearShapeNN(x_grid, r_adapt=False, u0=0.1).double()
+    with torch.no_grad():
+        model.u.copy_(torch.randn(model.u.shape, generator=g, dtype=F64))
+    x_eval = torch.rand(100, generator=g, dtype=F64)
+    u = model(x_eval)
+    c = torch.randn(u.shape, generator=g, dtype=F64)
+    (u * c).sum().backward()
+    p = "line_fixed/"
+    out[p + "x_grid"], out[p + "u"], out[p + "x_eval"] = np_(x_grid), np_(model.u), np_(x_eval)
+    out[p + "pred"], out[p + "cot"], out[p + "g_u"] = np_(u), np_(c), np_(model.u.grad)
+
+    # example-3 configuration: energy + grads (examples/example3.py:27-96)
+    import matplotlib
+    matplotlib.use("Agg")
+    ref_utils.gauss_legendre_points_weights = \
+        lambda n, device=None, dtype=torch.float32: interval_gauss_points(n, device=device, dtype=dtype)
+    ex3_src = open(os.path.join(REF, "examples", "example3.py")).read()
+    # only the imports + two function definitions (lines 1-70): no 4000-epoch loop, no plotting
+    ns = {}
+    exec("\n".join(ex3_src.split("\n")[:70]), ns)
+    energy_loss, b_force = ns["energy_loss"], ns["b_force"]
+    for npts, tag in ((89, "n89"), (1001, "n1001")):
+        x_grid = torch.linspace(0, 10.0, npts, dtype=F64)
+        xi, wi = interval_gauss_points(2, device=CPU, dtype=F64)
+        model = PiecewiseLinearShapeNN(x_grid, r_adapt=True, u0=0.0, uN=0.0).double()
+        with torch.no_grad():
+            model.u.copy_(1e-2 * torch.randn(model.u.shape, generator=g, dtype=F64))
+            model.x_increments.mul_(1 + 0.05 * torch.randn(model.x_increments.shape, generator=g, dtype=F64))
+        loss = energy_loss(model, xi, wi, b_force, E=175.0)
+        loss.backward()
+        p = f"ex3_{tag}/"
+        out[p + "x_grid"], out[p + "u"], out[p + "incr"] = np_(x_grid), np_(model.u), np_(model.x_increments)
+        out[p + "loss"], out[p + "g_u"], out[p + "g_incr"] = np_(loss), np_(model.u.grad), np_(model.x_increments.grad)
+    # first 10 Adam losses of example 3 as committed (zero init, 89 nodes, lr 1e-4), fp64
+    x_grid = torch.linspace(0, 10.0, 89, dtype=F64)
+    xi, wi = interval_gauss_points(2, device=CPU, dtype=F64)
+    model = PiecewiseLinearShapeNN(x_grid, r_adapt=True, u0=0.0, uN=0.0).double()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    tr = []
+    for _ in range(10):
+        opt.zero_grad()
+        loss = energy_loss(model, xi, wi, b_force, E=175.0)
+        loss.backward()
+        opt.step()
+        tr.append(loss.item())
+    out["ex3_adam/losses"] = np.array(tr)
+
+
+# ---------------------------------------------------------------- G4 structured 2D
+def g4_rect(out):
+    S2D = _structured_class()
+    g = torch.Generator().manual_seed(11)
+    gx = torch.linspace(0, 1, 17, dtype=F64) ** 1.2
+    gy = torch.linspace(0, 2, 13, dtype=F64)
+    bmx = torch.zeros(17, dtype=torch.bool)
+    bmx[[0, 5, 16]] = True
+    bmy = torch.zeros(13, dtype=torch.bool)
+    bmy[[0, 12]] = True
+    for name, kw in {"radapt_masks_fixed": dict(boundary_mask_x=bmx, boundary_mask_y=bmy, r_adapt=True, u_fixed=0.3),
+                     "radapt_default": dict(r_adapt=True),
+                     "fixed_nodes": dict(r_adapt=False, u_fixed=-1.0),
+                     "fixed_free": dict(r_adapt=False)}.items():
+        torch.manual_seed(5)
+        model = S2D(gx, gy, **kw).double()
+        if kw.get("r_adapt"):
+            with torch.no_grad():
+                model.increments_x.mul_(1 + 0.05 * torch.randn(16, generator=g, dtype=F64))
+                model.increments_y.mul_(1 + 0.05 * torch.randn(12, generator=g, dtype=F64))
+        x_eval = torch.rand(301, 2, generator=g, dtype=F64) * torch.tensor([1.0, 2.0], dtype=F64)
+        gxx, gyy = (t.detach() for t in model.grid)
+        x_eval[0] = torch.stack([gxx[3], gyy[4]])           # on a node
+        x_eval[1] = torch.stack([gxx[0], gyy[0]])
+        x_eval[2] = torch.stack([gxx[16], gyy[12]])
+        x_eval = x_eval.requires_grad_(True)
+        u = model(x_eval)
+        c = torch.randn(u.shape, generator=g, dtype=F64)
+        (u * c).sum().backward()
+        p = f"rect_{name}/"
+        out[p + "grid_x"], out[p + "grid_y"], out[p + "u"] = np_(gx), np_(gy), np_(model.u)
+        out[p + "mask_x"], out[p + "mask_y"] = np_(model.boundary_mask_x), np_(model.boundary_mask_y)
+        out[p + "u_fixed"] = np.array([np.nan if kw.get("u_fixed") is None else kw["u_fixed"]])
+        out[p + "r_adapt"] = np.array([int(bool(kw.get("r_adapt")))])
+        if kw.get("r_adapt"):
+            out[p + "incr_x"], out[p + "incr_y"] = np_(model.increments_x), np_(model.increments_y)
+            out[p + "g_incr_x"], out[p + "g_incr_y"] = np_(model.increments_x.grad), np_(model.increments_y.grad)
+        out[p + "gx_full"], out[p + "gy_full"] = np_(gxx), np_(gyy)
+        out[p + "x_eval"], out[p + "pred"], out[p + "cot"] = np_(x_eval), np_(u), np_(c)
+        out[p + "g_u"], out[p + "g_x_eval"] = np_(model.u.grad), np_(x_eval.grad)
+
+
+def main():
+    groups = {"g5_quadrature": g5_quadrature, "g1_tri3": g1_tri3, "g6_lbfgs": g6_lbfgs,
+              "g3_line": g3_line, "g4_rect": g4_rect}
+    for name, fn in groups.items():
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays -> {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

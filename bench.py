@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused TRI3+EDGE2 elastic-energy forward+backward ("element-evals/s").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...``
+(one rank per GPU, RCCL).  A *step* is one pass of the hot path over the synthetic mesh:
+loss + d/d node_coords_free + d/d u_free, inputs resident in HBM.
+
+Workload at N = 1: BASELINE.json configs[3] "Example 4", reading (i) of SURVEY F11 = "T1M":
+plate [0,2]x[0,1], 1001x501 nodes -> 1,000,000 TRI3 (each structured quad split in two),
+interior nodes jittered 0.2 h (seed 0), outer boundary fixed, left edge Dirichlet, right edge
+Neumann (500 edges), u_free ~ 1e-5 N(0,1), E=10e9, nu=0.3, gauss_order=4, fp64, r-adaptivity on.
+N > 1 (weak scaling): the plate grows to N x 1,000,000 elements (N*1000+1 x 501 nodes); every
+rank evaluates its contiguous tile range and ONE all-reduce of the packed [gX|gU|loss] buffer
+follows.
+
+One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel
+(tri3_energy_tiled_kernel): algorithmic bytes (12 Ne + 64 Nn + 8) over its
+average back-to-back launch time measured with HIP events on the launch stream.
+``cpu_baseline`` times the oracle's op-for-op PyTorch restatement of the reference chain on the
+host cores, on the same workload (bounded number of evaluations).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nx", type=int, default=1001, help="nodes along x PER GPU (+1 shared column)")
+    ap.add_argument("--ny", type=int, default=501)
+    ap.add_argument("--tile-elems", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
+    ap.add_argument("--cpu-evals", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(mesh6, u_free, n_evals):
+    """oracle/ref_chain.py (the reference's ATen op chain + autograd) on the host cores."""
+    from oracle import ref_chain as R
+    coords, conn, geom, bc, mn, edges = mesh6
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    mesh = dict(n_nodes=coords.shape[0], conn=conn, free_mask=~geom, boundary_mask=geom,
+                coords_fixed=coords[geom], u_free_mask=~bc, dirichlet_mask=bc,
+                u_fixed=torch.tensor(0.0, dtype=torch.float64), edges=edges)
+    xf, uf = coords[~geom].clone(), u_free.clone()
+    R.energy_and_grads(xf, uf, mesh)                       # warm-up
+    best = float("inf")
+    for _ in range(n_evals):
+        t0 = time.perf_counter()
+        loss, gx, gu = R.energy_and_grads(xf, uf, mesh)
+        best = min(best, time.perf_counter() - t0)
+    return dict(value=conn.shape[0] / best, unit="element-evals/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"same workload ({conn.shape[0]} TRI3, fp64), best of {n_evals} fwd+bwd evaluations "
+                       f"after 1 warm-up, {best:.3f} s/eval"), loss.item()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device; there is no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+
+    f64 = torch.float64
+    nx = (a.nx - 1) * world + 1
+    mesh6 = structured_tri_mesh(nx, a.ny, length=2.0 * world, height=1.0, jitter=0.2, seed=0, dtype=f64)
+    coords, conn, geom, bc, mn, edges = mesh6
+    ne, nn = conn.shape[0], coords.shape[0]
+    torch.manual_seed(0)
+    model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                     neumann_edges=edges).to(dev)
+    loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+    sh = ShardedTri3Energy(model, loss_fn)
+    plan = sh.plan
+    lo, hi = sh.lo, sh.hi
+    td = plan.export("tile_desc")
+    ne_local_home = ne if world == 1 else None
+
+    def step():
+        sh.evaluate_local()
+        if world > 1:
+            sh.exchange()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- correctness guard: the benchmarked path must produce the oracle's numbers
+    step()
+    torch.cuda.synchronize()
+    loss_v, gx_v, gu_v = sh._views(sh.recv if world > 1 else sh.send)
+    loss_gpu = loss_v.item()
+
+    # ---- timed region: W warm-up steps, then exactly K steps between barrier+synchronize
+    use_graph = (world == 1) and not a.no_graph
+    graph = None
+    if use_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(a.steps):
+                    step()
+        except Exception as e:  # pragma: no cover
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
+            graph = None
+    for _ in range(a.warmup):
+        step()
+    if graph is not None:
+        graph.replay()
+    sync_all()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(a.steps):
+            step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=f64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / a.steps * 1e3
+    value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
+
+    # ---- roofline leg: the dominant kernel alone, K back-to-back launches, HIP events on its stream
+    L = _lib.lib()
+    dv = lambda v: (C.c_double * len(v))(*v)
+    xf, uf = model.node_coords_free.detach(), model.u_free.detach()
+    xfix, ufix = model.node_coords_fixed, model.u_fixed_rows()
+    _, Tconst = loss_fn._traction(model, None)
+    loss_s, gx_s, gu_s = sh._views(sh.send)
+    mat, W, Bk, Tc = dv(loss_fn._mat), loss_fn._W, dv([0.0] * 6), dv(Tconst)
+    stream = torch.cuda.current_stream()
+
+    def kernel_only():
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None,
+                                           uf.data_ptr(), ufix.data_ptr() if ufix.numel() else None, mat, W, Bk, None,
+                                           Tc, lo, hi, loss_s.data_ptr(), gx_s.data_ptr(), gu_s.data_ptr(),
+                                           8, stream.cuda_stream))           # HFEM_FLAG_NO_LOSS_SUM
+
+    kreps = max(a.steps, 50)
+    kgraph = None
+    if not a.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                stream = s
+                kernel_only()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            kgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(kgraph):
+                stream = torch.cuda.current_stream()
+                for _ in range(kreps):
+                    kernel_only()
+        except Exception:
+            kgraph = None
+    stream = torch.cuda.current_stream()
+    for _ in range(5):
+        kernel_only()
+    if kgraph is not None:
+        kgraph.replay()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    if kgraph is not None:
+        kgraph.replay()
+    else:
+        for _ in range(kreps):
+            kernel_only()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    k_us = ev0.elapsed_time(ev1) * 1e3 / kreps
+    # algorithmic bytes of ONE launch on this rank: its home elements and owned nodes
+    ne_launch = int(td[lo:hi, 1].sum()) if world > 1 else ne      # (halo elements are not algorithmic work)
+    if world > 1:
+        ep = plan.export("elem_pack")
+        ne_launch = int(sum(int(((ep[o:o + n] >> 30) & 1).sum()) for o, n in td[lo:hi, :2]))
+    nn_launch = int(td[lo:hi, 4].sum())
+    alg_bytes = 12 * ne_launch + 64 * nn_launch + 8
+    achieved = alg_bytes / (k_us * 1e-6) / 1e9
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=None, kernel="tri3_energy_tiled_kernel", kernel_us=k_us,
+                    alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if not a.no_cpu_baseline:
+            if world == 1:
+                cpu, loss_cpu = cpu_baseline(mesh6, model.u_free.detach().cpu(), a.cpu_evals)
+                rel = abs(loss_cpu - loss_gpu) / abs(loss_cpu)
+                assert rel <= 1e-12, f"GPU loss {loss_gpu!r} != oracle loss {loss_cpu!r} (rel {rel:.2e})"
+                cpu["loss_rel_err_vs_gpu"] = rel
+        st = plan.stats
+        out = dict(
+            metric="element-evals/sec (fwd+bwd energy) + achieved HBM GB/s, 2D quad mesh",
+            value=value, unit="element-evals/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+            ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
+            data="synthetic",
+            config=dict(workload=f"Example 4 (T1M x {world}): 2D plate linear elasticity, {ne} TRI3 "
+                                 f"(structured quads split in 2), {nn} nodes, gauss_order=4, r-adaptivity on, "
+                                 f"Neumann edges {edges.shape[0]}, fwd+bwd (loss + dX + dU)",
+                        elements=ne, nodes=nn, elements_per_gpu=ne // world, tiles=st["n_tiles"],
+                        tile_elems=st["tile_elems"], halo_elem_factor=st["tile_elem_total"] / max(ne, 1),
+                        lds_bytes=st["lds_bytes"], launch="hipgraph" if graph is not None else "eager",
+                        exchange="none" if world == 1 else "all_reduce(gX|gU|loss) fp64 dense",
+                        loss=loss_gpu),
+            roofline=roofline,
+        )
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""Build libhidenn_hip.so in-tree with hipcc for gfx950 (MI355X / CDNA4 only).
+
+    python hidenn_fem_amd/csrc/build.py [--force] [--keep-temps]
+
+One object per source (compiled in parallel), one link.  ``-munsafe-fp-atomics``
+selects the hardware fp64 atomics (``global_atomic_add_f64`` / ``ds_add_f64``)
+instead of compare-and-swap loops.  The .so is git-ignored but travels to the GPU
+box with the gpurun snapshot; hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["plan.cpp", "tri3_energy.hip", "tri3_eval.hip", "line_rect.hip"]
+HEADERS = ["hfem_common.h", "hfem_device.h", os.path.join(ROOT, "include", "hidenn_fem.h")]
+OUT = os.path.join(HERE, "libhidenn_hip.so")
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
+            "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, keep_temps: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
+    objs = [os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+
+    def compile_one(pair):
+        src, obj = pair
+        if not force and not _stale(obj, [src] + hdrs + [__file__]):
+            return
+        cmd = [hipcc] + CXXFLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        if keep_temps:
+            cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.join(HERE, "build"))
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if keep_temps and r.stderr:
+            with open(obj + ".resource.txt", "w") as f:
+                f.write(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv))

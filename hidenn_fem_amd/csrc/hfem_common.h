@@ -1,0 +1,58 @@
+// Shared host-side helpers for libhidenn_hip.so: error reporting + plan layout.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/hidenn_fem.h"
+
+namespace hfem {
+
+// thread-local last-error string (hfem_last_error)
+void set_error(const std::string &msg);
+const char *get_error();
+
+#define HFEM_ARG_CHECK(cond, msg)                                            \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            ::hfem::set_error(std::string(__func__) + ": " + (msg));         \
+            return -1;                                                       \
+        }                                                                    \
+    } while (0)
+
+// ---- tile plan layout -------------------------------------------------------
+// Local node indices are 10 bits: a tile references at most 1024 nodes.
+constexpr int kLocalBits = 10;
+constexpr int kMaxLocal = 1 << kLocalBits;
+constexpr uint32_t kLocalMask = kMaxLocal - 1;
+constexpr uint32_t kHomeBit = 1u << 30;   // element/edge energy is counted by this tile
+
+// tile_desc[t] = 8 x int32
+struct TileDesc {
+    int32_t elem_off, n_elem;     // into elem_pack / elem_gid
+    int32_t node_off, n_node;     // into node_src; owned nodes first
+    int32_t n_owned;
+    int32_t edge_off, n_edge;     // into edge_pack / edge_gid
+    int32_t pad;
+};
+static_assert(sizeof(TileDesc) == 32, "TileDesc must be 8 x int32");
+
+struct HostPlan {
+    int64_t ne = 0, nn = 0, ned = 0;
+    int32_t tile_elems = 0;
+    std::vector<TileDesc> tiles;
+    std::vector<uint32_t> elem_pack;   // l0 | l1<<10 | l2<<20 | home<<30
+    std::vector<int32_t> elem_gid;     // global element id (tests / debugging)
+    std::vector<int32_t> node_src;     // [.][2] = {x_src, u_src} of each local node
+    std::vector<uint32_t> edge_pack;   // li | lj<<10 | home<<30
+    std::vector<int32_t> edge_gid;     // global edge id (row of the traction table)
+    int32_t max_nodes = 0, max_owned = 0, max_elems = 0, max_edges = 0;
+};
+
+// Build the owner-computes tiling.  Returns 0 or -1 (message via set_error).
+int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
+                    const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
+                    int64_t ned, int32_t tile_elems, HostPlan &out);
+
+}  // namespace hfem

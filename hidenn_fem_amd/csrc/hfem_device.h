@@ -1,0 +1,135 @@
+// Device-side helpers shared by the gfx950 kernels of libhidenn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hfem_common.h"
+
+namespace hfem {
+
+#define HFEM_HIP_CHECK(expr)                                                          \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            ::hfem::set_error(std::string(__func__) + ": " #expr " -> " +             \
+                              hipGetErrorString(_e));                                 \
+            return (int)_e;                                                           \
+        }                                                                             \
+    } while (0)
+
+// Select the device for this call (no thread-affine state is kept: PyTorch runs
+// backward on a different host thread than forward).
+inline int use_device(int device) {
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        set_error(std::string("hipSetDevice(") + std::to_string(device) + "): " + hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+inline int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string(what) + ": launch failed: " + hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// Material + quadrature constants of one energy evaluation (kernel argument).
+struct Tri3Consts {
+    double c11, c12, c22, c33;   // plane-stress C, /root/reference/src/loss.py:29-32
+    double W;                    // sum of triangle weights
+    double Bk[6];                // body-force table [3][2]
+};
+
+// 64-lane wavefront sum (gfx950: wave64).  Result valid in lane 0.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block sum; `scratch` holds >= blockDim.x/64 doubles in LDS.  Result in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 0; w < nw; ++w) r += scratch[w];   // fixed order: deterministic
+    }
+    return r;
+}
+
+// One TRI3 element: energy density terms and (optionally) the 12 gradient
+// entries.  Closed forms of SURVEY section 8a; they restate
+//   J = [[x0-x2, x1-x2],[y0-y2, y1-y2]], detJ, Jinv      src/models.py:336-343
+//   dN_dx = Jinv * dN_dxi  (reference convention, F4)    src/models.py:347-351
+//   grad_u = sum_a U_a (x) dN_dx[:,a] = G Jinv^T          src/models.py:355
+//   eps, sigma = C eps, psi = 1/2 eps.sigma               src/loss.py:66-77
+//   e = abs(detJ) (W psi - sum_k U_k.B_k)                 src/loss.py:80-88
+// and the hand-derived backward w.r.t. U (gu[k][i]) and X (gx[k][i]).
+template <bool GRAD>
+__device__ __forceinline__ double tri3_element(const double2 X0, const double2 X1, const double2 X2,
+                                               const double2 U0, const double2 U1, const double2 U2,
+                                               const Tri3Consts &k, double2 (&gx)[3], double2 (&gu)[3]) {
+    const double a = X0.x - X2.x, b = X1.x - X2.x, c = X0.y - X2.y, d = X1.y - X2.y;
+    const double det = a * d - b * c;
+    const double inv = 1.0 / det;
+    const double A = fabs(det);
+    const double g0x = U0.x - U2.x, g0y = U0.y - U2.y;
+    const double g1x = U1.x - U2.x, g1y = U1.y - U2.y;
+    const double h00 = (g0x * d - g1x * b) * inv, h01 = (g1x * a - g0x * c) * inv;
+    const double h10 = (g0y * d - g1y * b) * inv, h11 = (g1y * a - g0y * c) * inv;
+    const double gam = h01 + h10;
+    const double sxx = k.c11 * h00 + k.c12 * h11;
+    const double syy = k.c12 * h00 + k.c22 * h11;
+    const double sxy = k.c33 * gam;
+    const double psi = 0.5 * (h00 * sxx + h11 * syy + gam * sxy);
+    const double beta = U0.x * k.Bk[0] + U0.y * k.Bk[1] + U1.x * k.Bk[2] + U1.y * k.Bk[3] +
+                        U2.x * k.Bk[4] + U2.y * k.Bk[5];
+    const double dens = k.W * psi - beta;
+    if (GRAD) {
+        const double aw = A * k.W;
+        const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;   // P[1][0] = p01
+        const double dg0x = (p00 * d - p01 * c) * inv, dg0y = (p01 * d - p11 * c) * inv;
+        const double dg1x = (p01 * a - p00 * b) * inv, dg1y = (p11 * a - p01 * b) * inv;
+        gu[0] = make_double2(dg0x - A * k.Bk[0], dg0y - A * k.Bk[1]);
+        gu[1] = make_double2(dg1x - A * k.Bk[2], dg1y - A * k.Bk[3]);
+        gu[2] = make_double2(-(dg0x + dg1x) - A * k.Bk[4], -(dg0y + dg1y) - A * k.Bk[5]);
+        const double ddet = (det < 0.0 ? -dens : dens) -
+                            (p00 * h00 + p01 * (h01 + h10) + p11 * h11) * inv;
+        const double da = (p01 * g1x + p11 * g1y) * inv + ddet * d;
+        const double db = -(p00 * g1x + p01 * g1y) * inv - ddet * c;
+        const double dc = -(p01 * g0x + p11 * g0y) * inv - ddet * b;
+        const double dd = (p00 * g0x + p01 * g0y) * inv + ddet * a;
+        gx[0] = make_double2(da, dc);
+        gx[1] = make_double2(db, dd);
+        gx[2] = make_double2(-(da + db), -(dc + dd));
+    }
+    return A * dens;
+}
+
+// One Neumann edge (i,j): work ds*m and gradient of (-work).   src/loss.py:91-110,
+// src/models.py:359-376.  t = {Ti.x, Ti.y, Tj.x, Tj.y}.
+template <bool GRAD>
+__device__ __forceinline__ double edge2_element(const double2 Xi, const double2 Xj, const double2 Ui,
+                                                const double2 Uj, const double4 t, double2 (&gx)[2],
+                                                double2 (&gu)[2]) {
+    const double rx = Xj.x - Xi.x, ry = Xj.y - Xi.y;
+    const double ds = sqrt(rx * rx + ry * ry);
+    const double m = Ui.x * t.x + Ui.y * t.y + Uj.x * t.z + Uj.y * t.w;
+    if (GRAD) {
+        gu[0] = make_double2(-ds * t.x, -ds * t.y);
+        gu[1] = make_double2(-ds * t.z, -ds * t.w);
+        const double f = m / ds;
+        gx[0] = make_double2(f * rx, f * ry);
+        gx[1] = make_double2(-f * rx, -f * ry);
+    }
+    return ds * m;
+}
+
+}  // namespace hfem

@@ -1,0 +1,438 @@
+// 1D (LINE2) and structured-2D (RECT-Q4) paths of the reference, gfx950:
+//   grid parametrisation   /root/reference/src/models.py:45-56, 146-168
+//   LINE2 interpolation    /root/reference/src/models.py:70-90
+//   RECT-Q4 interpolation  /root/reference/src/models.py:180-212
+//   inline losses          /root/reference/examples/example1.py:38, example2.py:46,
+//                          example3.py:27-70
+// Forward + hand-derived backward.  These problems are tiny
+// (10^2..10^5 points): the kernels are launch-bound, so each loss is ONE launch
+// that produces the scalar and all parameter gradients.
+#include <hip/hip_runtime.h>
+
+#include "hfem_device.h"
+
+namespace hfem {
+
+constexpr int kBlockL = 256;
+constexpr int kScan = 1024;   // single-block scan width for the grid parametrisation
+
+__device__ __forceinline__ double softplus_clamped(double v) {
+    const double s = v > 20.0 ? v : log1p(exp(v));   // torch softplus, beta=1, threshold=20
+    return s < 1e-6 ? 1e-6 : s;                      // clamp(min=1e-6)
+}
+__device__ __forceinline__ double softplus_clamped_grad(double v) {
+    const double s = v > 20.0 ? v : log1p(exp(v));
+    if (s < 1e-6) return 0.0;
+    return v > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-v));
+}
+
+// inclusive Hillis-Steele scan over kScan LDS entries; forward (dir=+1) or suffix (dir=-1)
+__device__ __forceinline__ double block_scan(double v, double *buf, bool suffix) {
+    const int tid = threadIdx.x;
+    buf[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < kScan; off <<= 1) {
+        const int o = suffix ? tid + off : tid - off;
+        const double add = (o >= 0 && o < kScan) ? buf[o] : 0.0;
+        __syncthreads();
+        buf[tid] += add;
+        __syncthreads();
+    }
+    return buf[tid];
+}
+
+// p[n] -> grid[n+1]; one workgroup of kScan threads, each owning a contiguous chunk.
+__global__ __launch_bounds__(kScan) void grid_param_fwd_kernel(const double *__restrict__ p, int64_t n,
+                                                              double x0, double xN,
+                                                              const uint8_t *__restrict__ mask,
+                                                              const double *__restrict__ initial,
+                                                              double *__restrict__ grid) {
+    __shared__ double buf[kScan];
+    const int tid = threadIdx.x;
+    const int64_t chunk = (n + kScan - 1) / kScan;
+    const int64_t k0 = tid * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
+    double s = 0.0;
+    for (int64_t k = k0; k < k1; ++k) s += softplus_clamped(p[k]);
+    const double incl = block_scan(s, buf, false);
+    const double S = buf[kScan - 1];
+    double run = incl - s;
+    for (int64_t k = k0; k < k1; ++k) {
+        run += softplus_clamped(p[k]);
+        const double cum = (k == n - 1) ? S : run;              // cum[-1]/cum[-1] == 1 exactly
+        double g = x0 + (xN - x0) * cum / S;                    // models.py:52
+        if (mask && mask[k + 1]) g = initial[k + 1];            // models.py:165-166
+        grid[k + 1] = g;
+    }
+    if (tid == 0) grid[0] = (mask && mask[0]) ? initial[0] : x0;
+}
+
+// ggrid[n+1] -> gp[n]
+__global__ __launch_bounds__(kScan) void grid_param_bwd_kernel(const double *__restrict__ p, int64_t n,
+                                                              double x0, double xN,
+                                                              const uint8_t *__restrict__ mask,
+                                                              const double *__restrict__ ggrid,
+                                                              double *__restrict__ gp) {
+    __shared__ double buf[kScan];
+    __shared__ double red[kScan / 64];
+    __shared__ double dot_s;
+    const int tid = threadIdx.x;
+    const int64_t chunk = (n + kScan - 1) / kScan;
+    const int64_t k0 = tid * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
+    const double L = xN - x0;
+    double s = 0.0;
+    for (int64_t k = k0; k < k1; ++k) s += softplus_clamped(p[k]);
+    const double incl = block_scan(s, buf, false);
+    const double S = buf[kScan - 1];
+    __syncthreads();
+    // dot = sum_k gx_k cum_k (masked rows carry no gradient)
+    double run = incl - s, dot = 0.0;
+    for (int64_t k = k0; k < k1; ++k) {
+        run += softplus_clamped(p[k]);
+        const double g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+        dot += g * ((k == n - 1) ? S : run);
+    }
+    const double dtot = block_sum(dot, red);
+    if (tid == 0) dot_s = dtot;
+    __syncthreads();
+    const double corr = L * dot_s / (S * S);
+    // gcum_k = L g_k / S  (last: minus corr); ginc = suffix sum of gcum
+    double loc = 0.0;
+    for (int64_t k = k0; k < k1; ++k) {
+        const double g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+        loc += L * g / S - (k == n - 1 ? corr : 0.0);
+    }
+    const double suf = block_scan(loc, buf, true);   // sum over chunks >= tid
+    double acc = suf - loc;                           // chunks strictly after this one
+    for (int64_t k = k1 - 1; k >= k0; --k) {
+        const double g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+        acc += L * g / S - (k == n - 1 ? corr : 0.0);
+        gp[k] = acc * softplus_clamped_grad(p[k]);
+    }
+}
+
+// searchsorted(grid, x, right=False) - 1, clamp(0, n-2)      models.py:73-74
+__device__ __forceinline__ int find_elem(const double *__restrict__ grid, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (grid[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    int e = lo - 1;
+    e = e < 0 ? 0 : e;
+    return e > n - 2 ? n - 2 : e;
+}
+
+struct Hat {   // one axis of the hat-function pair, models.py:84-85
+    int e;
+    double N1, N2, h, raw, ui, uj;
+};
+__device__ __forceinline__ Hat hat_eval(const double *__restrict__ grid, int n, double x) {
+    Hat t;
+    t.e = find_elem(grid, n, x);
+    const double xi = grid[t.e], xj = grid[t.e + 1];
+    t.raw = xj - xi;
+    t.h = t.raw < 1e-10 ? 1e-10 : t.raw;        // .clamp(self.epsilon)
+    t.N1 = (xj - x) / t.h;
+    t.N2 = (x - xi) / t.h;
+    return t;
+}
+// accumulate d/dgrid of one axis given dL/dN1, dL/dN2
+__device__ __forceinline__ void hat_grid_grad(const Hat &t, double gN1, double gN2, double extra_gh,
+                                              double *__restrict__ ggrid) {
+    const double gh = t.raw < 1e-10 ? 0.0 : (extra_gh - (gN1 * t.N1 + gN2 * t.N2) / t.h);
+    unsafeAtomicAdd(&ggrid[t.e + 1], gN1 / t.h + gh);
+    unsafeAtomicAdd(&ggrid[t.e], -gN2 / t.h - gh);
+}
+
+__global__ __launch_bounds__(kBlockL) void line2_eval_fwd_kernel(const double *__restrict__ grid,
+                                                                const double *__restrict__ u, int n,
+                                                                const double *__restrict__ x_eval, int64_t m,
+                                                                double *__restrict__ pred,
+                                                                double *__restrict__ dudx) {
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
+        const Hat t = hat_eval(grid, n, x_eval[q]);
+        const double ui = u[t.e], uj = u[t.e + 1];
+        if (pred) pred[q] = ui * t.N1 + uj * t.N2;               // models.py:88
+        if (dudx) dudx[q] = (uj - ui) / t.h;
+    }
+}
+
+__global__ __launch_bounds__(kBlockL) void line2_eval_bwd_kernel(
+    const double *__restrict__ grid, const double *__restrict__ u, int n, const double *__restrict__ x_eval,
+    int64_t m, const double *__restrict__ cot, const double *__restrict__ cot_d, double *__restrict__ ggrid,
+    double *__restrict__ gu, double *__restrict__ gx_eval) {
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
+        const Hat t = hat_eval(grid, n, x_eval[q]);
+        const double ui = u[t.e], uj = u[t.e + 1];
+        const double g = cot ? cot[q] : 0.0, gd = cot_d ? cot_d[q] : 0.0;
+        const double du = (uj - ui) / t.h;
+        if (gu) {
+            unsafeAtomicAdd(&gu[t.e], g * t.N1 - gd / t.h);
+            unsafeAtomicAdd(&gu[t.e + 1], g * t.N2 + gd / t.h);
+        }
+        if (ggrid) hat_grid_grad(t, g * ui, g * uj, -gd * du / t.h, ggrid);
+        if (gx_eval) gx_eval[q] = g * du;
+    }
+}
+
+// examples/example3.py:27-70 with detached xq,wq (F8): loss += sum wq (E/2 du^2 - b u)
+__global__ __launch_bounds__(kBlockL) void bar_energy_kernel(const double *__restrict__ grid,
+                                                            const double *__restrict__ u, int n,
+                                                            const double *__restrict__ xq,
+                                                            const double *__restrict__ wq,
+                                                            const double *__restrict__ bq, int64_t npts,
+                                                            double E, double *__restrict__ loss,
+                                                            double *__restrict__ ggrid,
+                                                            double *__restrict__ gu) {
+    __shared__ double red[kBlockL / 64];
+    double loc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < npts; q += stride) {
+        const Hat t = hat_eval(grid, n, xq[q]);
+        const double ui = u[t.e], uj = u[t.e + 1], w = wq[q], b = bq[q];
+        const double uu = ui * t.N1 + uj * t.N2, du = (uj - ui) / t.h;
+        loc += w * (0.5 * E * du * du - b * uu);
+        const double gdu = w * E * du, guq = -w * b;
+        if (gu) {
+            unsafeAtomicAdd(&gu[t.e], guq * t.N1 - gdu / t.h);
+            unsafeAtomicAdd(&gu[t.e + 1], guq * t.N2 + gdu / t.h);
+        }
+        if (ggrid) hat_grid_grad(t, guq * ui, guq * uj, -gdu * du / t.h, ggrid);
+    }
+    const double tot = block_sum(loc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, tot);
+}
+
+// examples/example1.py:38: loss += mean((pred - target)^2) and its backward
+__global__ __launch_bounds__(kBlockL) void line2_mse_kernel(const double *__restrict__ grid,
+                                                           const double *__restrict__ u, int n,
+                                                           const double *__restrict__ x_eval,
+                                                           const double *__restrict__ target, int64_t m,
+                                                           double *__restrict__ loss,
+                                                           double *__restrict__ ggrid,
+                                                           double *__restrict__ gu) {
+    __shared__ double red[kBlockL / 64];
+    double loc = 0.0;
+    const double invm = 1.0 / (double)m;
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
+        const Hat t = hat_eval(grid, n, x_eval[q]);
+        const double ui = u[t.e], uj = u[t.e + 1];
+        const double diff = ui * t.N1 + uj * t.N2 - target[q];
+        loc += diff * diff;
+        const double g = 2.0 * diff * invm;
+        if (gu) {
+            unsafeAtomicAdd(&gu[t.e], g * t.N1);
+            unsafeAtomicAdd(&gu[t.e + 1], g * t.N2);
+        }
+        if (ggrid) hat_grid_grad(t, g * ui, g * uj, 0.0, ggrid);
+    }
+    const double tot = block_sum(loc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, tot * invm);
+}
+
+// ---- RECT-Q4 ---------------------------------------------------------------
+struct Q4 {
+    Hat x, y;
+    double u00, u10, u01, u11;
+};
+__device__ __forceinline__ Q4 q4_eval(const double *__restrict__ gx, int nx, const double *__restrict__ gy,
+                                      int ny, const double *__restrict__ u, double2 pt) {
+    Q4 c;
+    c.x = hat_eval(gx, nx, pt.x);
+    c.y = hat_eval(gy, ny, pt.y);
+    const int64_t b = (int64_t)c.x.e * ny + c.y.e;
+    c.u00 = u[b]; c.u01 = u[b + 1]; c.u10 = u[b + ny]; c.u11 = u[b + ny + 1];   // models.py:197-200
+    return c;
+}
+__device__ __forceinline__ double q4_value(const Q4 &c) {   // models.py:210
+    return c.x.N1 * c.y.N1 * c.u00 + c.x.N2 * c.y.N1 * c.u10 + c.x.N1 * c.y.N2 * c.u01 + c.x.N2 * c.y.N2 * c.u11;
+}
+__device__ __forceinline__ void q4_backward(const Q4 &c, double g, int ny, double *__restrict__ ggx,
+                                            double *__restrict__ ggy, double *__restrict__ gu,
+                                            double2 *gpt) {
+    if (gu) {
+        const int64_t b = (int64_t)c.x.e * ny + c.y.e;
+        unsafeAtomicAdd(&gu[b], g * c.x.N1 * c.y.N1);
+        unsafeAtomicAdd(&gu[b + ny], g * c.x.N2 * c.y.N1);
+        unsafeAtomicAdd(&gu[b + 1], g * c.x.N1 * c.y.N2);
+        unsafeAtomicAdd(&gu[b + ny + 1], g * c.x.N2 * c.y.N2);
+    }
+    const double gN1x = g * (c.y.N1 * c.u00 + c.y.N2 * c.u01), gN2x = g * (c.y.N1 * c.u10 + c.y.N2 * c.u11);
+    const double gN1y = g * (c.x.N1 * c.u00 + c.x.N2 * c.u10), gN2y = g * (c.x.N1 * c.u01 + c.x.N2 * c.u11);
+    if (ggx) hat_grid_grad(c.x, gN1x, gN2x, 0.0, ggx);
+    if (ggy) hat_grid_grad(c.y, gN1y, gN2y, 0.0, ggy);
+    if (gpt) *gpt = make_double2((gN2x - gN1x) / c.x.h, (gN2y - gN1y) / c.y.h);
+}
+
+__global__ __launch_bounds__(kBlockL) void rectq4_eval_fwd_kernel(const double *__restrict__ gx, int nx,
+                                                                 const double *__restrict__ gy, int ny,
+                                                                 const double *__restrict__ u,
+                                                                 const double2 *__restrict__ x_eval, int64_t m,
+                                                                 double *__restrict__ pred) {
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride)
+        pred[q] = q4_value(q4_eval(gx, nx, gy, ny, u, x_eval[q]));
+}
+
+__global__ __launch_bounds__(kBlockL) void rectq4_eval_bwd_kernel(
+    const double *__restrict__ gx, int nx, const double *__restrict__ gy, int ny, const double *__restrict__ u,
+    const double2 *__restrict__ x_eval, int64_t m, const double *__restrict__ cot, double *__restrict__ ggx,
+    double *__restrict__ ggy, double *__restrict__ gu, double2 *__restrict__ gx_eval) {
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
+        const Q4 c = q4_eval(gx, nx, gy, ny, u, x_eval[q]);
+        double2 gpt;
+        q4_backward(c, cot[q], ny, ggx, ggy, gu, gx_eval ? &gpt : nullptr);
+        if (gx_eval) gx_eval[q] = gpt;
+    }
+}
+
+__global__ __launch_bounds__(kBlockL) void rectq4_mse_kernel(
+    const double *__restrict__ gx, int nx, const double *__restrict__ gy, int ny, const double *__restrict__ u,
+    const double2 *__restrict__ x_eval, const double *__restrict__ target, int64_t m, double *__restrict__ loss,
+    double *__restrict__ ggx, double *__restrict__ ggy, double *__restrict__ gu) {
+    __shared__ double red[kBlockL / 64];
+    double loc = 0.0;
+    const double invm = 1.0 / (double)m;
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
+        const Q4 c = q4_eval(gx, nx, gy, ny, u, x_eval[q]);
+        const double diff = q4_value(c) - target[q];
+        loc += diff * diff;
+        q4_backward(c, 2.0 * diff * invm, ny, ggx, ggy, gu, nullptr);
+    }
+    const double tot = block_sum(loc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, tot * invm);
+}
+
+static int grid_l(int64_t n) {
+    int64_t g = (n + kBlockL - 1) / kBlockL;
+    return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+
+}  // namespace hfem
+
+using namespace hfem;
+
+#define HFEM_N_CHECK(n) HFEM_ARG_CHECK((n) >= 2 && (n) < (1ll << 31), "need 2 <= n < 2^31 grid nodes")
+
+extern "C" int hfem_grid_param_fwd(int device, const double *p, int64_t n, double x0, double xN,
+                                   const uint8_t *mask, const double *initial, double *grid, void *stream) {
+    HFEM_ARG_CHECK(p && grid && n >= 1, "null pointer / empty increments");
+    HFEM_ARG_CHECK(!mask || initial, "mask given without initial grid");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(grid_param_fwd_kernel, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask,
+                       initial, grid);
+    return launch_status("hfem_grid_param_fwd");
+}
+
+extern "C" int hfem_grid_param_bwd(int device, const double *p, int64_t n, double x0, double xN,
+                                   const uint8_t *mask, const double *ggrid, double *gp, void *stream) {
+    HFEM_ARG_CHECK(p && ggrid && gp && n >= 1, "null pointer / empty increments");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(grid_param_bwd_kernel, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask,
+                       ggrid, gp);
+    return launch_status("hfem_grid_param_bwd");
+}
+
+extern "C" int hfem_line2_eval_fwd(int device, const double *grid, const double *u, int64_t n,
+                                   const double *x_eval, int64_t m, double *pred, double *dudx, void *stream) {
+    HFEM_N_CHECK(n);
+    HFEM_ARG_CHECK(m >= 0, "negative point count");
+    if (m == 0) return 0;
+    HFEM_ARG_CHECK(grid && u && x_eval && (pred || dudx), "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(line2_eval_fwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u,
+                       (int)n, x_eval, m, pred, dudx);
+    return launch_status("hfem_line2_eval_fwd");
+}
+
+extern "C" int hfem_line2_eval_bwd(int device, const double *grid, const double *u, int64_t n,
+                                   const double *x_eval, int64_t m, const double *cot, const double *cot_dudx,
+                                   double *ggrid, double *gu, double *gx_eval, void *stream) {
+    HFEM_N_CHECK(n);
+    HFEM_ARG_CHECK(m >= 0, "negative point count");
+    if (m == 0) return 0;
+    HFEM_ARG_CHECK(grid && u && x_eval && (cot || cot_dudx), "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(line2_eval_bwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u,
+                       (int)n, x_eval, m, cot, cot_dudx, ggrid, gu, gx_eval);
+    return launch_status("hfem_line2_eval_bwd");
+}
+
+extern "C" int hfem_bar_energy(int device, const double *grid, const double *u, int64_t n, const double *xq,
+                               const double *wq, const double *bq, int64_t npts, double E, double *loss_acc,
+                               double *ggrid, double *gu, void *stream) {
+    HFEM_N_CHECK(n);
+    HFEM_ARG_CHECK(npts >= 0, "negative point count");
+    if (npts == 0) return 0;
+    HFEM_ARG_CHECK(grid && u && xq && wq && bq && loss_acc, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(bar_energy_kernel, dim3(grid_l(npts)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u,
+                       (int)n, xq, wq, bq, npts, E, loss_acc, ggrid, gu);
+    return launch_status("hfem_bar_energy");
+}
+
+extern "C" int hfem_line2_mse(int device, const double *grid, const double *u, int64_t n, const double *x_eval,
+                              const double *target, int64_t m, double *loss_acc, double *ggrid, double *gu,
+                              void *stream) {
+    HFEM_N_CHECK(n);
+    HFEM_ARG_CHECK(m >= 1, "need at least one point (mean of an empty set)");
+    HFEM_ARG_CHECK(grid && u && x_eval && target && loss_acc, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(line2_mse_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u, (int)n,
+                       x_eval, target, m, loss_acc, ggrid, gu);
+    return launch_status("hfem_line2_mse");
+}
+
+extern "C" int hfem_rectq4_eval_fwd(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
+                                    const double *u, const double *x_eval, int64_t m, double *pred,
+                                    void *stream) {
+    HFEM_N_CHECK(nx);
+    HFEM_N_CHECK(ny);
+    HFEM_ARG_CHECK(m >= 0, "negative point count");
+    if (m == 0) return 0;
+    HFEM_ARG_CHECK(gx && gy && u && x_eval && pred, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(rectq4_eval_fwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx,
+                       (int)nx, gy, (int)ny, u, (const double2 *)x_eval, m, pred);
+    return launch_status("hfem_rectq4_eval_fwd");
+}
+
+extern "C" int hfem_rectq4_eval_bwd(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
+                                    const double *u, const double *x_eval, int64_t m, const double *cot,
+                                    double *ggx, double *ggy, double *gu, double *gx_eval, void *stream) {
+    HFEM_N_CHECK(nx);
+    HFEM_N_CHECK(ny);
+    HFEM_ARG_CHECK(m >= 0, "negative point count");
+    if (m == 0) return 0;
+    HFEM_ARG_CHECK(gx && gy && u && x_eval && cot, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(rectq4_eval_bwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx,
+                       (int)nx, gy, (int)ny, u, (const double2 *)x_eval, m, cot, ggx, ggy, gu,
+                       (double2 *)gx_eval);
+    return launch_status("hfem_rectq4_eval_bwd");
+}
+
+extern "C" int hfem_rectq4_mse(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
+                               const double *u, const double *x_eval, const double *target, int64_t m,
+                               double *loss_acc, double *ggx, double *ggy, double *gu, void *stream) {
+    HFEM_N_CHECK(nx);
+    HFEM_N_CHECK(ny);
+    HFEM_ARG_CHECK(m >= 1, "need at least one point (mean of an empty set)");
+    HFEM_ARG_CHECK(gx && gy && u && x_eval && target && loss_acc, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(rectq4_mse_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx, (int)nx, gy,
+                       (int)ny, u, (const double2 *)x_eval, target, m, loss_acc, ggx, ggy, gu);
+    return launch_status("hfem_rectq4_mse");
+}
+
+extern "C" int hfem_version(void) { return HFEM_VERSION; }
+extern "C" const char *hfem_last_error(void) { return hfem::get_error(); }
+extern "C" int hfem_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : -1;
+}

@@ -1,0 +1,256 @@
+// Host-side owner-computes tiling of a TRI3 mesh (no HIP calls in this file).
+//
+// Input is the reference's mesh contract (connectivity [Ne][3] int64,
+// neumann_edges [E][2] int64; /root/reference/src/mesh.py:261-276) plus the
+// free/fixed row maps that replace the bool-mask assembly of
+// /root/reference/src/models.py:292-305.  Output is the tile plan the fused
+// energy kernel walks (layout: hfem_common.h, DESIGN.md "Data layout").
+//
+//  1. elements are sorted along a Morton curve of their centroids and cut into
+//     tiles of `tile_elems` consecutive elements (the tile's HOME elements);
+//  2. a node is OWNED by the lowest-numbered tile among its adjacent elements'
+//     home tiles (nodes without elements go to extra element-less tiles);
+//  3. a tile evaluates home elements + HALO elements (other tiles' elements that
+//     touch one of its owned nodes): every contribution to an owned node is
+//     produced inside the owning tile, so gradient rows need no atomics;
+//  4. a Neumann edge is evaluated by the owner tiles of its two nodes; its work
+//     is counted by the owner of its first node.
+//
+// The local order of an element's three nodes is never changed (the reference
+// energy depends on it).
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "hfem_common.h"
+
+namespace hfem {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *get_error() { return g_err.c_str(); }
+
+namespace {
+
+inline uint32_t spread16(uint32_t v) {   // 16 bits -> every other bit of 32
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+void morton_order(const int64_t *conn, int64_t ne, int64_t nn, const double *xy,
+                  std::vector<int32_t> &order) {
+    order.resize(ne);
+    if (!xy || ne == 0) {
+        std::iota(order.begin(), order.end(), 0);
+        return;
+    }
+    double lo[2] = {std::numeric_limits<double>::max(), std::numeric_limits<double>::max()};
+    double hi[2] = {-lo[0], -lo[1]};
+    for (int64_t n = 0; n < nn; ++n)
+        for (int a = 0; a < 2; ++a) {
+            const double v = xy[2 * n + a];
+            if (v == v) { lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+        }
+    // one isotropic scale: keeps Morton cells square on non-square domains
+    const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
+    const double scale = 65535.0 / span;
+    std::vector<uint64_t> keys(ne);
+    for (int64_t e = 0; e < ne; ++e) {
+        double c[2] = {0, 0};
+        for (int k = 0; k < 3; ++k) {
+            const int64_t n = conn[3 * e + k];
+            c[0] += xy[2 * n];
+            c[1] += xy[2 * n + 1];
+        }
+        uint32_t q[2];
+        for (int a = 0; a < 2; ++a) {
+            double v = (c[a] / 3.0 - lo[a]) * scale;
+            if (!(v > 0)) v = 0;
+            if (v > 65535.0) v = 65535.0;
+            q[a] = (uint32_t)v;
+        }
+        const uint64_t code = spread16(q[0]) | (spread16(q[1]) << 1);
+        keys[e] = (code << 32) | (uint64_t)(uint32_t)e;   // ties: element id (stable)
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int64_t p = 0; p < ne; ++p) order[p] = (int32_t)(keys[p] & 0xFFFFFFFFu);
+}
+
+constexpr int kOrphanTileNodes = 512;
+
+// returns 0 ok, 1 = a tile exceeded kMaxLocal nodes (retry smaller), -1 error
+int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
+              const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T,
+              const std::vector<int32_t> &order, HostPlan &P) {
+    const int32_t nt_main = (int32_t)((ne + T - 1) / T);
+    std::vector<int32_t> owner(nn, std::numeric_limits<int32_t>::max());
+    for (int64_t p = 0; p < ne; ++p) {
+        const int32_t t = (int32_t)(p / T);
+        const int64_t e = order[p];
+        for (int k = 0; k < 3; ++k) {
+            int32_t &o = owner[conn[3 * e + k]];
+            if (t < o) o = t;
+        }
+    }
+    int64_t n_orphan = 0;
+    for (int64_t n = 0; n < nn; ++n)
+        if (owner[n] == std::numeric_limits<int32_t>::max())
+            owner[n] = nt_main + (int32_t)(n_orphan++ / kOrphanTileNodes);
+    const int32_t nt = nt_main + (int32_t)((n_orphan + kOrphanTileNodes - 1) / kOrphanTileNodes);
+
+    // node -> element adjacency (CSR), elements listed in sorted-position order
+    std::vector<int64_t> adj_ptr(nn + 1, 0);
+    for (int64_t e = 0; e < ne; ++e)
+        for (int k = 0; k < 3; ++k) adj_ptr[conn[3 * e + k] + 1]++;
+    for (int64_t n = 0; n < nn; ++n) adj_ptr[n + 1] += adj_ptr[n];
+    std::vector<int32_t> adj(adj_ptr[nn]);
+    {
+        std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
+        for (int64_t p = 0; p < ne; ++p) {
+            const int32_t e = order[p];
+            for (int k = 0; k < 3; ++k) adj[fill[conn[3 * e + k]]++] = e;
+        }
+    }
+    // home tile of every element
+    std::vector<int32_t> home(ne);
+    for (int64_t p = 0; p < ne; ++p) home[order[p]] = (int32_t)(p / T);
+
+    // owned nodes per tile (ascending node id), edges per tile
+    std::vector<int64_t> own_ptr(nt + 1, 0), edg_ptr(nt + 1, 0);
+    for (int64_t n = 0; n < nn; ++n) own_ptr[owner[n] + 1]++;
+    for (int64_t g = 0; g < ned; ++g) {
+        const int32_t ti = owner[edges[2 * g]], tj = owner[edges[2 * g + 1]];
+        edg_ptr[ti + 1]++;
+        if (tj != ti) edg_ptr[tj + 1]++;
+    }
+    for (int32_t t = 0; t < nt; ++t) { own_ptr[t + 1] += own_ptr[t]; edg_ptr[t + 1] += edg_ptr[t]; }
+    std::vector<int32_t> own(nn), tedge(edg_ptr[nt]);
+    {
+        std::vector<int64_t> f(own_ptr.begin(), own_ptr.end() - 1);
+        for (int64_t n = 0; n < nn; ++n) own[f[owner[n]]++] = (int32_t)n;
+        std::vector<int64_t> fe(edg_ptr.begin(), edg_ptr.end() - 1);
+        for (int64_t g = 0; g < ned; ++g) {
+            const int32_t ti = owner[edges[2 * g]], tj = owner[edges[2 * g + 1]];
+            tedge[fe[ti]++] = (int32_t)g;
+            if (tj != ti) tedge[fe[tj]++] = (int32_t)g;
+        }
+    }
+
+    P = HostPlan();
+    P.ne = ne; P.nn = nn; P.ned = ned; P.tile_elems = T;
+    P.tiles.resize(nt);
+    P.elem_pack.reserve(ne + ne / 4);
+    P.elem_gid.reserve(ne + ne / 4);
+    P.node_src.reserve(2 * (nn + nn / 3));
+
+    std::vector<int32_t> stamp_e(ne, -1), stamp_n(nn, -1), lid(nn, 0);
+    std::vector<int32_t> telems, halo;
+    for (int32_t t = 0; t < nt; ++t) {
+        TileDesc &d = P.tiles[t];
+        d = TileDesc();
+        telems.clear();
+        halo.clear();
+        // elements: home first (sorted order), then halo in discovery order
+        if (t < nt_main) {
+            const int64_t p0 = (int64_t)t * T, p1 = std::min<int64_t>(ne, p0 + T);
+            for (int64_t p = p0; p < p1; ++p) { stamp_e[order[p]] = t; telems.push_back(order[p]); }
+        }
+        const int64_t o0 = own_ptr[t], o1 = own_ptr[t + 1];
+        for (int64_t i = o0; i < o1; ++i) {
+            const int32_t n = own[i];
+            for (int64_t a = adj_ptr[n]; a < adj_ptr[n + 1]; ++a) {
+                const int32_t e = adj[a];
+                if (stamp_e[e] != t) { stamp_e[e] = t; telems.push_back(e); }
+            }
+        }
+        // local nodes: owned first
+        int32_t nloc = 0;
+        for (int64_t i = o0; i < o1; ++i) { stamp_n[own[i]] = t; lid[own[i]] = nloc++; }
+        d.n_owned = nloc;
+        for (int32_t e : telems)
+            for (int k = 0; k < 3; ++k) {
+                const int32_t n = (int32_t)conn[3 * (int64_t)e + k];
+                if (stamp_n[n] != t) { stamp_n[n] = t; halo.push_back(n); }
+            }
+        for (int64_t i = edg_ptr[t]; i < edg_ptr[t + 1]; ++i)
+            for (int k = 0; k < 2; ++k) {
+                const int32_t n = (int32_t)edges[2 * (int64_t)tedge[i] + k];
+                if (stamp_n[n] != t) { stamp_n[n] = t; halo.push_back(n); }
+            }
+        std::sort(halo.begin(), halo.end());
+        for (int32_t n : halo) lid[n] = nloc++;
+        if (nloc > kMaxLocal) return 1;
+
+        d.elem_off = (int32_t)P.elem_pack.size();
+        d.n_elem = (int32_t)telems.size();
+        d.node_off = (int32_t)(P.node_src.size() / 2);
+        d.n_node = nloc;
+        d.edge_off = (int32_t)P.edge_pack.size();
+        d.n_edge = (int32_t)(edg_ptr[t + 1] - edg_ptr[t]);
+        for (int32_t e : telems) {
+            const uint32_t l0 = lid[conn[3 * (int64_t)e]], l1 = lid[conn[3 * (int64_t)e + 1]],
+                           l2 = lid[conn[3 * (int64_t)e + 2]];
+            P.elem_pack.push_back(l0 | (l1 << kLocalBits) | (l2 << (2 * kLocalBits)) |
+                                  (home[e] == t ? kHomeBit : 0u));
+            P.elem_gid.push_back(e);
+        }
+        auto push_node = [&](int32_t n) {
+            P.node_src.push_back(x_src ? x_src[n] : n);
+            P.node_src.push_back(u_src ? u_src[n] : n);
+        };
+        for (int64_t i = o0; i < o1; ++i) push_node(own[i]);
+        for (int32_t n : halo) push_node(n);
+        for (int64_t i = edg_ptr[t]; i < edg_ptr[t + 1]; ++i) {
+            const int32_t g = tedge[i];
+            const int64_t ni = edges[2 * (int64_t)g], nj = edges[2 * (int64_t)g + 1];
+            P.edge_pack.push_back((uint32_t)lid[ni] | ((uint32_t)lid[nj] << kLocalBits) |
+                                  (owner[ni] == t ? kHomeBit : 0u));
+            P.edge_gid.push_back(g);
+        }
+        P.max_nodes = std::max(P.max_nodes, d.n_node);
+        P.max_owned = std::max(P.max_owned, d.n_owned);
+        P.max_elems = std::max(P.max_elems, d.n_elem);
+        P.max_edges = std::max(P.max_edges, d.n_edge);
+    }
+    if (P.elem_pack.size() > (size_t)std::numeric_limits<int32_t>::max() ||
+        P.node_src.size() / 2 > (size_t)std::numeric_limits<int32_t>::max()) {
+        set_error("plan: tile arrays exceed int32 offsets");
+        return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
+                    const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
+                    int64_t ned, int32_t tile_elems, HostPlan &out) {
+    if (ne < 0 || nn < 0 || ned < 0 || nn > std::numeric_limits<int32_t>::max() ||
+        ne > std::numeric_limits<int32_t>::max() || ned > std::numeric_limits<int32_t>::max()) {
+        set_error("plan: sizes must be in [0, 2^31)");
+        return -1;
+    }
+    if ((ne > 0 && !conn) || (ned > 0 && !edges)) { set_error("plan: null connectivity/edges"); return -1; }
+    for (int64_t i = 0; i < 3 * ne; ++i)
+        if (conn[i] < 0 || conn[i] >= nn) { set_error("plan: connectivity index out of range"); return -1; }
+    for (int64_t i = 0; i < 2 * ned; ++i)
+        if (edges[i] < 0 || edges[i] >= nn) { set_error("plan: edge index out of range"); return -1; }
+    if (tile_elems <= 0) tile_elems = 1024;
+    if (tile_elems > 4096) tile_elems = 4096;
+
+    std::vector<int32_t> order;
+    morton_order(conn, ne, nn, coords, order);
+    for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
+        const int rc = try_build(conn, ne, nn, x_src, u_src, edges, ned, T, order, out);
+        if (rc <= 0) return rc;
+    }
+    set_error("plan: could not fit a tile into 1024 local nodes (node valence too high?)");
+    return -1;
+}
+
+}  // namespace hfem

@@ -1,0 +1,145 @@
+"""Energy / L2 losses with the reference's API over the fused HIP kernels.
+
+``EnergyLoss2D`` keeps the constructor, attributes and call signature of
+``/root/reference/src/loss.py:6-116``; ``loss_fn(model)`` is ONE tiled kernel launch
+(+ a tiny reduction) that yields the scalar and the gradients w.r.t.
+``model.node_coords_free`` and ``model.u_free``.  The inline losses of examples 1-3
+(``examples/example1.py:38``, ``example2.py:46``, ``example3.py:27-70``) are provided as
+library functions with fused kernels.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import ops
+from .utils import interval_gauss_points, triangle_gauss_points
+
+HFEM_FLAG_NO_EDGES = 4
+
+
+class EnergyLoss2D:
+    def __init__(self, E: float = 10e9, nu: float = 0.3, length: float = 1.0, height: float = 1.0,
+                 gauss_order: int = 4, gauss_order_1d: int = 2, device: Optional[torch.device] = None,
+                 dtype: torch.dtype = torch.float32, tile_elems: int = 0):
+        self.E, self.nu = E, nu
+        self.length, self.height = length, height          # stored, never read (as upstream, F9)
+        self.gauss_order, self.gauss_order_1d = gauss_order, gauss_order_1d
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.dtype = dtype
+        self.tile_elems = tile_elems
+        factor = E / (1 - nu ** 2)
+        self.C = torch.tensor([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, (1.0 - nu) / 2.0]],
+                              dtype=dtype, device=self.device) * factor          # loss.py:29-32
+        self.xg, self.wg = triangle_gauss_points(order=gauss_order, device=self.device, dtype=dtype)
+        self.ng = self.xg.shape[0]
+        self.xg_1d, self.wg_1d = interval_gauss_points(order=gauss_order_1d, device=self.device, dtype=dtype)
+        self.ng1 = self.xg_1d.shape[0]
+        # host copies of the constants the kernel takes by value (no D2H sync per call)
+        Cc = self.C.detach().cpu().double()
+        self._mat = [Cc[0, 0].item(), Cc[0, 1].item(), Cc[1, 1].item(), Cc[2, 2].item()]
+        self._W = float(self.wg.detach().cpu().double().sum())
+        xg1, wg1 = self.xg_1d.detach().cpu().double(), self.wg_1d.detach().cpu().double()
+        self._ci, self._cj = float((wg1 * (1.0 - xg1)).sum()), float((wg1 * xg1).sum())
+
+    # ---- default forces (loss.py:43-51)
+    def uniform_body_force(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.zeros_like(x)
+
+    def uniform_edge_force(self, x: torch.Tensor, L: float = 1.0, F_total: float = 100e3) -> torch.Tensor:
+        t_x = torch.full((x.shape[0],), F_total / L, device=x.device, dtype=x.dtype)
+        return torch.stack([t_x, torch.zeros_like(t_x)], dim=1)
+
+    # ---- tables handed to the kernel instead of Python callables
+    def _body_table(self, b_force):
+        """B_k = sum_q w_q N_k(xi_q) b(xi_q) with b at the REFERENCE points (loss.py:60,80; F6)."""
+        if b_force is None:
+            return [0.0] * 6
+        xg = self.xg
+        b = b_force(xg).to(torch.float64)
+        w, x = self.wg.to(torch.float64), xg.to(torch.float64)
+        N = torch.stack([x[:, 0], x[:, 1], 1.0 - x[:, 0] - x[:, 1]], dim=1)
+        return torch.einsum("q,qk,qi->ki", w, N, b).reshape(-1).cpu().tolist()
+
+    def _traction(self, model, t_force):
+        """Constant table {c_i t, c_j t} for the default traction, else per-edge
+        {T_i, T_j} = sum_q w_q {(1-xi_q), xi_q} t(x_q) with raw Legendre xi (loss.py:96-106; F3)."""
+        if t_force is None:
+            t = [100e3 / 1.0, 0.0]                                     # uniform_edge_force defaults
+            return None, [self._ci * t[0], self._ci * t[1], self._cj * t[0], self._cj * t[1]]
+        with torch.no_grad():
+            x_i, x_j = model.nm_edges[:]
+            xg1 = self.xg_1d.to(x_i.dtype)
+            xq = (1.0 - xg1[None, :, None]) * x_i[:, None, :] + xg1[None, :, None] * x_j[:, None, :]
+            tq = t_force(xq.reshape(-1, 2)).reshape(x_i.shape[0], self.ng1, 2).to(torch.float64)
+            w1, x1 = self.wg_1d.to(torch.float64), self.xg_1d.to(torch.float64)
+            Ti = torch.einsum("q,eqi->ei", w1 * (1.0 - x1), tq)
+            Tj = torch.einsum("q,eqi->ei", w1 * x1, tq)
+            return torch.cat([Ti, Tj], dim=1).contiguous(), None
+
+    def _edge_nodes_free(self, model):
+        if model.neumann_edges is None or model.N_edges == 0:
+            return False
+        return bool(model.free_mask[model.neumann_edges.reshape(-1)].any().item())
+
+    def _fused(self, model, b_force, T_edge, Tconst, flags, tile_range=(0, -1)):
+        plan = model.tile_plan(self.tile_elems)
+        return ops.Tri3EnergyFn.apply(model.node_coords_free, model.u_free,
+                                      model.node_coords_fixed.to(model.dtype), model.u_fixed_rows(), plan,
+                                      self._mat, self._W, self._body_table(b_force), T_edge, Tconst,
+                                      tile_range, flags)
+
+    # ---- reference API
+    def domain_energy(self, model, b_force: Optional[Callable] = None) -> torch.Tensor:
+        """loss.py:55-88 (strain energy minus body work), fused."""
+        return self._fused(model, b_force, None, [0.0] * 4, HFEM_FLAG_NO_EDGES)
+
+    def edge_energy(self, model, t_force: Optional[Callable] = None) -> torch.Tensor:
+        """loss.py:91-110 through the unfused edge forward; differentiable in everything,
+        including a position-dependent traction (edges are O(sqrt(Ne)): negligible)."""
+        x_i, x_j = model.nm_edges[:]
+        n_edges, dev = model.N_edges, x_i.device
+        xg1, wg1 = self.xg_1d.to(device=dev, dtype=x_i.dtype), self.wg_1d.to(device=dev, dtype=x_i.dtype)
+        xq = (1.0 - xg1[None, :, None]) * x_i[:, None, :] + xg1[None, :, None] * x_j[:, None, :]
+        xq_flat = xq.reshape(-1, 2)
+        wq_flat = wg1[None, :].expand(n_edges, self.ng1).reshape(-1)
+        x_eval = xg1[None, :].expand(n_edges, self.ng1).reshape(-1, 1).contiguous()
+        edge_id = torch.repeat_interleave(torch.arange(n_edges, device=dev), repeats=self.ng1)
+        u_edge, ds = model(x_eval, edge_id, edge=True)
+        t_edge = t_force(xq_flat) if t_force is not None else self.uniform_edge_force(xq_flat)
+        return torch.sum((u_edge * t_edge).sum(dim=1) * (wq_flat * ds))
+
+    def __call__(self, model, b_force=None, t_force=None) -> torch.Tensor:
+        """Total potential = domain - edge (loss.py:113-116), one fused launch."""
+        if model.neumann_edges is None or model.N_edges == 0:
+            return self._fused(model, b_force, None, [0.0] * 4, HFEM_FLAG_NO_EDGES)
+        if t_force is not None and model.node_coords_free.requires_grad and self._edge_nodes_free(model):
+            # traction depends on points that move with free nodes: keep autograd through t_force
+            return self.domain_energy(model, b_force) - self.edge_energy(model, t_force)
+        T_edge, Tconst = self._traction(model, t_force)
+        return self._fused(model, b_force, T_edge, Tconst, 0)
+
+
+# ---------------------------------------------------------------- inline losses of examples 1-3
+def l2_projection_loss(model, x_eval, target):
+    """``((model(x) - target)**2).mean()`` of examples/example1.py:38 as one fused launch
+    (1D model) or examples/example2.py:46 (structured 2D model)."""
+    if hasattr(model, "Nx"):
+        gx, gy = model.grid
+        return ops.RectQ4MseFn.apply(gx, gy, model.u_full, x_eval, target)
+    return ops.Line2MseFn.apply(model.grid, model.u_full, x_eval, target)
+
+
+def bar_energy_loss(model, xi, wi, b_force, E, L=None):
+    """1D bar total potential of examples/example3.py:27-70:
+    ``sum_q wq (E/2 (du/dx)^2 - b(xq) u(xq))`` with quadrature points and weights built
+    from the *detached* grid (the reference computes them under ``no_grad``)."""
+    grid = model.grid
+    with torch.no_grad():
+        g = grid.detach()
+        x_i, x_j = g[:-1].unsqueeze(1), g[1:].unsqueeze(1)
+        xq = 0.5 * (x_j - x_i) * xi + 0.5 * (x_j + x_i)
+        wq = 0.5 * (x_j - x_i) * wi
+        bq = b_force(xq)
+    return ops.BarEnergyFn.apply(grid, model.u_full, xq, wq, bq, float(E))

@@ -1,0 +1,350 @@
+"""``torch.autograd.Function`` wrappers over the C ABI (``include/hidenn_fem.h``).
+
+PyTorch tensors are only the container (device memory, streams, autograd
+bookkeeping); every number is produced by a hand-written gfx950 kernel.  All
+kernels compute in fp64; fp32 callers are widened on the way in and narrowed on
+the way out.  Nothing here runs on CPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_gpu_tensor, stream_ptr, dev_index
+
+F64 = torch.float64
+
+
+def _f64(t, name):
+    """Contiguous fp64 ROCm tensor view/copy of ``t`` (raises for CPU tensors)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        require_gpu_tensor(t, name, dtype=None)
+    t = t.detach()
+    if t.dtype != F64:
+        t = t.to(F64)
+    return t.contiguous()
+
+
+def _dvec(vals):
+    return (C.c_double * len(vals))(*[float(v) for v in vals])
+
+
+# ---------------------------------------------------------------- fused TRI3 + EDGE2 energy
+class Tri3EnergyFn(torch.autograd.Function):
+    """loss = sum_elem A (W psi - beta) - sum_edge ds m, with d/dx_free and d/du_free.
+
+    One pass over the tile plan produces the scalar and both *unit* gradients
+    (stashed on ctx); backward only scales them by the upstream gradient.
+    Replaces EnergyLoss2D.__call__ + autograd (reference src/loss.py:113-116)."""
+
+    @staticmethod
+    def forward(ctx, x_free, u_free, x_fixed, u_fixed, plan, mat, W, Bk, T_edge, Tconst, tile_range, flags):
+        dev = x_free.device
+        xf, uf = _f64(x_free, "node_coords_free"), _f64(u_free, "u_free")
+        xfix, ufix = _f64(x_fixed, "node_coords_fixed"), _f64(u_fixed, "u_fixed")
+        need_gx = ctx.needs_input_grad[0] and not (flags & 1)
+        need_gu = ctx.needs_input_grad[1] and not (flags & 2)
+        loss = torch.empty((), dtype=F64, device=dev)
+        # rows owned by tiles outside tile_range are not written -> start from zeros then
+        lo, hi = tile_range
+        full = (lo == 0 and hi in (-1, plan.n_tiles))
+        alloc = torch.empty_like if full else torch.zeros_like
+        gx = alloc(xf) if need_gx else None
+        gu = alloc(uf) if need_gu else None
+        fl = (flags & ~3) | (0 if need_gx else 1) | (0 if need_gu else 2)
+        te = _f64(T_edge, "T_edge")
+        rc = _lib.lib().hfem_tri3_energy_plan(
+            plan.handle, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix), _dvec(mat), float(W), _dvec(Bk),
+            ptr(te), None if Tconst is None else _dvec(Tconst), int(lo), int(hi), ptr(loss), ptr(gx), ptr(gu),
+            int(fl), stream_ptr(dev))
+        check(rc, "hfem_tri3_energy_plan")
+        ctx.unit = (gx, gu)
+        ctx.dtypes = (x_free.dtype, u_free.dtype)
+        return loss.to(x_free.dtype) if x_free.dtype != F64 else loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gx, gu = ctx.unit
+        g64 = g.to(F64)
+        out_x = None if gx is None else (gx * g64).to(ctx.dtypes[0])
+        out_u = None if gu is None else (gu * g64).to(ctx.dtypes[1])
+        return (out_x, out_u) + (None,) * 10
+
+
+# ---------------------------------------------------------------- free/fixed row assembly
+class AssembleRowsFn(torch.autograd.Function):
+    """full[idx_free] = free ; full[idx_fixed] = fixed   (reference src/models.py:292-305,
+    with precomputed int32 index lists instead of bool masks -> no aten::nonzero per call)."""
+
+    @staticmethod
+    def forward(ctx, free, fixed, idx_free, idx_fixed, n_rows):
+        dev = free.device
+        f = _f64(free, "free rows")
+        out = torch.zeros((n_rows, f.shape[1]), dtype=F64, device=dev)
+        L = _lib.lib()
+        check(L.hfem_scatter_rows(dev_index(dev), ptr(f), ptr(idx_free), f.shape[0], f.shape[1], ptr(out),
+                                  stream_ptr(dev)), "hfem_scatter_rows")
+        if fixed is not None and fixed.shape[0] > 0:
+            fx = _f64(fixed, "fixed rows")
+            check(L.hfem_scatter_rows(dev_index(dev), ptr(fx), ptr(idx_fixed), fx.shape[0], fx.shape[1], ptr(out),
+                                      stream_ptr(dev)), "hfem_scatter_rows")
+        ctx.save_for_backward(idx_free)
+        ctx.shape, ctx.dt = f.shape, free.dtype
+        return out.to(free.dtype) if free.dtype != F64 else out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (idx_free,) = ctx.saved_tensors
+        g64 = _f64(g, "grad")
+        out = torch.empty(ctx.shape, dtype=F64, device=g.device)
+        check(_lib.lib().hfem_gather_rows(dev_index(g.device), ptr(g64), ptr(idx_free), ctx.shape[0], ctx.shape[1],
+                                          ptr(out), stream_ptr(g.device)), "hfem_gather_rows")
+        return out.to(ctx.dt), None, None, None, None
+
+
+# ---------------------------------------------------------------- unfused per-point TRI3 / EDGE2
+class Tri3EvalFn(torch.autograd.Function):
+    """(u_h, detJ, grad_u) at reference points of given elements; reference src/models.py:316-357."""
+
+    @staticmethod
+    def forward(ctx, X, U, conn32, x_eval, elem_id):
+        dev = X.device
+        Xd, Ud, xe = _f64(X, "coords"), _f64(U, "u_full"), _f64(x_eval, "x_eval")
+        eid = require_gpu_tensor(elem_id.contiguous(), "elem_id", torch.int64)
+        m = eid.shape[0]
+        u_h = torch.empty((m, 2), dtype=F64, device=dev)
+        detJ = torch.empty((m,), dtype=F64, device=dev)
+        grad_u = torch.empty((m, 2, 2), dtype=F64, device=dev)
+        check(_lib.lib().hfem_tri3_eval_fwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid), m,
+                                            ptr(u_h), ptr(detJ), ptr(grad_u), stream_ptr(dev)), "hfem_tri3_eval_fwd")
+        ctx.save_for_backward(Xd, Ud, conn32, xe, eid)
+        ctx.dt = X.dtype
+        if X.dtype != F64:
+            return u_h.to(X.dtype), detJ.to(X.dtype), grad_u.to(X.dtype)
+        return u_h, detJ, grad_u
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, cu, cd, cg):
+        Xd, Ud, conn32, xe, eid = ctx.saved_tensors
+        dev = Xd.device
+        gX, gU = torch.zeros_like(Xd), torch.zeros_like(Ud)
+        cu, cd, cg = _f64(cu, "cu"), _f64(cd, "cd"), _f64(cg, "cg")
+        check(_lib.lib().hfem_tri3_eval_bwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid),
+                                            eid.shape[0], ptr(cu), ptr(cd), ptr(cg), ptr(gX), ptr(gU),
+                                            stream_ptr(dev)), "hfem_tri3_eval_bwd")
+        return gX.to(ctx.dt), gU.to(ctx.dt), None, None, None
+
+
+class Edge2EvalFn(torch.autograd.Function):
+    """(u_h, ds) on Neumann edges; reference src/models.py:359-376."""
+
+    @staticmethod
+    def forward(ctx, X, U, edges32, xi, edge_id):
+        dev = X.device
+        Xd, Ud, xd = _f64(X, "coords"), _f64(U, "u_full"), _f64(xi.reshape(-1), "xi")
+        eid = require_gpu_tensor(edge_id.contiguous(), "edge_id", torch.int64)
+        m = eid.shape[0]
+        u_h = torch.empty((m, 2), dtype=F64, device=dev)
+        ds = torch.empty((m,), dtype=F64, device=dev)
+        check(_lib.lib().hfem_edge2_eval_fwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(edges32), ptr(xd), ptr(eid), m,
+                                             ptr(u_h), ptr(ds), stream_ptr(dev)), "hfem_edge2_eval_fwd")
+        ctx.save_for_backward(Xd, Ud, edges32, xd, eid)
+        ctx.dt = X.dtype
+        return (u_h.to(X.dtype), ds.to(X.dtype)) if X.dtype != F64 else (u_h, ds)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, cu, cds):
+        Xd, Ud, edges32, xd, eid = ctx.saved_tensors
+        dev = Xd.device
+        gX, gU = torch.zeros_like(Xd), torch.zeros_like(Ud)
+        check(_lib.lib().hfem_edge2_eval_bwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(edges32), ptr(xd), ptr(eid),
+                                             eid.shape[0], ptr(_f64(cu, "cu")), ptr(_f64(cds, "cds")), ptr(gX),
+                                             ptr(gU), stream_ptr(dev)), "hfem_edge2_eval_bwd")
+        return gX.to(ctx.dt), gU.to(ctx.dt), None, None, None
+
+
+# ---------------------------------------------------------------- 1D / structured grids
+class GridParamFn(torch.autograd.Function):
+    """increments p[n] -> grid[n+1] = {x0, x0 + (xN-x0) cumsum(clamp(softplus p))/S}, optionally
+    ``where(mask, initial, grid)``; reference src/models.py:45-56, 146-168."""
+
+    @staticmethod
+    def forward(ctx, p, x0, xN, mask_u8, initial):
+        dev = p.device
+        pd = _f64(p, "increments")
+        n = pd.shape[0]
+        grid = torch.empty((n + 1,), dtype=F64, device=dev)
+        init = _f64(initial, "initial grid")
+        check(_lib.lib().hfem_grid_param_fwd(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8),
+                                             ptr(init), ptr(grid), stream_ptr(dev)), "hfem_grid_param_fwd")
+        ctx.save_for_backward(pd)
+        ctx.mask, ctx.x0, ctx.xN, ctx.dt = mask_u8, float(x0), float(xN), p.dtype
+        return grid.to(p.dtype) if p.dtype != F64 else grid
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        (pd,) = ctx.saved_tensors
+        dev = pd.device
+        gp = torch.empty_like(pd)
+        check(_lib.lib().hfem_grid_param_bwd(dev_index(dev), ptr(pd), pd.shape[0], ctx.x0, ctx.xN, ptr(ctx.mask),
+                                             ptr(_f64(gg, "ggrid")), ptr(gp), stream_ptr(dev)), "hfem_grid_param_bwd")
+        return gp.to(ctx.dt), None, None, None, None
+
+
+class Line2EvalFn(torch.autograd.Function):
+    """(u(x), du/dx(x)) by hat-function interpolation; reference src/models.py:70-90.
+
+    ``du/dx`` is an explicit differentiable output.  The reference obtains it with
+    ``autograd.grad(u, xq, create_graph=True)`` (examples/example3.py:56); that call still
+    works here: under ``create_graph`` the input gradient is re-expressed through this
+    Function's differentiable ``du/dx`` output."""
+
+    @staticmethod
+    def forward(ctx, grid, u_full, x_eval):
+        dev = grid.device
+        gd, ud, xd = _f64(grid, "grid"), _f64(u_full, "u_full"), _f64(x_eval.reshape(-1), "x_eval")
+        m = xd.shape[0]
+        pred = torch.empty((m,), dtype=F64, device=dev)
+        dudx = torch.empty((m,), dtype=F64, device=dev)
+        check(_lib.lib().hfem_line2_eval_fwd(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), m, ptr(pred),
+                                             ptr(dudx), stream_ptr(dev)), "hfem_line2_eval_fwd")
+        ctx.save_for_backward(grid, u_full, x_eval)
+        ctx.dt = grid.dtype
+        shp = x_eval.shape
+        pred, dudx = pred.reshape(shp), dudx.reshape(shp)
+        return (pred.to(grid.dtype), dudx.to(grid.dtype)) if grid.dtype != F64 else (pred, dudx)
+
+    @staticmethod
+    def backward(ctx, g_pred, g_dudx):
+        grid, u_full, x_eval = ctx.saved_tensors
+        dev = grid.device
+        gd, ud, xd = _f64(grid, "grid"), _f64(u_full, "u_full"), _f64(x_eval.reshape(-1), "x_eval")
+        m = xd.shape[0]
+        ggrid, gu = torch.zeros_like(gd), torch.zeros_like(ud)
+        gx = torch.empty_like(xd) if ctx.needs_input_grad[2] else None
+        cp = None if g_pred is None else _f64(g_pred.reshape(-1), "g_pred")
+        cdd = None if g_dudx is None else _f64(g_dudx.reshape(-1), "g_dudx")
+        if cp is None and cdd is None:
+            return None, None, None
+        check(_lib.lib().hfem_line2_eval_bwd(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), m, ptr(cp),
+                                             ptr(cdd), ptr(ggrid), ptr(gu), ptr(gx), stream_ptr(dev)),
+              "hfem_line2_eval_bwd")
+        gxe = None
+        if gx is not None:
+            if torch.is_grad_enabled() and g_pred is not None:
+                # create_graph=True: keep d(u)/d(x_eval) = g * du/dx connected to grid and u
+                with torch.enable_grad():
+                    _, d = Line2EvalFn.apply(grid, u_full, x_eval.detach())
+                gxe = g_pred * d
+            else:
+                gxe = gx.reshape(x_eval.shape).to(x_eval.dtype)
+        return ggrid.to(ctx.dt), gu.to(u_full.dtype), gxe
+
+
+class BarEnergyFn(torch.autograd.Function):
+    """Fused sum_q wq (E/2 (du/dx)^2 - b(xq) u(xq)) with detached xq,wq (reference
+    examples/example3.py:27-70): one launch gives the loss and d/dgrid, d/du."""
+
+    @staticmethod
+    def forward(ctx, grid, u_full, xq, wq, bq, E):
+        dev = grid.device
+        gd, ud = _f64(grid, "grid"), _f64(u_full, "u_full")
+        xqd, wqd, bqd = (_f64(t.reshape(-1), n) for t, n in ((xq, "xq"), (wq, "wq"), (bq, "bq")))
+        loss = torch.zeros((), dtype=F64, device=dev)
+        ggrid, gu = torch.zeros_like(gd), torch.zeros_like(ud)
+        check(_lib.lib().hfem_bar_energy(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xqd), ptr(wqd), ptr(bqd),
+                                         xqd.shape[0], float(E), ptr(loss), ptr(ggrid), ptr(gu), stream_ptr(dev)),
+              "hfem_bar_energy")
+        ctx.unit, ctx.dts = (ggrid, gu), (grid.dtype, u_full.dtype)
+        return loss.to(grid.dtype) if grid.dtype != F64 else loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        ggrid, gu = ctx.unit
+        g64 = g.to(F64)
+        return (ggrid * g64).to(ctx.dts[0]), (gu * g64).to(ctx.dts[1]), None, None, None, None
+
+
+class Line2MseFn(torch.autograd.Function):
+    """Fused mean((u(x) - target)^2) + backward; reference examples/example1.py:38."""
+
+    @staticmethod
+    def forward(ctx, grid, u_full, x_eval, target):
+        dev = grid.device
+        gd, ud = _f64(grid, "grid"), _f64(u_full, "u_full")
+        xd, td = _f64(x_eval.reshape(-1), "x_eval"), _f64(target.reshape(-1), "target")
+        loss = torch.zeros((), dtype=F64, device=dev)
+        ggrid, gu = torch.zeros_like(gd), torch.zeros_like(ud)
+        check(_lib.lib().hfem_line2_mse(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), ptr(td), xd.shape[0],
+                                        ptr(loss), ptr(ggrid), ptr(gu), stream_ptr(dev)), "hfem_line2_mse")
+        ctx.unit, ctx.dts = (ggrid, gu), (grid.dtype, u_full.dtype)
+        return loss.to(grid.dtype) if grid.dtype != F64 else loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        ggrid, gu = ctx.unit
+        g64 = g.to(F64)
+        return (ggrid * g64).to(ctx.dts[0]), (gu * g64).to(ctx.dts[1]), None, None
+
+
+class RectQ4EvalFn(torch.autograd.Function):
+    """Bilinear interpolation on the tensor-product grid; reference src/models.py:180-212."""
+
+    @staticmethod
+    def forward(ctx, gx, gy, u_full, x_eval):
+        dev = gx.device
+        gxd, gyd, ud, xd = _f64(gx, "grid_x"), _f64(gy, "grid_y"), _f64(u_full, "u_full"), _f64(x_eval, "x_eval")
+        m = xd.shape[0]
+        pred = torch.empty((m,), dtype=F64, device=dev)
+        check(_lib.lib().hfem_rectq4_eval_fwd(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
+                                              ptr(xd), m, ptr(pred), stream_ptr(dev)), "hfem_rectq4_eval_fwd")
+        ctx.save_for_backward(gxd, gyd, ud, xd)
+        ctx.dts = (gx.dtype, gy.dtype, u_full.dtype, x_eval.dtype)
+        return pred.to(u_full.dtype) if u_full.dtype != F64 else pred
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gxd, gyd, ud, xd = ctx.saved_tensors
+        dev = gxd.device
+        ggx, ggy, gu = torch.zeros_like(gxd), torch.zeros_like(gyd), torch.zeros_like(ud)
+        gxe = torch.empty_like(xd) if ctx.needs_input_grad[3] else None
+        check(_lib.lib().hfem_rectq4_eval_bwd(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
+                                              ptr(xd), xd.shape[0], ptr(_f64(g, "grad")), ptr(ggx), ptr(ggy), ptr(gu),
+                                              ptr(gxe), stream_ptr(dev)), "hfem_rectq4_eval_bwd")
+        d = ctx.dts
+        return ggx.to(d[0]), ggy.to(d[1]), gu.to(d[2]), None if gxe is None else gxe.to(d[3])
+
+
+class RectQ4MseFn(torch.autograd.Function):
+    """Fused mean((u_h(x) - target)^2) + backward; reference examples/example2.py:45-46."""
+
+    @staticmethod
+    def forward(ctx, gx, gy, u_full, x_eval, target):
+        dev = gx.device
+        gxd, gyd, ud = _f64(gx, "grid_x"), _f64(gy, "grid_y"), _f64(u_full, "u_full")
+        xd, td = _f64(x_eval, "x_eval"), _f64(target.reshape(-1), "target")
+        loss = torch.zeros((), dtype=F64, device=dev)
+        ggx, ggy, gu = torch.zeros_like(gxd), torch.zeros_like(gyd), torch.zeros_like(ud)
+        check(_lib.lib().hfem_rectq4_mse(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
+                                         ptr(xd), ptr(td), xd.shape[0], ptr(loss), ptr(ggx), ptr(ggy), ptr(gu),
+                                         stream_ptr(dev)), "hfem_rectq4_mse")
+        ctx.unit, ctx.dts = (ggx, ggy, gu), (gx.dtype, gy.dtype, u_full.dtype)
+        return loss.to(u_full.dtype) if u_full.dtype != F64 else loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        g64 = g.to(F64)
+        return tuple((t * g64).to(dt) for t, dt in zip(ctx.unit, ctx.dts)) + (None, None)

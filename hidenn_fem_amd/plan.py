@@ -1,0 +1,111 @@
+"""Host handle of the owner-computes tile plan (``hfem_plan_*`` in the C ABI).
+
+A plan is built once per mesh (and per device) from the reference's mesh tensors
+(``connectivity`` int64 ``[Ne,3]``, ``neumann_edges`` int64 ``[E,2]``;
+``/root/reference/src/models.py:252,281``) plus the free/fixed row maps that
+replace the bool-mask assembly of ``models.py:292-305``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5}
+
+
+def _np(a, dtype):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def row_maps(free_mask: np.ndarray):
+    """Bool mask -> int32 map n -> (row in the free array) or (-1 - row in the fixed array)."""
+    free_mask = np.asarray(free_mask, dtype=bool)
+    src = np.empty(free_mask.shape[0], dtype=np.int32)
+    src[free_mask] = np.arange(int(free_mask.sum()), dtype=np.int32)
+    src[~free_mask] = -1 - np.arange(int((~free_mask).sum()), dtype=np.int32)
+    return src
+
+
+class TilePlan:
+    """Owner-computes tiling of a TRI3 mesh.  ``device=None`` -> host-only plan
+    (no HIP call; what the CPU tests inspect)."""
+
+    def __init__(self, connectivity, n_nodes: int, coords_hint=None, x_src=None, u_src=None,
+                 edges=None, tile_elems: int = 0, device: Optional[torch.device] = None):
+        conn = _np(connectivity, np.int64).reshape(-1, 3)
+        hint = _np(coords_hint, np.float64)
+        xs, us = _np(x_src, np.int32), _np(u_src, np.int32)
+        ed = _np(edges, np.int64)
+        ed = None if ed is None else ed.reshape(-1, 2)
+        if hint is not None and hint.shape != (n_nodes, 2):
+            raise ValueError("coords_hint must be [n_nodes, 2]")
+        for m in (xs, us):
+            if m is not None and m.shape != (n_nodes,):
+                raise ValueError("x_src / u_src must be [n_nodes]")
+        self.device = device
+        self.n_nodes, self.n_elems = int(n_nodes), int(conn.shape[0])
+        self.n_edges = 0 if ed is None else int(ed.shape[0])
+        self._h = C.c_void_p()
+        dev = -1 if device is None else _lib.dev_index(device)
+
+        def p(a):
+            return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+
+        rc = _lib.lib().hfem_plan_create(dev, p(conn), self.n_elems, self.n_nodes, p(hint), p(xs), p(us),
+                                         p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
+        _lib.check(rc, "hfem_plan_create")
+        st = _lib.PlanStats()
+        _lib.check(_lib.lib().hfem_plan_get_stats(self._h, C.byref(st)), "hfem_plan_get_stats")
+        self.stats = st.as_dict()
+        self.n_tiles = self.stats["n_tiles"]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def export(self, name: str) -> np.ndarray:
+        which = EXPORT_IDS[name]
+        n = _lib.lib().hfem_plan_export(self._h, which, None, 0)
+        if n < 0:
+            _lib.check(-1, "hfem_plan_export")
+        dt = np.uint32 if name in ("elem_pack", "edge_pack") else np.int32
+        out = np.empty(int(n), dtype=dt)
+        if n:
+            got = _lib.lib().hfem_plan_export(self._h, which, out.ctypes.data_as(C.c_void_p), n)
+            if got != n:
+                _lib.check(-1, "hfem_plan_export")
+        if name == "tile_desc":
+            out = out.reshape(-1, 8)
+        elif name == "node_src":
+            out = out.reshape(-1, 2)
+        return out
+
+    def shard_range(self, rank: int, world: int):
+        """Contiguous tile range of ``rank`` (tiles are Morton-ordered, so a range is a
+        spatially compact strip).  Balanced to within one tile."""
+        nt = self.n_tiles
+        lo = (nt * rank) // world
+        hi = (nt * (rank + 1)) // world
+        return lo, hi
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            try:
+                _lib.lib().hfem_plan_destroy(self._h)
+            finally:
+                self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,212 @@
+/* hidenn_fem.h -- C ABI of libhidenn_hip.so (MI355X / gfx950 HIP kernels for the
+ * HiDeNN-FEM element-evaluation + energy hot path).
+ *
+ * The reference (achraf-15/HiDeNN-FEM) is pure Python/PyTorch and has no FFI of
+ * its own; the boundary below is what a ctypes binding inside the reference's
+ * src/models.py / src/loss.py would call instead of its ATen op chains.  Each
+ * entry point cites the reference code it replaces (paths are relative to the
+ * reference repo root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every device buffer is allocated and owned
+ *     by the caller (torch tensors on the ROCm device), contiguous, 16-B aligned;
+ *   - every call takes the device ordinal and a hipStream_t (as void*); work is
+ *     enqueued on that stream, nothing synchronises, results are stream-ordered;
+ *   - return 0 = ok, <0 = argument error, >0 = hipError_t; message via
+ *     hfem_last_error() (thread-local).  No exceptions, no exit();
+ *   - degenerate elements are not errors: divisions by a tiny det / clamp(1e-10)
+ *     spans behave as in the reference and NaN/Inf propagate;
+ *   - dtype: fp64 (the parity contract of BASELINE.md);
+ *   - no thread-affine state: PyTorch runs backward on another thread.
+ */
+#ifndef HIDENN_FEM_H
+#define HIDENN_FEM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFEM_VERSION 100   /* 0.1.0 */
+
+int hfem_version(void);
+const char *hfem_last_error(void);
+/* number of HIP devices visible, or -1 (used by the loader to fail loudly) */
+int hfem_device_count(void);
+
+/* ------------------------------------------------------------------ TRI3 + EDGE2
+ * Plane-stress material: mat = {c11, c12, c22, c33} of C (src/loss.py:29-32).
+ * W  = sum_q w_q of the triangle rule (src/utils.py:13-81; 0.25 for the default
+ *      gauss_order=4).
+ * Bk = [3][2] body-force table  B_k = sum_q w_q N_k(xi_q) b(xi_q), b evaluated
+ *      at the REFERENCE points as src/loss.py:80 does (zeros by default).
+ * Traction: Tconst[4] = {c_i t, c_j t} with c_i = sum_q w_q (1-xi_q), c_j = sum_q
+ *      w_q xi_q over the raw Legendre nodes (src/loss.py:96-110), or a
+ *      per-edge table T[Ned][4] = {T_i, T_j} when t depends on the point.      */
+
+/* Planless variant: element-parallel, fp64 global atomics.  Replaces
+ * EnergyLoss2D.domain_energy + its autograd backward (src/loss.py:55-88,
+ * src/models.py:316-357) on ASSEMBLED arrays X,U [Nn][2].
+ * ACCUMULATES: loss_acc[0] += E_domain, gX += dE/dX, gU += dE/dU (caller zeroes).
+ * gX/gU may be NULL (forward only).  Elements [e_begin, e_end).               */
+int hfem_tri3_energy_atomic(int device, const double *X, const double *U,
+                            const int32_t *conn, int64_t e_begin, int64_t e_end, int64_t nn,
+                            const double mat[4], double W, const double Bk[6],
+                            double *loss_acc, double *gX, double *gU, void *stream);
+
+/* Planless Neumann-edge work; replaces EnergyLoss2D.edge_energy + backward
+ * (src/loss.py:91-110, src/models.py:359-376).  ACCUMULATES the NEGATIVE work:
+ * loss_acc[0] -= sum ds*m, gX/gU += d(-work).  edges [Ned][2] int32, i<j.     */
+int hfem_edge2_energy_atomic(int device, const double *X, const double *U,
+                             const int32_t *edges, int64_t ned, const double *T,
+                             const double Tconst[4], double *loss_acc, double *gX,
+                             double *gU, void *stream);
+
+/* Planned variant -- the fast path.  A plan is an owner-computes tiling of the
+ * mesh (host-side preprocessing, once per mesh): elements are Morton-sorted and
+ * cut into tiles; every node is owned by exactly one tile; a tile evaluates its
+ * home elements plus the halo elements that touch its owned nodes, with node
+ * data staged in LDS and gradients accumulated in LDS, so each gradient row is
+ * written exactly once with a plain store (no global atomics, no zero fill).
+ *
+ * It also fuses the free/fixed parameter assembly of src/models.py:292-305:
+ *   x_src[n] >= 0 -> coords of node n = x_free[x_src[n]]   (node_coords_free row)
+ *   x_src[n] <  0 -> coords of node n = x_fixed[-1-x_src[n]]
+ *   u_src likewise for u_free / u_fixed rows (Dirichlet rows).
+ * NULL maps mean identity (x_free = X, u_free = U are the full arrays).
+ * coords_hint [Nn][2] (host) is only used for the locality sort.
+ * device < 0 builds a host-only plan (no HIP call; for CPU tests).            */
+typedef struct hfem_plan hfem_plan;
+
+typedef struct hfem_plan_stats {
+    int64_t n_elems, n_nodes, n_edges;
+    int32_t n_tiles, tile_elems;          /* home elements per tile */
+    int64_t tile_elem_total;              /* home + halo elements over all tiles */
+    int64_t tile_node_total;              /* owned + halo local nodes over all tiles */
+    int32_t max_tile_nodes, max_tile_owned, max_tile_elems, max_tile_edges;
+    int64_t device_bytes;                 /* plan arrays resident in HBM */
+    int32_t lds_bytes;                    /* dynamic LDS per workgroup */
+} hfem_plan_stats;
+
+int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
+                     const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
+                     const int64_t *edges, int64_t ned, int32_t tile_elems,
+                     hfem_plan **out);
+int hfem_plan_destroy(hfem_plan *plan);
+int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
+/* Copy a host-side plan array out (for tests).  which: 0 tile_desc [n_tiles][8]
+ * i32, 1 elem_pack u32, 2 node_src [.][2] i32, 3 edge_pack u32, 4 edge_gid i32,
+ * 5 elem_gid i32 (global element id of every tile element).
+ * Returns the element count, or <0.  buf may be NULL to query the size.       */
+int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t cap_elems);
+
+#define HFEM_FLAG_NO_GX 1   /* do not write gx_free (nodes fixed / no r-adaptivity) */
+#define HFEM_FLAG_NO_GU 2   /* do not write gu_free */
+#define HFEM_FLAG_NO_EDGES 4 /* domain energy only (EnergyLoss2D.domain_energy, src/loss.py:55-88) */
+#define HFEM_FLAG_NO_LOSS_SUM 8 /* leave the per-tile partial energies unsummed, loss_out untouched
+                                   (gradient-only callers; bench.py's kernel-only roofline leg) */
+
+/* One fwd+bwd "element-eval" pass over tiles [tile_begin, tile_end):
+ *   loss_out[0]  = sum_elem A (W psi - beta)  -  sum_edge ds m        (OVERWRITTEN)
+ *   gx_free[r]   = dL/d node_coords_free[r]   for rows owned by those tiles (OVERWRITTEN)
+ *   gu_free[r]   = dL/d u_free[r]             likewise
+ * = EnergyLoss2D.__call__ + loss.backward() (src/loss.py:113-116) including the
+ * coords/u_full assembly and its backward.  Rows owned by tiles outside the range
+ * are not touched (element sharding).  tile_end = -1: all.   */
+int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                          const double *u_free, const double *u_fixed,
+                          const double mat[4], double W, const double Bk[6],
+                          const double *T_edge, const double Tconst[4],
+                          int32_t tile_begin, int32_t tile_end, double *loss_out,
+                          double *gx_free, double *gu_free, int32_t flags, void *stream);
+
+/* ------------------------------------------------------------------ per-point TRI3
+ * Unfused forward of src/models.py:316-357 on assembled X,U: u_h [M][2],
+ * detJ [M], grad_u [M][2][2] at reference points x_eval [M][2] of elements
+ * elem_id [M] (int64, the reference's dtype).                                  */
+int hfem_tri3_eval_fwd(int device, const double *X, const double *U, const int32_t *conn,
+                       const double *x_eval, const int64_t *elem_id, int64_t m,
+                       double *u_h, double *detJ, double *grad_u, void *stream);
+/* Backward of the above: cotangents cu [M][2], cd [M], cg [M][2][2] ->
+ * ACCUMULATES gX,gU [Nn][2] (fp64 atomics; caller zeroes).                    */
+int hfem_tri3_eval_bwd(int device, const double *X, const double *U, const int32_t *conn,
+                       const double *x_eval, const int64_t *elem_id, int64_t m,
+                       const double *cu, const double *cd, const double *cg,
+                       double *gX, double *gU, void *stream);
+/* Edge branch of src/models.py:359-376: u_h [M][2], ds [M]; and its backward. */
+int hfem_edge2_eval_fwd(int device, const double *X, const double *U, const int32_t *edges,
+                        const double *xi, const int64_t *edge_id, int64_t m,
+                        double *u_h, double *ds, void *stream);
+int hfem_edge2_eval_bwd(int device, const double *X, const double *U, const int32_t *edges,
+                        const double *xi, const int64_t *edge_id, int64_t m,
+                        const double *cu, const double *cds, double *gX, double *gU,
+                        void *stream);
+
+/* ------------------------------------------------------------------ row gather/scatter
+ * src/models.py:292-305 as index lists instead of bool-mask index_put (which
+ * runs aten::nonzero on every call): dst[idx[r]][0..w) = src[r][0..w).         */
+int hfem_scatter_rows(int device, const double *src, const int32_t *idx, int64_t rows,
+                      int32_t width, double *dst, void *stream);
+int hfem_gather_rows(int device, const double *src, const int32_t *idx, int64_t rows,
+                     int32_t width, double *dst, void *stream);
+
+/* ------------------------------------------------------------------ 1D / structured
+ * Grid parametrisation softplus -> clamp(1e-6) -> cumsum -> renormalise
+ * (src/models.py:45-56, 146-168): p[n] -> grid[n+1]; backward ggrid[n+1] -> gp[n].
+ * mask (uint8[n+1], may be NULL) + initial[n+1]: grid = where(mask, initial, grid)
+ * (src/models.py:165-166); masked entries get no gradient.                     */
+int hfem_grid_param_fwd(int device, const double *p, int64_t n, double x0, double xN,
+                        const uint8_t *mask, const double *initial, double *grid,
+                        void *stream);
+int hfem_grid_param_bwd(int device, const double *p, int64_t n, double x0, double xN,
+                        const uint8_t *mask, const double *ggrid, double *gp, void *stream);
+
+/* LINE2 hat-function interpolation, src/models.py:70-90: grid[n], u[n] full
+ * arrays, x_eval[m] physical points -> pred[m] and dudx[m] = (u_{e+1}-u_e)/h of the
+ * element e = clamp(searchsorted(grid,x)-1, 0, n-2) (either output may be NULL).
+ * dudx is the explicit, differentiable replacement for the reference's
+ * autograd.grad(u, xq, create_graph=True) (examples/example3.py:56).           */
+int hfem_line2_eval_fwd(int device, const double *grid, const double *u, int64_t n,
+                        const double *x_eval, int64_t m, double *pred, double *dudx,
+                        void *stream);
+/* Backward: cot[m] (d/dpred), cot_dudx[m] (d/d dudx, may be NULL) -> ACCUMULATES
+ * ggrid[n], gu[n]; writes gx_eval[m] (may be NULL).                            */
+int hfem_line2_eval_bwd(int device, const double *grid, const double *u, int64_t n,
+                        const double *x_eval, int64_t m, const double *cot,
+                        const double *cot_dudx, double *ggrid, double *gu, double *gx_eval,
+                        void *stream);
+/* Fused 1D bar energy of examples/example3.py:27-70 with detached quadrature
+ * (SURVEY F8): xq,wq,bq [npts] constants.  ONE launch; loss_acc[0], ggrid[n],
+ * gu[n] are all ACCUMULATED (caller zeroes; ggrid/gu may be NULL).              */
+int hfem_bar_energy(int device, const double *grid, const double *u, int64_t n,
+                    const double *xq, const double *wq, const double *bq, int64_t npts,
+                    double E, double *loss_acc, double *ggrid, double *gu, void *stream);
+/* Fused L2-projection loss mean((pred-target)^2) of examples/example1.py:38 with
+ * its backward in one launch: loss_acc, ggrid, gu ACCUMULATED (caller zeroes).  */
+int hfem_line2_mse(int device, const double *grid, const double *u, int64_t n,
+                   const double *x_eval, const double *target, int64_t m, double *loss_acc,
+                   double *ggrid, double *gu, void *stream);
+
+/* RECT-Q4 bilinear interpolation on the tensor-product grid, src/models.py:180-212:
+ * gx[nx], gy[ny], u[nx][ny] (u_full, i.e. after where(node_mask,u_fixed,u)),
+ * x_eval [m][2] physical -> pred[m].                                           */
+int hfem_rectq4_eval_fwd(int device, const double *gx, int64_t nx, const double *gy,
+                         int64_t ny, const double *u, const double *x_eval, int64_t m,
+                         double *pred, void *stream);
+/* Backward: cot[m] -> ACCUMULATES ggx[nx], ggy[ny], gu[nx][ny]; writes
+ * gx_eval[m][2] (may be NULL).                                                 */
+int hfem_rectq4_eval_bwd(int device, const double *gx, int64_t nx, const double *gy,
+                         int64_t ny, const double *u, const double *x_eval, int64_t m,
+                         const double *cot, double *ggx, double *ggy, double *gu,
+                         double *gx_eval, void *stream);
+/* Fused 2D L2-projection loss mean((pred-target)^2) of examples/example2.py:45-46
+ * with its backward in one launch: loss_acc, ggx, ggy, gu ACCUMULATED.         */
+int hfem_rectq4_mse(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
+                    const double *u, const double *x_eval, const double *target, int64_t m,
+                    double *loss_acc, double *ggx, double *ggy, double *gu, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIDENN_FEM_H */

@@ -1,0 +1,352 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the
+C ABI / host mirror, against (a) the golden vectors generated from the imported reference
+and (b) the oracle on larger seeded meshes.
+
+Tolerances (fp64): loss rel <= 1e-12, gradients
+max-abs <= 1e-10 * max|g|.  Index outputs and pure copies are bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import tri_mesh_dict, tri_case_forces
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-12
+GRAD_RTOL = 1e-10
+F64 = torch.float64
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def assert_grad_close(got, want, what=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    scale = max(np.abs(want).max(), 1e-300)
+    err = np.abs(got - want).max()
+    assert err <= GRAD_RTOL * scale, f"{what}: max-abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def tri_model_from_golden(g, case, device):
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    p = case + "/"
+    nc = g.t(p + "node_coords")
+    bmask = g.t(p + "boundary_mask")
+    model = PiecewiseLinearShapeNN2D(nc, g.t(p + "conn"), boundary_mask=bmask if bmask.any() else None,
+                                     dirichlet_mask=g.t(p + "dirichlet_mask"), u_fixed=0.0,
+                                     neumann_edges=g.t(p + "edges")).double().to(device)
+    with torch.no_grad():
+        model.u_free.copy_(g.t(p + "u_free").to(device))
+    return model
+
+
+def test_library_loaded_and_native():
+    from hidenn_fem_amd import _lib
+    L = _lib.lib()
+    assert L.hfem_version() == 100
+    assert L.hfem_device_count() >= 1
+
+
+def test_cpu_tensors_fail_loudly():
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+    m = PiecewiseLinearShapeNN(torch.linspace(0, 1, 5, dtype=F64)).double()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(3, dtype=F64))
+
+
+@pytest.mark.parametrize("tile_elems", [0, 32])
+def test_fused_energy_matches_reference_golden(g_tri, tile_elems):
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = dev()
+    for case in g_tri.cases():
+        model = tri_model_from_golden(g_tri, case, d)
+        go, go1 = (int(v) for v in g_tri[case + "/gauss_order"])
+        b, t = tri_case_forces(case)
+        loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=go, gauss_order_1d=go1, device=d, dtype=F64,
+                               tile_elems=tile_elems)
+        loss = loss_fn(model, b_force=b, t_force=t)
+        loss.backward()
+        want = g_tri[case + "/loss"].item()
+        assert abs(loss.item() - want) <= LOSS_RTOL * abs(want), (case, loss.item(), want)
+        assert_grad_close(model.u_free.grad, g_tri[case + "/g_u_free"], case + " gU")
+        assert_grad_close(model.node_coords_free.grad, g_tri[case + "/g_coords_free"], case + " gX")
+        # the two halves of the reference API
+        dom = loss_fn.domain_energy(model, b)
+        edg = loss_fn.edge_energy(model, t)
+        wd, we = g_tri[case + "/domain"].item(), g_tri[case + "/edge"].item()
+        assert abs(dom.item() - wd) <= LOSS_RTOL * abs(wd)
+        assert abs(edg.item() - we) <= LOSS_RTOL * max(abs(we), 1e-300)
+
+
+def test_unfused_forward_backward_matches_golden(g_tri):
+    d = dev()
+    case = "order4"
+    model = tri_model_from_golden(g_tri, case, d)
+    p = case + "/pp_"
+    x_eval, elem_id = g_tri.t(p + "x_eval").to(d), g_tri.t(p + "elem_id").to(d)
+    u_h, detJ, grad_u = model(x_eval, elem_id)
+    np.testing.assert_allclose(u_h.detach().cpu().numpy(), g_tri[p + "u_h"], rtol=1e-13, atol=1e-20)
+    np.testing.assert_allclose(detJ.detach().cpu().numpy(), g_tri[p + "detJ"], rtol=1e-13)
+    np.testing.assert_allclose(grad_u.detach().cpu().numpy(), g_tri[p + "grad_u"], rtol=1e-11, atol=1e-16)
+    ((u_h * g_tri.t(p + "cu").to(d)).sum() + (detJ * g_tri.t(p + "cd").to(d)).sum()
+     + (grad_u * g_tri.t(p + "cg").to(d)).sum()).backward()
+    assert_grad_close(model.u_free.grad, g_tri[p + "g_u_free"], "unfused gU")
+    assert_grad_close(model.node_coords_free.grad, g_tri[p + "g_coords_free"], "unfused gX")
+    q = case + "/pe_"
+    ue, ds = model(g_tri.t(q + "x_eval").to(d), g_tri.t(q + "edge_id").to(d), edge=True)
+    np.testing.assert_allclose(ue.detach().cpu().numpy(), g_tri[q + "u_h"], rtol=1e-13, atol=1e-20)
+    np.testing.assert_allclose(ds.detach().cpu().numpy(), g_tri[q + "ds"], rtol=1e-14)
+    # assembly is a pure copy: bit-exact
+    X = model.coords.detach().cpu().numpy()
+    assert np.array_equal(X, g_tri[case + "/node_coords"])
+
+
+def _random_problem(nx, ny, seed, **kw):
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(nx, ny, jitter=0.2, seed=seed, dtype=F64, **kw)
+    rng = np.random.default_rng(seed)
+    U = 1e-5 * rng.standard_normal((coords.shape[0], 2))
+    return coords.numpy(), U, conn.numpy(), edges.numpy()
+
+
+@pytest.mark.parametrize("nx,ny,kw", [(64, 33, {}), (301, 151, dict(diagonal="random", permute=True)),
+                                      (120, 90, dict(flip_fraction=0.3))])
+def test_atomic_and_tiled_kernels_vs_oracle(nx, ny, kw):
+    """C ABI called directly: planless atomic kernels and the tiled kernel (identity row maps)
+    against the plain-C closed forms on seeded meshes."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.plan import TilePlan
+    from oracle import closed_form as CF
+    d = dev()
+    X, U, conn, edges = _random_problem(nx, ny, seed=nx, **kw)
+    mat, W = CF.plane_stress(), 0.25
+    rng = np.random.default_rng(1)
+    Bk = rng.standard_normal(6) * 1e4
+    Tc = np.array([2e5, 0.0, 0.0, 1e4])
+    e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn, mat, W, Bk)
+    e_ref -= CF.edge2_energy(X, U, edges, Tconst=Tc, gX=gX_ref, gU=gU_ref)
+
+    L = _lib.lib()
+    s = _lib.stream_ptr(d)
+    Xd, Ud = torch.from_numpy(X).to(d), torch.from_numpy(U).to(d)
+    conn32 = torch.from_numpy(conn.astype(np.int32)).to(d)
+    edges32 = torch.from_numpy(edges.astype(np.int32)).to(d)
+    dv = lambda a: (C.c_double * len(a))(*a)
+    # --- planless atomics
+    loss = torch.zeros((), dtype=F64, device=d)
+    gX, gU = torch.zeros_like(Xd), torch.zeros_like(Ud)
+    _lib.check(L.hfem_tri3_energy_atomic(0, Xd.data_ptr(), Ud.data_ptr(), conn32.data_ptr(), 0, conn.shape[0],
+                                         X.shape[0], dv(mat), W, dv(Bk), loss.data_ptr(), gX.data_ptr(),
+                                         gU.data_ptr(), s))
+    _lib.check(L.hfem_edge2_energy_atomic(0, Xd.data_ptr(), Ud.data_ptr(), edges32.data_ptr(), edges.shape[0],
+                                          None, dv(Tc), loss.data_ptr(), gX.data_ptr(), gU.data_ptr(), s))
+    assert abs(loss.item() - e_ref) <= LOSS_RTOL * abs(e_ref)
+    assert_grad_close(gX, gX_ref, "atomic gX")
+    assert_grad_close(gU, gU_ref, "atomic gU")
+    # --- tiled, identity maps, several tile sizes; outputs are OVERWRITTEN (poison first)
+    for T in (0, 200):
+        plan = TilePlan(conn, X.shape[0], coords_hint=X, edges=edges, tile_elems=T, device=d)
+        loss2 = torch.full((), 7.0, dtype=F64, device=d)
+        gX2, gU2 = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv(Bk),
+                                           None, dv(Tc), 0, -1, loss2.data_ptr(), gX2.data_ptr(), gU2.data_ptr(),
+                                           0, s))
+        assert abs(loss2.item() - e_ref) <= LOSS_RTOL * abs(e_ref)
+        assert_grad_close(gX2, gX_ref, "tiled gX")
+        assert_grad_close(gU2, gU_ref, "tiled gU")
+        # element sharding: tile ranges are additive and write disjoint rows
+        acc_l, accX, accU = 0.0, torch.zeros_like(Xd), torch.zeros_like(Ud)
+        for r in range(3):
+            lo, hi = plan.shard_range(r, 3)
+            l3 = torch.zeros((), dtype=F64, device=d)
+            gX3, gU3 = torch.zeros_like(Xd), torch.zeros_like(Ud)
+            _lib.check(L.hfem_tri3_energy_plan(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W,
+                                               dv(Bk), None, dv(Tc), lo, hi, l3.data_ptr(), gX3.data_ptr(),
+                                               gU3.data_ptr(), 0, s))
+            assert int(((gX3 != 0).any(dim=1) & (accX != 0).any(dim=1)).sum()) == 0
+            acc_l += l3.item()
+            accX += gX3
+            accU += gU3
+        assert abs(acc_l - e_ref) <= LOSS_RTOL * abs(e_ref)
+        assert_grad_close(accX, gX_ref, "sharded gX")
+        assert_grad_close(accU, gU_ref, "sharded gU")
+        plan.close()
+
+
+def test_full_size_1m_elements_vs_oracle():
+    """BASELINE config 'Example 4 / T1M': 1001x501 nodes -> 1,000,000 TRI3, through the model API."""
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from oracle import closed_form as CF
+    d = dev()
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(1001, 501, jitter=0.2, seed=0, dtype=F64)
+    torch.manual_seed(0)
+    model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                     neumann_edges=edges).to(d)
+    loss_fn = EnergyLoss2D(device=d, dtype=F64)
+    loss = loss_fn(model)
+    loss.backward()
+    X = model.coords.detach().cpu().numpy()
+    U = model.u_full.detach().cpu().numpy()
+    e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn.numpy(), CF.plane_stress(), 0.25)
+    e_ref -= CF.edge2_energy(X, U, edges.numpy(), Tconst=np.array([2e5, 0, 0, 0]), gX=gX_ref, gU=gU_ref)
+    assert abs(loss.item() - e_ref) <= LOSS_RTOL * abs(e_ref)
+    assert_grad_close(model.node_coords_free.grad, gX_ref[~geom.numpy()], "1M gX")
+    assert_grad_close(model.u_free.grad, gU_ref[~bc.numpy()], "1M gU")
+    # idempotence: a second evaluation overwrites, never accumulates
+    model.zero_grad()
+    loss2 = loss_fn(model)
+    loss2.backward()
+    assert loss2.item() == loss.item() or abs(loss2.item() - loss.item()) <= 1e-13 * abs(loss.item())
+
+
+# ----------------------------------------------------------------------------- 1D
+def _line_model(g_line, p, device, r_adapt=True):
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+    bc = g_line[p + "bc"] if g_line.has(p + "bc") else np.array([np.nan, np.nan])
+    u0 = None if np.isnan(bc[0]) else float(bc[0])
+    uN = None if np.isnan(bc[1]) else float(bc[1])
+    m = PiecewiseLinearShapeNN(g_line.t(p + "x_grid"), r_adapt=r_adapt, u0=u0, uN=uN).double().to(device)
+    with torch.no_grad():
+        m.u.copy_(g_line.t(p + "u").to(device))
+        if r_adapt:
+            m.x_increments.copy_(g_line.t(p + "incr").to(device))
+    return m
+
+
+def test_line2_forward_backward_matches_golden(g_line):
+    d = dev()
+    for name in ("free", "dir0", "dirN", "dir"):
+        p = f"line_{name}/"
+        m = _line_model(g_line, p, d)
+        np.testing.assert_allclose(m.grid.detach().cpu().numpy(), g_line[p + "grid"], rtol=1e-14, atol=1e-15)
+        xe = g_line.t(p + "x_eval").to(d).requires_grad_(True)
+        pred = m(xe)
+        np.testing.assert_allclose(pred.detach().cpu().numpy(), g_line[p + "pred"], rtol=1e-12, atol=1e-16)
+        (pred * g_line.t(p + "cot").to(d)).sum().backward()
+        assert_grad_close(m.u.grad, g_line[p + "g_u"], name + " gu")
+        assert_grad_close(m.x_increments.grad, g_line[p + "g_incr"], name + " gincr")
+        assert_grad_close(xe.grad, g_line[p + "g_x_eval"], name + " gx_eval")
+
+
+def test_line2_fixed_nodes_float32_bc_quirk(g_line):
+    d = dev()
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+    p = "line_fixed/"
+    m = PiecewiseLinearShapeNN(g_line.t(p + "x_grid"), r_adapt=False, u0=0.1).double().to(d)
+    with torch.no_grad():
+        m.u.copy_(g_line.t(p + "u").to(d))
+    pred = m(g_line.t(p + "x_eval").to(d))
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g_line[p + "pred"], rtol=1e-12, atol=1e-16)
+    (pred * g_line.t(p + "cot").to(d)).sum().backward()
+    assert_grad_close(m.u.grad, g_line[p + "g_u"], "fixed gu")
+
+
+def test_example1_adam_trajectory_fused_mse(g_line):
+    """examples/example1.py:25-42 with the fused L2 kernel: first 20 Adam losses, fp64."""
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+    from hidenn_fem_amd.loss import l2_projection_loss
+    d = dev()
+    for r_adapt in (True, False):
+        xg = torch.linspace(0, 1, 100, dtype=F64, device=d)
+        xt = torch.linspace(0, 1, 1000, dtype=F64, device=d)
+        ut = torch.sin(2 * torch.pi * xt)
+        m = PiecewiseLinearShapeNN(xg, r_adapt=r_adapt).double().to(d)
+        opt = torch.optim.Adam(m.parameters(), lr=0.005)
+        got = []
+        for _ in range(20):
+            opt.zero_grad()
+            loss = l2_projection_loss(m, xt, ut)
+            loss.backward()
+            opt.step()
+            got.append(loss.item())
+        # Adam divides by sqrt(v)+eps with tiny early v: 1e-16 gradient noise is amplified
+        np.testing.assert_allclose(got, g_line[f"ex1_f64_r{int(r_adapt)}/adam_losses"], rtol=1e-9)
+        # unfused form of the same loss agrees with the fused kernel
+        l1 = ((m(xt) - ut) ** 2).mean()
+        l2 = l2_projection_loss(m, xt, ut)
+        assert abs(l1.item() - l2.item()) <= 1e-13 * abs(l1.item())
+
+
+def test_example3_bar_energy_fused_and_autograd_form(g_line):
+    from hidenn_fem_amd.loss import bar_energy_loss
+    from hidenn_fem_amd.utils import gauss_legendre_points_weights
+    from oracle import ref_chain as R
+    d = dev()
+    xi, wi = gauss_legendre_points_weights(2, device=d, dtype=F64)
+    for tag in ("n89", "n1001"):
+        p = f"ex3_{tag}/"
+        from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+        m = PiecewiseLinearShapeNN(g_line.t(p + "x_grid"), r_adapt=True, u0=0.0, uN=0.0).double().to(d)
+        with torch.no_grad():
+            m.u.copy_(g_line.t(p + "u").to(d))
+            m.x_increments.copy_(g_line.t(p + "incr").to(d))
+        loss = bar_energy_loss(m, xi, wi, R.example3_body_force, 175.0)
+        loss.backward()
+        want = g_line[p + "loss"].item()
+        assert abs(loss.item() - want) <= LOSS_RTOL * abs(want)
+        assert_grad_close(m.u.grad, g_line[p + "g_u"], tag + " gu")
+        assert_grad_close(m.x_increments.grad, g_line[p + "g_incr"], tag + " gincr")
+        # the reference's own formulation (autograd.grad(..., create_graph=True), example3.py:52-68)
+        m.zero_grad()
+        with torch.no_grad():
+            g = m.grid
+            x_i, x_j = g[:-1].unsqueeze(1), g[1:].unsqueeze(1)
+            xq = 0.5 * (x_j - x_i) * xi + 0.5 * (x_j + x_i)
+            wq = 0.5 * (x_j - x_i) * wi
+        xq.requires_grad_(True)
+        u = m(xq)
+        du = torch.autograd.grad(u, xq, grad_outputs=torch.ones_like(u), create_graph=True)[0]
+        loss2 = torch.sum(wq * (0.5 * 175.0 * du ** 2 - R.example3_body_force(xq) * u))
+        loss2.backward()
+        assert abs(loss2.item() - want) <= LOSS_RTOL * abs(want)
+        assert_grad_close(m.u.grad, g_line[p + "g_u"], tag + " gu (autograd form)")
+        assert_grad_close(m.x_increments.grad, g_line[p + "g_incr"], tag + " gincr (autograd form)")
+
+
+# ----------------------------------------------------------------------------- structured 2D
+def test_rectq4_forward_backward_matches_golden(g_rect):
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import l2_projection_loss
+    d = dev()
+    for case in g_rect.cases():
+        p = case + "/"
+        uf = g_rect[p + "u_fixed"][0]
+        r_adapt = bool(g_rect[p + "r_adapt"][0])
+        m = PiecewiseLinearShapeNN2D(grid_x=g_rect.t(p + "grid_x"), grid_y=g_rect.t(p + "grid_y"),
+                                     boundary_mask_x=g_rect.t(p + "mask_x"), boundary_mask_y=g_rect.t(p + "mask_y"),
+                                     r_adapt=r_adapt, u_fixed=None if np.isnan(uf) else float(uf)).double().to(d)
+        with torch.no_grad():
+            m.u.copy_(g_rect.t(p + "u").to(d))
+            if r_adapt:
+                m.increments_x.copy_(g_rect.t(p + "incr_x").to(d))
+                m.increments_y.copy_(g_rect.t(p + "incr_y").to(d))
+        gx, gy = m.grid
+        np.testing.assert_allclose(gx.detach().cpu().numpy(), g_rect[p + "gx_full"], rtol=1e-14, atol=1e-15)
+        np.testing.assert_allclose(gy.detach().cpu().numpy(), g_rect[p + "gy_full"], rtol=1e-14, atol=1e-15)
+        xe = g_rect.t(p + "x_eval").to(d).requires_grad_(True)
+        pred = m(xe)
+        np.testing.assert_allclose(pred.detach().cpu().numpy(), g_rect[p + "pred"], rtol=1e-12, atol=1e-15)
+        cot = g_rect.t(p + "cot").to(d)
+        (pred * cot).sum().backward()
+        assert_grad_close(m.u.grad, g_rect[p + "g_u"], case + " gu")
+        assert_grad_close(xe.grad, g_rect[p + "g_x_eval"], case + " gx_eval")
+        if r_adapt:
+            assert_grad_close(m.increments_x.grad, g_rect[p + "g_incr_x"], case + " gincr_x")
+            assert_grad_close(m.increments_y.grad, g_rect[p + "g_incr_y"], case + " gincr_y")
+        # fused MSE == unfused MSE (value and gradients)
+        target = torch.sin(xe.detach()[:, 0]) * torch.cos(xe.detach()[:, 1])
+        m.zero_grad()
+        la = ((m(xe.detach()) - target) ** 2).mean()
+        la.backward()
+        ga = m.u.grad.clone()
+        m.zero_grad()
+        lb = l2_projection_loss(m, xe.detach(), target)
+        lb.backward()
+        assert abs(la.item() - lb.item()) <= 1e-13 * abs(la.item())
+        assert_grad_close(m.u.grad, ga.cpu().numpy(), case + " fused mse gu")

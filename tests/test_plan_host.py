@@ -1,0 +1,171 @@
+"""Host logic of the owner-computes tile plan (C++ in libhidenn_hip.so, no GPU needed):
+partition invariants, and a numpy emulation of what the tiled kernel does with the plan
+arrays, checked against the oracle's full-mesh closed form."""
+import numpy as np
+import pytest
+import torch
+
+from hidenn_fem_amd.mesh import structured_tri_mesh, generate_mesh
+from hidenn_fem_amd.plan import TilePlan, row_maps
+from oracle import closed_form as CF
+
+MASK = 1023
+HOME = 1 << 30
+
+
+def decode(plan):
+    td = plan.export("tile_desc")
+    return dict(td=td, ep=plan.export("elem_pack"), ns=plan.export("node_src"),
+                gp=plan.export("edge_pack"), gg=plan.export("edge_gid"), eg=plan.export("elem_gid"))
+
+
+def check_invariants(conn, edges, nn, plan):
+    a = decode(plan)
+    td = a["td"]
+    ne = conn.shape[0]
+    owned_count = np.zeros(nn, dtype=int)
+    home_count = np.zeros(ne, dtype=int)
+    edge_home = np.zeros(edges.shape[0], dtype=int)
+    owner = -np.ones(nn, dtype=int)
+    for t, (eo, nel, no, nno, nown, go, ned, _) in enumerate(td):
+        assert 0 <= nown <= nno <= 1024
+        gids = a["ns"][no:no + nno, 0]                       # identity maps: x_src == global id
+        assert len(np.unique(gids)) == nno
+        owned_count[gids[:nown]] += 1
+        owner[gids[:nown]] = t
+        pk = a["ep"][eo:eo + nel]
+        loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1)
+        assert loc.max(initial=0) < max(nno, 1)
+        eg = a["eg"][eo:eo + nel]
+        # the local node ORDER of every element is preserved (reference energy depends on it, F4)
+        assert np.array_equal(gids[loc], conn[eg])
+        home_count[eg[(pk & HOME) != 0]] += 1
+        assert len(np.unique(eg)) == nel
+        gpk = a["gp"][go:go + ned]
+        gl = np.stack([gpk & MASK, (gpk >> 10) & MASK], axis=1)
+        geid = a["gg"][go:go + ned]
+        if ned:
+            assert np.array_equal(gids[gl], edges[geid])
+            edge_home[geid[(gpk & HOME) != 0]] += 1
+    assert (owned_count == 1).all(), "every node is owned by exactly one tile"
+    assert (home_count == 1).all(), "every element is counted by exactly one tile"
+    assert (edge_home == 1).all(), "every edge is counted by exactly one tile"
+    # completeness: a tile holds every element / edge that touches one of its owned nodes
+    for t, (eo, nel, no, nno, nown, go, ned, _) in enumerate(td):
+        eg = set(a["eg"][eo:eo + nel].tolist())
+        need = np.nonzero((owner[conn] == t).any(axis=1))[0]
+        assert set(need.tolist()) <= eg
+        if edges.shape[0]:
+            gneed = np.nonzero((owner[edges] == t).any(axis=1))[0]
+            assert set(gneed.tolist()) <= set(a["gg"][go:go + ned].tolist())
+    return a
+
+
+def emulate(a, X, U, mat, W, Bk, Tc):
+    """What tri3_energy_tiled_kernel computes, tile by tile, with the oracle as the per-element math."""
+    nn = X.shape[0]
+    gX, gU = np.full((nn, 2), np.nan), np.full((nn, 2), np.nan)
+    loss = 0.0
+    for (eo, nel, no, nno, nown, go, ned, _) in a["td"]:
+        gids = a["ns"][no:no + nno, 0]
+        pk = a["ep"][eo:eo + nel]
+        loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1).astype(np.int64)
+        Xl, Ul = X[gids], U[gids]
+        _, gxl, gul = CF.tri3_energy(Xl, Ul, loc, mat, W, Bk)
+        home = (pk & HOME) != 0
+        e_home, _, _ = CF.tri3_energy(Xl, Ul, loc[home], mat, W, Bk, grads=False)
+        loss += e_home
+        if ned:
+            gpk = a["gp"][go:go + ned]
+            gl = np.stack([gpk & MASK, (gpk >> 10) & MASK], axis=1).astype(np.int64)
+            CF.edge2_energy(Xl, Ul, gl, Tconst=Tc, gX=gxl, gU=gul)
+            loss -= CF.edge2_energy(Xl, Ul, gl[(gpk & HOME) != 0], Tconst=Tc)
+        gX[gids[:nown]] = gxl[:nown]
+        gU[gids[:nown]] = gul[:nown]
+    return loss, gX, gU
+
+
+MESHES = {
+    "small": dict(nx=9, ny=7, jitter=0.2, seed=1),
+    "permuted": dict(nx=33, ny=21, jitter=0.3, seed=3, diagonal="random", permute=True),
+    "strip": dict(nx=201, ny=5, jitter=0.1, seed=4, diagonal="zigzag"),
+    "flipped": dict(nx=40, ny=37, jitter=0.25, seed=5, flip_fraction=0.5),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MESHES))
+@pytest.mark.parametrize("tile_elems", [16, 100, 1024])
+def test_plan_invariants_and_emulation(name, tile_elems):
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(dtype=torch.float64, **MESHES[name])
+    X, conn, edges = coords.numpy(), conn.numpy(), edges.numpy()
+    nn = X.shape[0]
+    rng = np.random.default_rng(0)
+    U = 1e-3 * rng.standard_normal((nn, 2))
+    plan = TilePlan(conn, nn, coords_hint=X, edges=edges, tile_elems=tile_elems)
+    assert plan.stats["n_elems"] == conn.shape[0] and plan.stats["n_edges"] == edges.shape[0]
+    a = check_invariants(conn, edges, nn, plan)
+    mat, W = CF.plane_stress(), 0.25
+    Bk = rng.standard_normal(6) * 1e5
+    Tc = np.array([2e5, 0.0, 0.0, 1e4])
+    loss, gX, gU = emulate(a, X, U, mat, W, Bk, Tc)
+    e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn, mat, W, Bk)
+    e_ref -= CF.edge2_energy(X, U, edges, Tconst=Tc, gX=gX_ref, gU=gU_ref)
+    assert abs(loss - e_ref) <= 1e-12 * abs(e_ref)
+    assert not np.isnan(gX).any() and not np.isnan(gU).any(), "every gradient row written"
+    assert np.abs(gX - gX_ref).max() <= 1e-11 * np.abs(gX_ref).max()
+    assert np.abs(gU - gU_ref).max() <= 1e-11 * np.abs(gU_ref).max()
+
+
+def test_plan_without_hint_and_with_maps():
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(17, 11, jitter=0.1, seed=2, dtype=torch.float64)
+    nn = coords.shape[0]
+    xs, us = row_maps(~geom.numpy()), row_maps(~bc.numpy())
+    plan = TilePlan(conn, nn, coords_hint=None, x_src=xs, u_src=us, edges=edges, tile_elems=64)
+    ns = plan.export("node_src")
+    td = plan.export("tile_desc")
+    # owned rows over all tiles = every node once, carrying its map entries
+    owned = np.concatenate([ns[no:no + nown] for (_, _, no, _, nown, _, _, _) in td])
+    assert owned.shape[0] == nn
+    assert sorted(owned[:, 0].tolist()) == sorted(xs.tolist())
+    assert sorted(owned[:, 1].tolist()) == sorted(us.tolist())
+    assert (xs >= 0).sum() == int((~geom).sum()) and (us < 0).sum() == int(bc.sum())
+
+
+def test_plan_orphan_nodes_empty_mesh_and_holes():
+    # nodes that no element references still get a gradient row (zero): extra element-less tiles
+    coords, conn, *_ = structured_tri_mesh(5, 4, dtype=torch.float64)
+    nn = coords.shape[0] + 700
+    plan = TilePlan(conn, nn, coords_hint=None, tile_elems=16)
+    a = check_invariants(conn.numpy(), np.zeros((0, 2), dtype=np.int64), nn, plan)
+    assert (a["td"][:, 1] == 0).sum() >= 2          # >= 2 orphan tiles of <= 512 nodes
+    # empty mesh
+    plan0 = TilePlan(np.zeros((0, 3), dtype=np.int64), 3)
+    assert plan0.stats["n_tiles"] == 1 and plan0.stats["tile_elem_total"] == 0
+    # plate with holes from the reference-style mesher
+    nc, cn, geom, bc, mn, ed = generate_mesh(2.0, 1.0, nx=60, ny=30)
+    plan2 = TilePlan(cn, nc.shape[0], coords_hint=nc.double(), edges=ed, tile_elems=256)
+    check_invariants(cn.numpy(), ed.numpy(), nc.shape[0], plan2)
+
+
+def test_plan_rejects_bad_input():
+    with pytest.raises(RuntimeError, match="out of range"):
+        TilePlan(np.array([[0, 1, 5]], dtype=np.int64), 3)
+    with pytest.raises(RuntimeError, match="out of range"):
+        TilePlan(np.array([[0, 1, 2]], dtype=np.int64), 3, edges=np.array([[0, 7]], dtype=np.int64))
+
+
+def test_plan_retries_smaller_tiles_when_local_nodes_overflow():
+    # a long 1-cell-wide strip in natural (unsorted) order: 1024-element tiles would touch > 1024 nodes
+    coords, conn, *_ = structured_tri_mesh(3000, 2, dtype=torch.float64)
+    plan = TilePlan(conn, coords.shape[0], coords_hint=None, tile_elems=4096)
+    assert plan.stats["max_tile_nodes"] <= 1024
+    assert plan.stats["tile_elems"] < 4096
+
+
+def test_shard_ranges_cover_all_tiles():
+    coords, conn, *_ = structured_tri_mesh(50, 40, dtype=torch.float64)
+    plan = TilePlan(conn, coords.shape[0], coords_hint=coords, tile_elems=128)
+    for world in (1, 2, 3, 8):
+        r = [plan.shard_range(k, world) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == plan.n_tiles
+        assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))

@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--tile-elems", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
-    ap.add_argument("--cpu-evals", type=int, default=3)
+    ap.add_argument("--cpu-evals", type=int, default=2)
     return ap.parse_args()
 
 
@@ -55,7 +55,8 @@ def cpu_baseline(mesh6, u_free, n_evals):
     """oracle/ref_chain.py (the reference's ATen op chain + autograd) on the host cores."""
     from oracle import ref_chain as R
     coords, conn, geom, bc, mn, edges = mesh6
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); more threads than that only thrash
+    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     mesh = dict(n_nodes=coords.shape[0], conn=conn, free_mask=~geom, boundary_mask=geom,
                 coords_fixed=coords[geom], u_free_mask=~bc, dirichlet_mask=bc,

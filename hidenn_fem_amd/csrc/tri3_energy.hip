@@ -255,7 +255,8 @@ template <typename T>
 static int upload(T **dst, const void *src, size_t count, int64_t &bytes) {
     const size_t nb = std::max<size_t>(count, 1) * sizeof(T);
     HFEM_HIP_CHECK(hipMalloc((void **)dst, nb));
-    if (count) HFEM_HIP_CHECK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    if (count && src) HFEM_HIP_CHECK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    if (!src) HFEM_HIP_CHECK(hipMemset(*dst, 0, nb));
     bytes += (int64_t)nb;
     return 0;
 }

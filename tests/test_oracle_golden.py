@@ -113,10 +113,12 @@ def test_line2_forward_backward(g_line):
     p = "line_fixed/"
     xg = g_line.t(p + "x_grid")
     u = g_line.t(p + "u").requires_grad_(True)
-    pred = R.line2_forward(xg, _line_u_full(u, np.array([0.1, np.nan])), g_line.t(p + "x_eval"))
+    xe = g_line.t(p + "x_eval").requires_grad_(True)
+    pred = R.line2_forward(xg, _line_u_full(u, np.array([0.1, np.nan])), xe)
     assert np.array_equal(pred.detach().numpy(), g_line[p + "pred"])
     (pred * g_line.t(p + "cot")).sum().backward()
     np.testing.assert_allclose(u.grad.numpy(), g_line[p + "g_u"], rtol=1e-14, atol=1e-18)
+    np.testing.assert_allclose(xe.grad.numpy(), g_line[p + "g_x_eval"], rtol=1e-14, atol=1e-18)
 
 
 def test_example1_adam_trajectory(g_line):

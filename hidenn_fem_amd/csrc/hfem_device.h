@@ -64,6 +64,18 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return r;
 }
 
+// 1/x to ~1 ulp: hardware v_rcp_f64 seed + two Newton steps (4 FMAs) instead of the ~15-instruction
+// IEEE division sequence.  det of a non-degenerate element is far from the denormal range; for
+// det = 0 the result is inf/NaN like the division (NaN/Inf propagate, as upstream).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
 // One TRI3 element: energy density terms and (optionally) the 12 gradient
 // entries.  Closed forms of SURVEY section 8a; they restate
 //   J = [[x0-x2, x1-x2],[y0-y2, y1-y2]], detJ, Jinv      src/models.py:336-343
@@ -78,7 +90,7 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
                                                const Tri3Consts &k, double2 (&gx)[3], double2 (&gu)[3]) {
     const double a = X0.x - X2.x, b = X1.x - X2.x, c = X0.y - X2.y, d = X1.y - X2.y;
     const double det = a * d - b * c;
-    const double inv = 1.0 / det;
+    const double inv = fast_rcp(det);
     const double A = fabs(det);
     const double g0x = U0.x - U2.x, g0y = U0.y - U2.y;
     const double g1x = U1.x - U2.x, g1y = U1.y - U2.y;

@@ -83,10 +83,68 @@ void morton_order(const int64_t *conn, int64_t ne, int64_t nn, const double *xy,
 
 constexpr int kOrphanTileNodes = 512;
 
+// Order the elements of one tile so that the 64 lanes of a wave-instruction (64 consecutive
+// positions) do not add into the same LDS accumulator: same-address ds_add_f64 lanes serialise.
+//   mode 0: keep Morton order (neighbouring lanes share nodes: worst for atomics)
+//   mode 1: transpose (lane l of batch b takes Morton position l*B + b)
+//   mode 2: greedy colouring -- fill batches of 64 with elements that share no owned node
+void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, const std::vector<int32_t> &lid,
+                         int32_t n_owned, int mode) {
+    const int n = (int)telems.size();
+    if (mode == 0 || n <= 64) return;
+    const int nb = (n + 63) / 64;
+    std::vector<int32_t> out;
+    out.reserve(n);
+    if (mode == 1) {
+        for (int b = 0; b < nb; ++b)
+            for (int l = 0; l < 64; ++l) {
+                const int p = l * nb + b;
+                if (p < n) out.push_back(telems[p]);
+            }
+        // positions l*nb+b >= n leave short batches; the list stays a permutation
+        telems.swap(out);
+        return;
+    }
+    // mode 2
+    std::vector<std::vector<int32_t>> batch(nb);
+    std::vector<std::vector<uint64_t>> used(nb, std::vector<uint64_t>(kMaxLocal / 64, 0));
+    std::vector<int32_t> leftover;
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t e = telems[i];
+        int32_t l[3];
+        for (int k = 0; k < 3; ++k) l[k] = lid[conn[3 * (int64_t)e + k]];
+        int placed = -1;
+        for (int t = 0; t < nb; ++t) {
+            const int b = (start + t) % nb;
+            const int cap = (b == nb - 1) ? n - 64 * (nb - 1) : 64;
+            if ((int)batch[b].size() >= cap) continue;
+            bool clash = false;
+            for (int k = 0; k < 3; ++k)
+                if (l[k] < n_owned && (used[b][l[k] >> 6] >> (l[k] & 63)) & 1) clash = true;
+            if (clash) continue;
+            placed = b;
+            break;
+        }
+        if (placed < 0) { leftover.push_back(e); continue; }
+        batch[placed].push_back(e);
+        for (int k = 0; k < 3; ++k)
+            if (l[k] < n_owned) used[placed][l[k] >> 6] |= 1ull << (l[k] & 63);
+        start = (placed + 1) % nb;      // neighbours in Morton order go to different batches
+    }
+    size_t lo = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int cap = (b == nb - 1) ? n - 64 * (nb - 1) : 64;
+        while ((int)batch[b].size() < cap && lo < leftover.size()) batch[b].push_back(leftover[lo++]);
+        out.insert(out.end(), batch[b].begin(), batch[b].end());
+    }
+    telems.swap(out);
+}
+
 // returns 0 ok, 1 = a tile exceeded kMaxLocal nodes (retry smaller), -1 error
 int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
               const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T,
-              const std::vector<int32_t> &order, HostPlan &P) {
+              const std::vector<int32_t> &order, int elem_order, HostPlan &P) {
     const int32_t nt_main = (int32_t)((ne + T - 1) / T);
     std::vector<int32_t> owner(nn, std::numeric_limits<int32_t>::max());
     for (int64_t p = 0; p < ne; ++p) {
@@ -185,6 +243,7 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
         std::sort(halo.begin(), halo.end());
         for (int32_t n : halo) lid[n] = nloc++;
         if (nloc > kMaxLocal) return 1;
+        order_tile_elements(telems, conn, lid, d.n_owned, elem_order);
 
         d.elem_off = (int32_t)P.elem_pack.size();
         d.n_elem = (int32_t)telems.size();
@@ -229,7 +288,7 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
 
 int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
-                    int64_t ned, int32_t tile_elems, HostPlan &out) {
+                    int64_t ned, int32_t tile_elems, int elem_order, HostPlan &out) {
     if (ne < 0 || nn < 0 || ned < 0 || nn > std::numeric_limits<int32_t>::max() ||
         ne > std::numeric_limits<int32_t>::max() || ned > std::numeric_limits<int32_t>::max()) {
         set_error("plan: sizes must be in [0, 2^31)");
@@ -246,7 +305,7 @@ int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *c
     std::vector<int32_t> order;
     morton_order(conn, ne, nn, coords, order);
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
-        const int rc = try_build(conn, ne, nn, x_src, u_src, edges, ned, T, order, out);
+        const int rc = try_build(conn, ne, nn, x_src, u_src, edges, ned, T, order, elem_order, out);
         if (rc <= 0) return rc;
     }
     set_error("plan: could not fit a tile into 1024 local nodes (node valence too high?)");

@@ -98,9 +98,137 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-// LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] double | red[4]
-__global__ __launch_bounds__(kBlock) void tri3_energy_tiled_kernel(
+// Ablation bits of the lab build (hfem_set_option("tiled_ablate", bits)); 0 in production.
+//   1: LDS atomics -> plain LDS stores    2: skip the element/edge phase
+//   4: skip the global node gather        8: skip the gradient write-out
+//  16: no LDS node reads in the element loop (synthetic operands)   32: no LDS accumulate at all
+//
+// LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] double | red[BLOCK/64]
+template <int BLOCK, int ABL>
+__global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free,
+    const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
+    const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
+    double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
+    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges, int stagger_ticks,
+    int stagger_mode) {
+    extern __shared__ double2 lds[];
+    double2 *nd_xy = lds;
+    double2 *nd_uv = lds + cap_nodes;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
+
+    const int tid = threadIdx.x;
+    const int slot = xcd_tile(blockIdx.x, gridDim.x);
+    // Stagger the start of co-resident workgroups: all resident tiles otherwise gather at the same
+    // time and then compute at the same time (HBM idle while the VALU/LDS work, and vice versa).
+    if (stagger_ticks > 0) {
+        const unsigned b = blockIdx.x;
+        unsigned frac;   // 0..255
+        if (stagger_mode == 0) frac = ((b >> 8) * 37u) & 255u;                    // by dispatch round of 256
+        else if (stagger_mode == 1) frac = (b * 2654435761u) >> 24;              // hash
+        else frac = ((b >> 11) * 32u + ((b >> 8) & 7u) * 4u) & 255u;             // rounds of 2048, then 256
+        const long long wait = ((long long)stagger_ticks * frac) >> 8;           // 10 ns ticks (100 MHz)
+        const long long t_start = __builtin_amdgcn_s_memrealtime();
+        while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
+    }
+    const TileDesc d = pd.tiles[tile_begin + slot];
+
+    // ---- phase 1: gather node data through the free/fixed maps, clear accumulators
+    const int2 *src = pd.node_src + d.node_off;
+    for (int l = tid; l < d.n_node; l += BLOCK) {
+        if (ABL & 4) {
+            nd_xy[l] = make_double2(0.001 * l, 0.002 * (l % 7));
+            nd_uv[l] = make_double2(1e-5, 2e-5 * (l % 3));
+        } else {
+            const int2 s = src[l];
+            nd_xy[l] = s.x >= 0 ? x_free[s.x] : x_fixed[~s.x];
+            nd_uv[l] = s.y >= 0 ? u_free[s.y] : u_fixed[~s.y];
+        }
+    }
+    for (int l = tid; l < d.n_owned; l += BLOCK) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
+    __syncthreads();
+
+    // ---- phase 2: elements (home + halo), then the tile's Neumann edges
+    double e_loc = 0.0;
+    const uint32_t *ep = pd.elem_pack + d.elem_off;
+    const int n_owned = d.n_owned;
+    auto accumulate = [&](int l, const double2 gx, const double2 gu) {
+        if (ABL & 32) {
+            asm volatile("" ::"v"(gx.x), "v"(gx.y), "v"(gu.x), "v"(gu.y));
+        } else if (ABL & 1) {
+            acc0[l] = gx.x; acc1[l] = gx.y; acc2[l] = gu.x; acc3[l] = gu.y;
+        } else {
+            unsafeAtomicAdd(&acc0[l], gx.x);
+            unsafeAtomicAdd(&acc1[l], gx.y);
+            unsafeAtomicAdd(&acc2[l], gu.x);
+            unsafeAtomicAdd(&acc3[l], gu.y);
+        }
+    };
+    if (!(ABL & 2)) {
+        for (int i = tid; i < d.n_elem; i += BLOCK) {
+            const uint32_t p = ep[i];
+            const int l[3] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask),
+                              (int)((p >> (2 * kLocalBits)) & kLocalMask)};
+            double2 gx[3], gu[3];
+            double e;
+            if (ABL & 16) {
+                const double f = 1e-3 * (double)(p & 0xFFFF);
+                e = tri3_element<true>(make_double2(1.0 + f, f), make_double2(f, 1.0 - f), make_double2(-f, f * f),
+                                       make_double2(f, 2 * f), make_double2(3 * f, f), make_double2(f, -f), k, gx, gu);
+            } else {
+                e = tri3_element<true>(nd_xy[l[0]], nd_xy[l[1]], nd_xy[l[2]], nd_uv[l[0]], nd_uv[l[1]],
+                                       nd_uv[l[2]], k, gx, gu);
+            }
+            if (p & kHomeBit) e_loc += e;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (l[j] < n_owned) accumulate(l[j], gx[j], gu[j]);
+        }
+        const int n_edge = skip_edges ? 0 : d.n_edge;
+        for (int i = tid; i < n_edge; i += BLOCK) {
+            const uint32_t p = pd.edge_pack[d.edge_off + i];
+            const int l[2] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask)};
+            const double4 t = T_edge ? T_edge[pd.edge_gid[d.edge_off + i]] : Tconst;
+            double2 gx[2], gu[2];
+            const double w = edge2_element<true>(nd_xy[l[0]], nd_xy[l[1]], nd_uv[l[0]], nd_uv[l[1]], t, gx, gu);
+            if (p & kHomeBit) e_loc -= w;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (l[j] < n_owned) accumulate(l[j], gx[j], gu[j]);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: every owned gradient row is written exactly once
+    if (!(ABL & 8)) {
+        for (int l = tid; l < n_owned; l += BLOCK) {
+            const int2 s = src[l];
+            if (gx_free && s.x >= 0) gx_free[s.x] = make_double2(acc0[l], acc1[l]);
+            if (gu_free && s.y >= 0) gu_free[s.y] = make_double2(acc2[l], acc3[l]);
+        }
+    }
+    const double tot = block_sum(e_loc, red);
+    if (tid == 0) partials[slot] = tot;
+}
+
+// ------------------------------------------------------------------ persistent, pipelined
+// Same tile algorithm, but a workgroup walks a contiguous run of tiles and overlaps the HBM
+// phase of tile t+1 with the VALU/LDS phase of tile t (register-staged prefetch): the gather of
+// tile t+1 is issued right after the barrier that starts tile t's element loop and lands in VGPRs
+// while the loop runs; it is written to LDS when tile t's gradients have left.  The element loop
+// itself touches no VMEM-loaded register (its packed records are staged through LDS as well), so
+// the compiler places no vmcnt wait inside it and the prefetch really stays in flight.  Row-map
+// loads run two tiles ahead (three register sets) so that no gather waits on its own index load.
+// One partial energy per workgroup.
+//   NPT >= ceil(max nodes per tile / BLOCK), EPT >= ceil(max elements per tile / BLOCK).
+// LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] double | red[16] | pk[cap_elems] u32
+constexpr int kPipeMaxTiles = 16;   // tiles one persistent workgroup may walk (descriptors cached in LDS)
+
+template <int BLOCK, int NPT, int EPT>
+__global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
+    PlanDev pd, int tile_begin, int n_tiles, const double2 *__restrict__ x_free,
     const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
     const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
@@ -111,69 +239,184 @@ __global__ __launch_bounds__(kBlock) void tri3_energy_tiled_kernel(
     double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
     double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
     double *red = acc3 + cap_owned;
+    int *ldesc = reinterpret_cast<int *>(red + 16);                      // [kPipeMaxTiles][8]
+    uint32_t *lpk = reinterpret_cast<uint32_t *>(ldesc + 8 * kPipeMaxTiles);
 
     const int tid = threadIdx.x;
-    const int slot = xcd_tile(blockIdx.x, gridDim.x);
-    const TileDesc d = pd.tiles[tile_begin + slot];
-
-    // ---- phase 1: gather node data through the free/fixed maps, clear accumulators
-    const int2 *src = pd.node_src + d.node_off;
-    for (int l = tid; l < d.n_node; l += kBlock) {
-        const int2 s = src[l];
-        nd_xy[l] = s.x >= 0 ? x_free[s.x] : x_fixed[~s.x];
-        nd_uv[l] = s.y >= 0 ? u_free[s.y] : u_fixed[~s.y];
-    }
-    for (int l = tid; l < d.n_owned; l += kBlock) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
-    __syncthreads();
-
-    // ---- phase 2: elements (home + halo), then the tile's Neumann edges
+    const int G = gridDim.x;
+    const int w = xcd_tile(blockIdx.x, G);           // consecutive w share an XCD (L2 reuse of halos)
+    const int t0 = (int)(((long long)w * n_tiles) / G), t1 = (int)(((long long)(w + 1) * n_tiles) / G);
     double e_loc = 0.0;
-    const uint32_t *ep = pd.elem_pack + d.elem_off;
-    const int n_owned = d.n_owned;
-    for (int i = tid; i < d.n_elem; i += kBlock) {
-        const uint32_t p = ep[i];
-        const int l[3] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask),
-                          (int)((p >> (2 * kLocalBits)) & kLocalMask)};
-        double2 gx[3], gu[3];
-        const double e = tri3_element<true>(nd_xy[l[0]], nd_xy[l[1]], nd_xy[l[2]], nd_uv[l[0]],
-                                            nd_uv[l[1]], nd_uv[l[2]], k, gx, gu);
-        if (p & kHomeBit) e_loc += e;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (l[j] < n_owned) {
-                unsafeAtomicAdd(&acc0[l[j]], gx[j].x);
-                unsafeAtomicAdd(&acc1[l[j]], gx[j].y);
-                unsafeAtomicAdd(&acc2[l[j]], gu[j].x);
-                unsafeAtomicAdd(&acc3[l[j]], gu[j].y);
-            }
-    }
-    const int n_edge = skip_edges ? 0 : d.n_edge;
-    for (int i = tid; i < n_edge; i += kBlock) {
-        const uint32_t p = pd.edge_pack[d.edge_off + i];
-        const int l[2] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask)};
-        const double4 t = T_edge ? T_edge[pd.edge_gid[d.edge_off + i]] : Tconst;
-        double2 gx[2], gu[2];
-        const double w = edge2_element<true>(nd_xy[l[0]], nd_xy[l[1]], nd_uv[l[0]], nd_uv[l[1]], t, gx, gu);
-        if (p & kHomeBit) e_loc -= w;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (l[j] < n_owned) {
-                unsafeAtomicAdd(&acc0[l[j]], gx[j].x);
-                unsafeAtomicAdd(&acc1[l[j]], gx[j].y);
-                unsafeAtomicAdd(&acc2[l[j]], gu[j].x);
-                unsafeAtomicAdd(&acc3[l[j]], gu[j].y);
-            }
-    }
-    __syncthreads();
 
-    // ---- phase 3: every owned gradient row is written exactly once
-    for (int l = tid; l < n_owned; l += kBlock) {
-        const int2 s = src[l];
-        if (gx_free && s.x >= 0) gx_free[s.x] = make_double2(acc0[l], acc1[l]);
-        if (gu_free && s.y >= 0) gu_free[s.y] = make_double2(acc2[l], acc3[l]);
+    // this workgroup's tile descriptors -> LDS once (the loop then reads them with LDS loads, which
+    // the vmcnt counter -- and hence the in-flight prefetch -- does not see)
+    if (tid < 8 * (t1 - t0)) ldesc[tid] = reinterpret_cast<const int *>(pd.tiles + tile_begin + t0)[tid];
+    __syncthreads();
+#define HFEM_DESC(T, F) __builtin_amdgcn_readfirstlane(ldesc[8 * ((T) - t0) + (F)])
+    // TileDesc fields: 0 elem_off 1 n_elem 2 node_off 3 n_node 4 n_owned 5 edge_off 6 n_edge
+
+    if (t0 < t1) {
+        // tile descriptors are wave-uniform scalars (SGPRs).
+        // d_: tile t (staged in LDS)   q_: tile t+1 (gather target)   row maps: s = t, s1 = t+1, s2 = t+2
+        // Every prefetch load below is STRAIGHT-LINE code: lanes without work clamp to row 0 and
+        // "no next tile" is a zero-sized sentinel tile.  hipcc can then count the loads in flight and
+        // emits exact vmcnt(N) waits instead of draining the queue with vmcnt(0) (which it does as
+        // soon as a VMEM op sits under a branch).
+        int d_n_node, d_n_owned, d_n_elem, d_edge_off, d_n_edge;
+        int q_n_node, q_n_owned, q_elem_off, q_n_elem, q_edge_off, q_n_edge;
+        int2 s[NPT], s1[NPT], s2[NPT];
+        double2 xy[NPT], uv[NPT];
+        uint32_t pkr[EPT];
+        const int2 *nsrc = pd.node_src;
+        const uint32_t *epk = pd.elem_pack;
+#define HFEM_GATHER(SRC, NN)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
+        const bool ok = tid + j * BLOCK < (NN);                                                    \
+        const int ix = ok ? SRC[j].x : 0, iu = ok ? SRC[j].y : 0;                                  \
+        xy[j] = *(ix >= 0 ? x_free + ix : x_fixed + ~ix);                                          \
+        uv[j] = *(iu >= 0 ? u_free + iu : u_fixed + ~iu);                                          \
     }
+#define HFEM_LOAD_SRC(DST, OFF, NN)                                                                \
+    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
+        const int l = tid + j * BLOCK;                                                             \
+        DST[j] = nsrc[(OFF) + (l < (NN) ? l : 0)];                                                 \
+    }
+#define HFEM_LOAD_PK(OFF, NN)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
+        const int i = tid + j * BLOCK;                                                             \
+        pkr[j] = epk[(OFF) + (i < (NN) ? i : 0)];                                                  \
+    }
+#define HFEM_STAGE()                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
+        const int l = tid + j * BLOCK;                                                             \
+        if (l < d_n_node) { nd_xy[l] = xy[j]; nd_uv[l] = uv[j]; }                                  \
+        if (l < d_n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }         \
+    }                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
+        const int i = tid + j * BLOCK;                                                             \
+        if (i < d_n_elem) lpk[i] = pkr[j];                                                         \
+    }
+        {
+            const int c_elem_off = HFEM_DESC(t0, 0), c_node_off = HFEM_DESC(t0, 2);
+            d_n_elem = HFEM_DESC(t0, 1); d_n_node = HFEM_DESC(t0, 3); d_n_owned = HFEM_DESC(t0, 4);
+            d_edge_off = HFEM_DESC(t0, 5); d_n_edge = HFEM_DESC(t0, 6);
+            const bool hn = t0 + 1 < t1;
+            const int tq = hn ? t0 + 1 : t0;
+            const int q_node_off = hn ? HFEM_DESC(tq, 2) : 0;
+            q_elem_off = hn ? HFEM_DESC(tq, 0) : 0; q_n_elem = hn ? HFEM_DESC(tq, 1) : 0;
+            q_n_node = hn ? HFEM_DESC(tq, 3) : 0; q_n_owned = hn ? HFEM_DESC(tq, 4) : 0;
+            q_edge_off = hn ? HFEM_DESC(tq, 5) : 0; q_n_edge = hn ? HFEM_DESC(tq, 6) : 0;
+            HFEM_LOAD_SRC(s, c_node_off, d_n_node)
+            HFEM_LOAD_SRC(s1, q_node_off, q_n_node)
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) s2[j] = make_int2(0, 0);
+            HFEM_LOAD_PK(c_elem_off, d_n_elem)
+            HFEM_GATHER(s, d_n_node)
+            HFEM_STAGE()          // the gather is the youngest load: this wait retires everything above
+        }
+
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();                       // tile t is staged
+            // ---- issue tile t+1's gather + element records and tile t+2's row maps: they land
+            //      while the element loop runs (nothing in that loop waits on vmcnt)
+            {
+                const bool hn2 = t + 2 < t1;
+                const int tr = hn2 ? t + 2 : t;
+                const int r_node_off = hn2 ? HFEM_DESC(tr, 2) : 0, r_n_node = hn2 ? HFEM_DESC(tr, 3) : 0;
+                HFEM_GATHER(s1, q_n_node)
+                HFEM_LOAD_PK(q_elem_off, q_n_elem)
+                HFEM_LOAD_SRC(s2, r_node_off, r_n_node)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- elements of tile t: LDS in, LDS out -- no VMEM dependence
+            const int n_owned = d_n_owned;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int i = tid + j * BLOCK;
+                if (i < d_n_elem) {
+                    const uint32_t p = lpk[i];
+                    const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask),
+                              l2 = (int)((p >> (2 * kLocalBits)) & kLocalMask);
+                    double2 gx[3], gu[3];
+                    const double e = tri3_element<true>(nd_xy[l0], nd_xy[l1], nd_xy[l2], nd_uv[l0], nd_uv[l1],
+                                                        nd_uv[l2], k, gx, gu);
+                    if (p & kHomeBit) e_loc += e;
+                    if (l0 < n_owned) {
+                        unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
+                        unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
+                    }
+                    if (l1 < n_owned) {
+                        unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
+                        unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
+                    }
+                    if (l2 < n_owned) {
+                        unsafeAtomicAdd(&acc0[l2], gx[2].x); unsafeAtomicAdd(&acc1[l2], gx[2].y);
+                        unsafeAtomicAdd(&acc2[l2], gu[2].x); unsafeAtomicAdd(&acc3[l2], gu[2].y);
+                    }
+                }
+            }
+            const int n_edge = skip_edges ? 0 : d_n_edge;
+            for (int i = tid; i < n_edge; i += BLOCK) {      // boundary tiles only
+                const uint32_t p = pd.edge_pack[d_edge_off + i];
+                const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
+                const double4 tt = T_edge ? T_edge[pd.edge_gid[d_edge_off + i]] : Tconst;
+                double2 gx[2], gu[2];
+                const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
+                if (p & kHomeBit) e_loc -= wk;
+                if (l0 < n_owned) {
+                    unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
+                    unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
+                }
+                if (l1 < n_owned) {
+                    unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
+                    unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
+                }
+            }
+            __syncthreads();                       // all accumulation of tile t done
+            // ---- tail.  Order matters for the vmcnt counter (in order, loads and stores together):
+            //      A store addresses  B accumulators -> registers  C stage tile t+1 (waits for the
+            //      prefetch; no store is pending yet)  D rotate row maps  E issue the stores LAST, so
+            //      they drain under the next tile's element loop.
+            double2 ogx[NPT], ogu[NPT];
+            double2 *dgx[NPT], *dgu[NPT];
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const int l = tid + j * BLOCK;
+                dgx[j] = (l < n_owned && gx_free && s[j].x >= 0) ? gx_free + s[j].x : nullptr;      // A
+                dgu[j] = (l < n_owned && gu_free && s[j].y >= 0) ? gu_free + s[j].y : nullptr;
+                ogx[j] = ogu[j] = make_double2(0.0, 0.0);
+                if (l < n_owned) {                                                                   // B
+                    ogx[j] = make_double2(acc0[l], acc1[l]);
+                    ogu[j] = make_double2(acc2[l], acc3[l]);
+                }
+            }
+            d_n_node = q_n_node; d_n_owned = q_n_owned; d_n_elem = q_n_elem; d_edge_off = q_edge_off;    // C
+            d_n_edge = q_n_edge;
+            HFEM_STAGE()
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) { s[j] = s1[j]; s1[j] = s2[j]; }                          // D
+            {
+                const bool hn2 = t + 2 < t1;
+                const int tr = hn2 ? t + 2 : t;
+                q_elem_off = hn2 ? HFEM_DESC(tr, 0) : 0; q_n_elem = hn2 ? HFEM_DESC(tr, 1) : 0;
+                q_n_node = hn2 ? HFEM_DESC(tr, 3) : 0; q_n_owned = hn2 ? HFEM_DESC(tr, 4) : 0;
+                q_edge_off = hn2 ? HFEM_DESC(tr, 5) : 0; q_n_edge = hn2 ? HFEM_DESC(tr, 6) : 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {                                                          // E
+                if (dgx[j]) *dgx[j] = ogx[j];
+                if (dgu[j]) *dgu[j] = ogu[j];
+            }
+        }
+#undef HFEM_GATHER
+#undef HFEM_LOAD_SRC
+#undef HFEM_LOAD_PK
+#undef HFEM_STAGE
+    }
+#undef HFEM_DESC
     const double tot = block_sum(e_loc, red);
-    if (tid == 0) partials[slot] = tot;
+    if (tid == 0) partials[blockIdx.x] = tot;
 }
 
 // Deterministic sum of the per-tile partial energies (fixed order).
@@ -190,6 +433,14 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double *__re
 
 // ====================================================================== C ABI
 using namespace hfem;
+
+// ---- tuning / lab options (process-wide; hfem_set_option)
+static int g_tiled_block = 512;    // threads per tile (measured best on T1M: 512 at 1024-element tiles)
+static int g_tiled_ablate = 0;
+static int g_plan_elem_order = 2;  // greedy colouring: no same-address ds_add_f64 lanes in a wave
+static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
+static int g_tiled_stagger_mode = 0;
+static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
 struct hfem_plan {
     HostPlan host;
@@ -282,9 +533,9 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
     HFEM_ARG_CHECK(out, "null out pointer");
     *out = nullptr;
     std::unique_ptr<hfem_plan> p(new hfem_plan);
-    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, p->host)) return -1;
+    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, g_plan_elem_order, p->host)) return -1;
     const HostPlan &h = p->host;
-    p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 64;
+    p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128 + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
     if (device >= 0) {
         if (int rc = use_device(device)) return rc;
         p->device = device;
@@ -296,10 +547,9 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
         if (!rc) rc = upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
         if (!rc) rc = upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
         if (!rc) rc = upload(&raw->d_partials, nullptr, h.tiles.size(), raw->device_bytes);
-        if (!rc) {
-            hipError_t e = hipFuncSetAttribute((const void *)tri3_energy_tiled_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
-            if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); rc = (int)e; }
+        if (!rc && p->lds_bytes > 64 * 1024) {
+            set_error("plan: tile needs more than 64 KiB of LDS");
+            rc = -1;
         }
         if (rc) { hfem_plan_destroy(p.release()); return rc; }
     }
@@ -364,16 +614,118 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     if (n > 0) {
         PlanDev pd{plan->d_tiles, plan->d_elem_pack, plan->d_node_src, plan->d_edge_pack, plan->d_edge_gid};
         const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
-        hipLaunchKernelGGL(tri3_energy_tiled_kernel, dim3(n), dim3(kBlock), (size_t)plan->lds_bytes, s, pd,
-                           (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,
-                           (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),
-                           (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
-                           (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
-                           (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, plan->host.max_nodes,
-                           plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0);
+        int n_partials = n;
+        bool launched = false;
+        if (g_tiled_pipe > 0 && g_tiled_ablate == 0) {
+            const HostPlan &h = plan->host;
+            int G = g_tiled_pipe * 256;
+            if (G > n) G = n;
+            if ((n + G - 1) / G > kPipeMaxTiles) G = (n + kPipeMaxTiles - 1) / kPipeMaxTiles;
+#define HFEM_LAUNCH_PIPE(BLK, NPT, EPT)                                                                     \
+    hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes, s, \
+                       pd, (int)tile_begin, n, (const double2 *)x_free, (const double2 *)x_fixed,           \
+                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
+                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0)
+            const int blk = g_tiled_block;
+            // clamped (branch-free) prefetch loads read row 0 of every array: all four must exist
+            const bool rows0 = x_free && u_free && h.nn > 0 && h.ne > 0;
+            const double *xfix0 = x_fixed ? x_fixed : x_free, *ufix0 = u_fixed ? u_fixed : u_free;
+            (void)xfix0; (void)ufix0;
+            if (!rows0) {
+            } else if (blk == 256 && h.max_nodes <= 512 && h.max_elems <= 3 * 256) { HFEM_LAUNCH_PIPE(256, 2, 3); launched = true; }
+            else if (blk == 256 && h.max_nodes <= 1024 && h.max_elems <= 6 * 256) { HFEM_LAUNCH_PIPE(256, 4, 6); launched = true; }
+            else if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) { HFEM_LAUNCH_PIPE(512, 1, 2); launched = true; }
+            else if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 3 * 512) { HFEM_LAUNCH_PIPE(512, 2, 3); launched = true; }
+            else if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 4 * 512) { HFEM_LAUNCH_PIPE(512, 2, 4); launched = true; }
+            else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) { HFEM_LAUNCH_PIPE(1024, 1, 2); launched = true; }
+#undef HFEM_LAUNCH_PIPE
+            if (launched) n_partials = G;
+        }
+        if (!launched) {
+#define HFEM_LAUNCH_TILED(BLK, ABL)                                                                        \
+    hipLaunchKernelGGL((tri3_energy_tiled_kernel<BLK, ABL>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, pd, \
+                       (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,                  \
+                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
+                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, plan->host.max_nodes,      \
+                       plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, g_tiled_stagger,         \
+                       g_tiled_stagger_mode)
+        const int abl = g_tiled_ablate;
+        if (abl == 0) {
+            switch (g_tiled_block) {
+                case 512: HFEM_LAUNCH_TILED(512, 0); break;
+                case 1024: HFEM_LAUNCH_TILED(1024, 0); break;
+                default: HFEM_LAUNCH_TILED(256, 0); break;
+            }
+        } else {   // lab build: ablations at 256 and 512 threads
+            const bool b512 = g_tiled_block == 512;
+            switch (abl) {
+                case 1: if (b512) HFEM_LAUNCH_TILED(512, 1); else HFEM_LAUNCH_TILED(256, 1); break;
+                case 2: if (b512) HFEM_LAUNCH_TILED(512, 2); else HFEM_LAUNCH_TILED(256, 2); break;
+                case 4: if (b512) HFEM_LAUNCH_TILED(512, 4); else HFEM_LAUNCH_TILED(256, 4); break;
+                case 6: if (b512) HFEM_LAUNCH_TILED(512, 6); else HFEM_LAUNCH_TILED(256, 6); break;
+                case 8: if (b512) HFEM_LAUNCH_TILED(512, 8); else HFEM_LAUNCH_TILED(256, 8); break;
+                case 5: if (b512) HFEM_LAUNCH_TILED(512, 5); else HFEM_LAUNCH_TILED(256, 5); break;
+                case 13: if (b512) HFEM_LAUNCH_TILED(512, 13); else HFEM_LAUNCH_TILED(256, 13); break;
+                case 10: if (b512) HFEM_LAUNCH_TILED(512, 10); else HFEM_LAUNCH_TILED(256, 10); break;
+                case 14: if (b512) HFEM_LAUNCH_TILED(512, 14); else HFEM_LAUNCH_TILED(256, 14); break;
+                case 32: if (b512) HFEM_LAUNCH_TILED(512, 32); else HFEM_LAUNCH_TILED(256, 32); break;
+                case 48: if (b512) HFEM_LAUNCH_TILED(512, 48); else HFEM_LAUNCH_TILED(256, 48); break;
+                case 16: if (b512) HFEM_LAUNCH_TILED(512, 16); else HFEM_LAUNCH_TILED(256, 16); break;
+                default: set_error("hfem_tri3_energy_plan: unsupported tiled_ablate value"); return -1;
+            }
+        }
+#undef HFEM_LAUNCH_TILED
+        }
         if (int rc = launch_status("hfem_tri3_energy_plan")) return rc;
+        if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin,
+                           n_partials, loss_out);
+        return launch_status("hfem_tri3_energy_plan(sum)");
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
     return launch_status("hfem_tri3_energy_plan(sum)");
+}
+
+extern "C" int hfem_set_option(const char *name, int value) {
+    HFEM_ARG_CHECK(name, "null option name");
+    const std::string n(name);
+    if (n == "tiled_block") {
+        HFEM_ARG_CHECK(value == 256 || value == 512 || value == 1024, "tiled_block must be 256, 512 or 1024");
+        g_tiled_block = value;
+    } else if (n == "tiled_ablate") {
+        g_tiled_ablate = value;
+    } else if (n == "tiled_stagger") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 100000, "tiled_stagger is in 10 ns ticks, 0..100000");
+        g_tiled_stagger = value;
+    } else if (n == "tiled_stagger_mode") {
+        g_tiled_stagger_mode = value;
+    } else if (n == "tiled_pipe") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 8, "tiled_pipe must be 0..8 workgroups per CU");
+        g_tiled_pipe = value;
+    } else if (n == "plan_elem_order") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 2, "plan_elem_order must be 0, 1 or 2");
+        g_plan_elem_order = value;
+    } else {
+        set_error("hfem_set_option: unknown option '" + n + "'");
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int hfem_get_option(const char *name) {
+    if (!name) return -1;
+    const std::string n(name);
+    if (n == "tiled_block") return g_tiled_block;
+    if (n == "tiled_ablate") return g_tiled_ablate;
+    if (n == "plan_elem_order") return g_plan_elem_order;
+    if (n == "tiled_pipe") return g_tiled_pipe;
+    if (n == "tiled_stagger") return g_tiled_stagger;
+    if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
+    return -1;
 }

@@ -40,7 +40,8 @@ class TilePlan:
     (no HIP call; what the CPU tests inspect)."""
 
     def __init__(self, connectivity, n_nodes: int, coords_hint=None, x_src=None, u_src=None,
-                 edges=None, tile_elems: int = 0, device: Optional[torch.device] = None):
+                 edges=None, tile_elems: int = 0, device: Optional[torch.device] = None,
+                 elem_order: Optional[int] = None):
         conn = _np(connectivity, np.int64).reshape(-1, 3)
         hint = _np(coords_hint, np.float64)
         xs, us = _np(x_src, np.int32), _np(u_src, np.int32)
@@ -60,6 +61,8 @@ class TilePlan:
         def p(a):
             return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
 
+        if elem_order is not None:
+            _lib.check(_lib.lib().hfem_set_option(b"plan_elem_order", int(elem_order)), "hfem_set_option")
         rc = _lib.lib().hfem_plan_create(dev, p(conn), self.n_elems, self.n_nodes, p(hint), p(xs), p(us),
                                          p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
         _lib.check(rc, "hfem_plan_create")

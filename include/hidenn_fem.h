@@ -121,6 +121,12 @@ int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, const double *x
                           int32_t tile_begin, int32_t tile_end, double *loss_out,
                           double *gx_free, double *gu_free, int32_t flags, void *stream);
 
+/* Process-wide tuning knobs of the tiled kernel: "tiled_block" (threads per tile: 256, 512,
+ * 1024) and "tiled_ablate" (lab-only ablation bits, 0 in production; see tri3_energy.hip).
+ * hfem_get_option returns the value or -1.                                     */
+int hfem_set_option(const char *name, int value);
+int hfem_get_option(const char *name);
+
 /* ------------------------------------------------------------------ per-point TRI3
  * Unfused forward of src/models.py:316-357 on assembled X,U: u_h [M][2],
  * detJ [M], grad_u [M][2][2] at reference points x_eval [M][2] of elements

@@ -1,0 +1,142 @@
+"""N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.
+
+Exercises the host logic of hidenn_fem_amd.sharded.ShardedTri3Energy -- tile-range split,
+packed [gX|gU|loss] buffer, the single all-reduce, autograd plumbing -- with the oracle's closed
+forms standing in for the HIP kernel (injected through the `evaluate` test seam; the product
+default is the HIP kernel and has no CPU path)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MASK, HOME = 1023, 1 << 30
+
+
+def oracle_tile_evaluator(plan, model):
+    """(lo, hi, loss_v, gx_v, gu_v) -> fills the views like hfem_tri3_energy_plan does for tiles [lo, hi)."""
+    from oracle import closed_form as CF
+    td, ep, ns = plan.export("tile_desc"), plan.export("elem_pack"), plan.export("node_src")
+    gp = plan.export("edge_pack")
+    mat, W = CF.plane_stress(), 0.25
+    Tc = np.array([2e5, 0.0, 0.0, 0.0])
+
+    def evaluate(lo, hi, loss_v, gx_v, gu_v):
+        xf, uf = model.node_coords_free.detach().numpy(), model.u_free.detach().numpy()
+        xfix, ufix = model.node_coords_fixed.numpy(), model.u_fixed_rows().numpy()
+        total = 0.0
+        for (eo, nel, no, nno, nown, go, ned, _) in td[lo:hi]:
+            src = ns[no:no + nno]
+            X = np.where((src[:, 0] >= 0)[:, None], xf[np.maximum(src[:, 0], 0)], xfix[np.maximum(~src[:, 0], 0)] if len(xfix) else 0.0)
+            U = np.where((src[:, 1] >= 0)[:, None], uf[np.maximum(src[:, 1], 0)], ufix[np.maximum(~src[:, 1], 0)] if len(ufix) else 0.0)
+            pk = ep[eo:eo + nel]
+            loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1).astype(np.int64)
+            _, gxl, gul = CF.tri3_energy(X, U, loc, mat, W)
+            total += CF.tri3_energy(X, U, loc[(pk & HOME) != 0], mat, W, grads=False)[0]
+            if ned:
+                q = gp[go:go + ned]
+                gl = np.stack([q & MASK, (q >> 10) & MASK], axis=1).astype(np.int64)
+                CF.edge2_energy(X, U, gl, Tconst=Tc, gX=gxl, gU=gul)
+                total -= CF.edge2_energy(X, U, gl[(q & HOME) != 0], Tconst=Tc)
+            own = src[:nown]
+            fx, fu = own[:, 0] >= 0, own[:, 1] >= 0
+            gx_v[torch.from_numpy(own[fx, 0].astype(np.int64))] = torch.from_numpy(gxl[:nown][fx])
+            gu_v[torch.from_numpy(own[fu, 1].astype(np.int64))] = torch.from_numpy(gul[:nown][fu])
+        loss_v[0] = total
+
+    return evaluate
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hidenn_fem_amd.mesh import structured_tri_mesh
+        from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+        from hidenn_fem_amd.loss import EnergyLoss2D
+        from hidenn_fem_amd.plan import TilePlan
+        from hidenn_fem_amd.sharded import ShardedTri3Energy
+        from oracle import closed_form as CF
+        f64 = torch.float64
+        coords, conn, geom, bc, mn, edges = structured_tri_mesh(41, 27, jitter=0.2, seed=5, dtype=f64)
+        torch.manual_seed(3)                                   # same replicated parameters on every rank
+        model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                         neumann_edges=edges)
+        loss_fn = EnergyLoss2D(device=torch.device("cpu"), dtype=f64, tile_elems=96)
+        plan = TilePlan(conn, coords.shape[0], coords_hint=coords, x_src=model._x_src, u_src=model._u_src,
+                        edges=edges, tile_elems=96)            # host-only plan: no HIP call
+        sh = ShardedTri3Energy(model, loss_fn, evaluate=oracle_tile_evaluator(plan, model), plan=plan)
+        assert (sh.rank, sh.world) == (rank, world)
+        lo, hi = sh.lo, sh.hi
+        assert 0 <= lo < hi <= plan.n_tiles
+        loss = sh()                                            # kernel stand-in + ONE all-reduce
+        loss.backward()
+        # local send buffer: only rows owned by this rank's tiles are non-zero
+        _, gx_s, gu_s = sh._views(sh.send)
+        owned_rows = int((gx_s != 0).any(dim=1).sum())
+        # reference: full-mesh oracle
+        X = np.zeros((coords.shape[0], 2)); U = np.zeros_like(X)
+        X[~geom.numpy()] = model.node_coords_free.detach().numpy(); X[geom.numpy()] = model.node_coords_fixed.numpy()
+        U[~bc.numpy()] = model.u_free.detach().numpy()
+        e_ref, gX, gU = CF.tri3_energy(X, U, conn.numpy(), CF.plane_stress(), 0.25)
+        e_ref -= CF.edge2_energy(X, U, edges.numpy(), Tconst=np.array([2e5, 0, 0, 0]), gX=gX, gU=gU)
+        gx_ref, gu_ref = gX[~geom.numpy()], gU[~bc.numpy()]
+        ok = (abs(loss.item() - e_ref) <= 1e-12 * abs(e_ref)
+              and np.abs(model.node_coords_free.grad.numpy() - gx_ref).max() <= 1e-11 * np.abs(gx_ref).max()
+              and np.abs(model.u_free.grad.numpy() - gu_ref).max() <= 1e-11 * np.abs(gu_ref).max())
+        # every rank must hold bit-identical reduced results (identical optimiser steps follow)
+        mine = torch.cat([model.node_coords_free.grad.reshape(-1), model.u_free.grad.reshape(-1), loss.detach().reshape(1)])
+        other = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        same = all(torch.equal(o, mine) for o in other)
+        q.put((rank, bool(ok), bool(same), lo, hi, owned_rows, int(gx_s.shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_energy_two_ranks_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    (r0, ok0, same0, lo0, hi0, own0, n0), (r1, ok1, same1, lo1, hi1, own1, n1) = res
+    assert ok0 and ok1, "sharded loss/gradients differ from the full-mesh oracle"
+    assert same0 and same1, "ranks disagree after the all-reduce"
+    assert lo0 == 0 and hi0 == lo1 and hi1 > lo1                # contiguous, disjoint, covering tile ranges
+    assert 0 < own0 < n0 and 0 < own1 < n1 and own0 + own1 <= n0   # each rank wrote only its own rows
+
+
+def test_single_process_sharded_equals_unsharded():
+    """world = 1 (no process group): same code path, the exchange is a copy."""
+    sys.path.insert(0, ROOT)
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.plan import TilePlan
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    f64 = torch.float64
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(17, 11, jitter=0.1, seed=2, dtype=f64)
+    model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges)
+    plan = TilePlan(conn, coords.shape[0], coords_hint=coords, x_src=model._x_src, u_src=model._u_src, edges=edges,
+                    tile_elems=64)
+    sh = ShardedTri3Energy(model, EnergyLoss2D(device=torch.device("cpu"), dtype=f64, tile_elems=64),
+                           evaluate=oracle_tile_evaluator(plan, model), plan=plan)
+    assert (sh.lo, sh.hi) == (0, plan.n_tiles)
+    loss, gx, gu = sh.value_and_grad()
+    assert torch.isfinite(loss) and (gx != 0).any(dim=1).all() and (gu != 0).any(dim=1).all()

@@ -453,7 +453,8 @@ struct hfem_plan {
     int32_t *d_edge_gid = nullptr;
     double *d_partials = nullptr;
     int64_t device_bytes = 0;
-    int32_t lds_bytes = 0;
+    int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
+    int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
 };
 
 static Tri3Consts make_consts(const double mat[4], double W, const double Bk[6]) {
@@ -535,7 +536,8 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
     std::unique_ptr<hfem_plan> p(new hfem_plan);
     if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, g_plan_elem_order, p->host)) return -1;
     const HostPlan &h = p->host;
-    p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128 + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
+    p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
+    p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
     if (device >= 0) {
         if (int rc = use_device(device)) return rc;
         p->device = device;
@@ -547,7 +549,7 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
         if (!rc) rc = upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
         if (!rc) rc = upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
         if (!rc) rc = upload(&raw->d_partials, nullptr, h.tiles.size(), raw->device_bytes);
-        if (!rc && p->lds_bytes > 64 * 1024) {
+        if (!rc && p->lds_bytes_pipe > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
             rc = -1;
         }
@@ -622,7 +624,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             if (G > n) G = n;
             if ((n + G - 1) / G > kPipeMaxTiles) G = (n + kPipeMaxTiles - 1) / kPipeMaxTiles;
 #define HFEM_LAUNCH_PIPE(BLK, NPT, EPT)                                                                     \
-    hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes, s, \
+    hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes_pipe, s, \
                        pd, (int)tile_begin, n, (const double2 *)x_free, (const double2 *)x_fixed,           \
                        (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \

@@ -27,6 +27,7 @@ constexpr int kLocalBits = 10;
 constexpr int kMaxLocal = 1 << kLocalBits;
 constexpr uint32_t kLocalMask = kMaxLocal - 1;
 constexpr uint32_t kHomeBit = 1u << 30;   // element/edge energy is counted by this tile
+constexpr uint32_t kSkipBit = 1u << 31;   // padding record: the lane has no element
 
 // tile_desc[t] = 8 x int32
 struct TileDesc {

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
     const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
     double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges, int stagger_ticks,
-    int stagger_mode) {
+    int stagger_mode, unsigned long long *__restrict__ stamps) {
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
     double2 *nd_uv = lds + cap_nodes;
@@ -121,6 +121,9 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 
     const int tid = threadIdx.x;
     const int slot = xcd_tile(blockIdx.x, gridDim.x);
+#define HFEM_STAMP(I)                                                                              \
+    if ((ABL & 64) && tid == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+    HFEM_STAMP(0)
     // Stagger the start of co-resident workgroups: all resident tiles otherwise gather at the same
     // time and then compute at the same time (HBM idle while the VALU/LDS work, and vice versa).
     if (stagger_ticks > 0) {
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
         while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
     }
     const TileDesc d = pd.tiles[tile_begin + slot];
+    if ((ABL & 64) && tid == 0 && d.n_node >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 1: gather node data through the free/fixed maps, clear accumulators
     const int2 *src = pd.node_src + d.node_off;
@@ -148,13 +152,22 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
         }
     }
     for (int l = tid; l < d.n_owned; l += BLOCK) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
+    HFEM_STAMP(2)
     __syncthreads();
+    HFEM_STAMP(3)
 
     // ---- phase 2: elements (home + halo), then the tile's Neumann edges
     double e_loc = 0.0;
     const uint32_t *ep = pd.elem_pack + d.elem_off;
     const int n_owned = d.n_owned;
     auto accumulate = [&](int l, const double2 gx, const double2 gu) {
+        if (ABL & 128) {   // lab: synthetic address patterns (timing only)
+            const int lane = tid & 63;
+            int pat = lane;                                                    // lane-linear: conflict-free under any model
+            if (ABL & 256) pat = ((lane & 15) << 1) + ((lane >> 4) & 1) + (lane & 32);   // A: distinct mod 32 per 32-lane half, 2-way mod 16 per 16-lane group
+            if (ABL & 512) pat = (lane & 15) + ((lane >> 4) << 5);                       // B: distinct mod 16 per 16-lane group, 2-way mod 32 per half
+            l = pat + ((l >> 7) << 7) < n_owned ? pat + ((l >> 7) << 7) : pat;
+        }
         if (ABL & 32) {
             asm volatile("" ::"v"(gx.x), "v"(gx.y), "v"(gu.x), "v"(gu.y));
         } else if (ABL & 1) {
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
     if (!(ABL & 2)) {
         for (int i = tid; i < d.n_elem; i += BLOCK) {
             const uint32_t p = ep[i];
+            if (p & kSkipBit) continue;
             const int l[3] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask),
                               (int)((p >> (2 * kLocalBits)) & kLocalMask)};
             double2 gx[3], gu[3];
@@ -199,7 +213,9 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
                 if (l[j] < n_owned) accumulate(l[j], gx[j], gu[j]);
         }
     }
+    HFEM_STAMP(4)
     __syncthreads();
+    HFEM_STAMP(5)
 
     // ---- phase 3: every owned gradient row is written exactly once
     if (!(ABL & 8)) {
@@ -209,8 +225,11 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
             if (gu_free && s.y >= 0) gu_free[s.y] = make_double2(acc2[l], acc3[l]);
         }
     }
+    HFEM_STAMP(6)
     const double tot = block_sum(e_loc, red);
     if (tid == 0) partials[slot] = tot;
+    HFEM_STAMP(7)
+#undef HFEM_STAMP
 }
 
 // ------------------------------------------------------------------ persistent, pipelined
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 const int i = tid + j * BLOCK;
-                if (i < d_n_elem) {
+                if (i < d_n_elem && !(lpk[i] & kSkipBit)) {
                     const uint32_t p = lpk[i];
                     const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask),
                               l2 = (int)((p >> (2 * kLocalBits)) & kLocalMask);
@@ -437,7 +456,7 @@ using namespace hfem;
 // ---- tuning / lab options (process-wide; hfem_set_option)
 static int g_tiled_block = 512;    // threads per tile (measured best on T1M: 512 at 1024-element tiles)
 static int g_tiled_ablate = 0;
-static int g_plan_elem_order = 2;  // greedy colouring: no same-address ds_add_f64 lanes in a wave
+static int g_plan_elem_order = 3;  // LDS-bank-aware 16-lane groups (plan.cpp order_tile_elements)
 static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
 static int g_tiled_stagger_mode = 0;
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
@@ -452,6 +471,7 @@ struct hfem_plan {
     uint32_t *d_edge_pack = nullptr;
     int32_t *d_edge_gid = nullptr;
     double *d_partials = nullptr;
+    unsigned long long *d_stamps = nullptr;   // lab only: [n_tiles][8] s_memrealtime stamps
     int64_t device_bytes = 0;
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
@@ -523,6 +543,7 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
         (void)hipFree(plan->d_edge_pack);
         (void)hipFree(plan->d_edge_gid);
         (void)hipFree(plan->d_partials);
+        (void)hipFree(plan->d_stamps);
     }
     delete plan;
     return 0;
@@ -549,6 +570,7 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
         if (!rc) rc = upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
         if (!rc) rc = upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
         if (!rc) rc = upload(&raw->d_partials, nullptr, h.tiles.size(), raw->device_bytes);
+        if (!rc) rc = upload(&raw->d_stamps, nullptr, h.tiles.size() * 8, raw->device_bytes);
         if (!rc && p->lds_bytes_pipe > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
             rc = -1;
@@ -588,6 +610,15 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 3: src = h.edge_pack.data(); n = (int64_t)h.edge_pack.size(); break;
         case 4: src = h.edge_gid.data(); n = (int64_t)h.edge_gid.size(); break;
         case 5: src = h.elem_gid.data(); n = (int64_t)h.elem_gid.size(); break;
+        case 6: {   // lab: device stamps, 8 x uint64 per tile, returned as 16 x int32 per tile
+            n = (int64_t)h.tiles.size() * 16;
+            if (buf) {
+                if (cap_elems < n || plan->device < 0) { set_error("hfem_plan_export: stamps need a device plan + buffer"); return -1; }
+                (void)hipSetDevice(plan->device);
+                if (hipMemcpy(buf, plan->d_stamps, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("hfem_plan_export: stamp copy failed"); return -1; }
+            }
+            return n;
+        }
         default: set_error("hfem_plan_export: unknown array id"); return -1;
     }
     if (buf) {
@@ -655,7 +686,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, plan->host.max_nodes,      \
                        plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, g_tiled_stagger,         \
-                       g_tiled_stagger_mode)
+                       g_tiled_stagger_mode, plan->d_stamps)
         const int abl = g_tiled_ablate;
         if (abl == 0) {
             switch (g_tiled_block) {
@@ -673,6 +704,11 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                 case 8: if (b512) HFEM_LAUNCH_TILED(512, 8); else HFEM_LAUNCH_TILED(256, 8); break;
                 case 5: if (b512) HFEM_LAUNCH_TILED(512, 5); else HFEM_LAUNCH_TILED(256, 5); break;
                 case 13: if (b512) HFEM_LAUNCH_TILED(512, 13); else HFEM_LAUNCH_TILED(256, 13); break;
+                case 128: if (b512) HFEM_LAUNCH_TILED(512, 128); else HFEM_LAUNCH_TILED(256, 128); break;
+                case 384: if (b512) HFEM_LAUNCH_TILED(512, 384); else HFEM_LAUNCH_TILED(256, 384); break;
+                case 640: if (b512) HFEM_LAUNCH_TILED(512, 640); else HFEM_LAUNCH_TILED(256, 640); break;
+                case 129: if (b512) HFEM_LAUNCH_TILED(512, 129); else HFEM_LAUNCH_TILED(256, 129); break;
+                case 64: if (b512) HFEM_LAUNCH_TILED(512, 64); else HFEM_LAUNCH_TILED(256, 64); break;
                 case 10: if (b512) HFEM_LAUNCH_TILED(512, 10); else HFEM_LAUNCH_TILED(256, 10); break;
                 case 14: if (b512) HFEM_LAUNCH_TILED(512, 14); else HFEM_LAUNCH_TILED(256, 14); break;
                 case 32: if (b512) HFEM_LAUNCH_TILED(512, 32); else HFEM_LAUNCH_TILED(256, 32); break;
@@ -711,7 +747,7 @@ extern "C" int hfem_set_option(const char *name, int value) {
         HFEM_ARG_CHECK(value >= 0 && value <= 8, "tiled_pipe must be 0..8 workgroups per CU");
         g_tiled_pipe = value;
     } else if (n == "plan_elem_order") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 2, "plan_elem_order must be 0, 1 or 2");
+        HFEM_ARG_CHECK(value >= 0 && value <= 3, "plan_elem_order must be 0..3");
         g_plan_elem_order = value;
     } else {
         set_error("hfem_set_option: unknown option '" + n + "'");

@@ -15,7 +15,8 @@ import torch
 
 from . import _lib
 
-EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5}
+EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
+              "stamps": 6}
 
 
 def _np(a, dtype):
@@ -90,6 +91,8 @@ class TilePlan:
             out = out.reshape(-1, 8)
         elif name == "node_src":
             out = out.reshape(-1, 2)
+        elif name == "stamps":
+            out = out.view(np.uint64).reshape(-1, 8)
         return out
 
     def shard_range(self, rank: int, world: int):

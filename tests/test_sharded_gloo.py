@@ -35,6 +35,7 @@ def oracle_tile_evaluator(plan, model):
             X = np.where((src[:, 0] >= 0)[:, None], xf[np.maximum(src[:, 0], 0)], xfix[np.maximum(~src[:, 0], 0)] if len(xfix) else 0.0)
             U = np.where((src[:, 1] >= 0)[:, None], uf[np.maximum(src[:, 1], 0)], ufix[np.maximum(~src[:, 1], 0)] if len(ufix) else 0.0)
             pk = ep[eo:eo + nel]
+            pk = pk[(pk >> 31) == 0]                    # padding records carry no element
             loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1).astype(np.int64)
             _, gxl, gul = CF.tri3_energy(X, U, loc, mat, W)
             total += CF.tri3_energy(X, U, loc[(pk & HOME) != 0], mat, W, grads=False)[0]

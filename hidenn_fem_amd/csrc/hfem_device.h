@@ -84,7 +84,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 //   eps, sigma = C eps, psi = 1/2 eps.sigma               src/loss.py:66-77
 //   e = abs(detJ) (W psi - sum_k U_k.B_k)                 src/loss.py:80-88
 // and the hand-derived backward w.r.t. U (gu[k][i]) and X (gx[k][i]).
-template <bool GRAD>
+// HASB = false compiles the body-force table out (B_k = 0: the reference's default, loss.py:43-45).
+template <bool GRAD, bool HASB = true>
 __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X1, const double2 X2,
                                                const double2 U0, const double2 U1, const double2 U2,
                                                const Tri3Consts &k, double2 (&gx)[3], double2 (&gu)[3]) {
@@ -101,17 +102,24 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
     const double syy = k.c12 * h00 + k.c22 * h11;
     const double sxy = k.c33 * gam;
     const double psi = 0.5 * (h00 * sxx + h11 * syy + gam * sxy);
-    const double beta = U0.x * k.Bk[0] + U0.y * k.Bk[1] + U1.x * k.Bk[2] + U1.y * k.Bk[3] +
-                        U2.x * k.Bk[4] + U2.y * k.Bk[5];
-    const double dens = k.W * psi - beta;
+    double dens = k.W * psi;
+    if (HASB)
+        dens -= U0.x * k.Bk[0] + U0.y * k.Bk[1] + U1.x * k.Bk[2] + U1.y * k.Bk[3] + U2.x * k.Bk[4] +
+                U2.y * k.Bk[5];
     if (GRAD) {
         const double aw = A * k.W;
         const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;   // P[1][0] = p01
         const double dg0x = (p00 * d - p01 * c) * inv, dg0y = (p01 * d - p11 * c) * inv;
         const double dg1x = (p01 * a - p00 * b) * inv, dg1y = (p11 * a - p01 * b) * inv;
-        gu[0] = make_double2(dg0x - A * k.Bk[0], dg0y - A * k.Bk[1]);
-        gu[1] = make_double2(dg1x - A * k.Bk[2], dg1y - A * k.Bk[3]);
-        gu[2] = make_double2(-(dg0x + dg1x) - A * k.Bk[4], -(dg0y + dg1y) - A * k.Bk[5]);
+        if (HASB) {
+            gu[0] = make_double2(dg0x - A * k.Bk[0], dg0y - A * k.Bk[1]);
+            gu[1] = make_double2(dg1x - A * k.Bk[2], dg1y - A * k.Bk[3]);
+            gu[2] = make_double2(-(dg0x + dg1x) - A * k.Bk[4], -(dg0y + dg1y) - A * k.Bk[5]);
+        } else {
+            gu[0] = make_double2(dg0x, dg0y);
+            gu[1] = make_double2(dg1x, dg1y);
+            gu[2] = make_double2(-(dg0x + dg1x), -(dg0y + dg1y));
+        }
         const double ddet = (det < 0.0 ? -dens : dens) -
                             (p00 * h00 + p01 * (h01 + h10) + p11 * h11) * inv;
         const double da = (p01 * g1x + p11 * g1y) * inv + ddet * d;

@@ -232,6 +232,119 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 #undef HFEM_STAMP
 }
 
+// ------------------------------------------------------------------ tiled, register-prefetched
+// Production variant of the tiled kernel: same phases, but everything a thread will need is
+// requested up front -- its row-map entries AND its packed element records go out with the first
+// loads (so the element loop starts on registers instead of a global-load latency per iteration),
+// and the row maps stay in registers for the write-out (no re-load).  HASB compiles the body-force
+// table out.  NPT >= ceil(max nodes/BLOCK), EPT >= ceil(max element slots/BLOCK); the launcher
+// falls back to tri3_energy_tiled_kernel when a plan exceeds them.
+template <int BLOCK, int NPT, int EPT, bool HASB>
+__global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
+    PlanDev pd, int tile_begin, const double2 *__restrict__ x_free,
+    const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
+    const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
+    double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
+    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges) {
+    extern __shared__ double2 lds[];
+    double2 *nd_xy = lds;
+    double2 *nd_uv = lds + cap_nodes;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
+
+    const int tid = threadIdx.x;
+    const int slot = xcd_tile(blockIdx.x, gridDim.x);
+    const TileDesc d = pd.tiles[tile_begin + slot];
+    const int n_owned = d.n_owned;
+
+    // ---- all index loads first: row maps and element records
+    int2 s[NPT];
+    uint32_t pk[EPT];
+    const int2 *src = pd.node_src + d.node_off;
+    const uint32_t *ep = pd.elem_pack + d.elem_off;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        s[j] = make_int2(0, 0);
+        if (l < d.n_node) s[j] = src[l];
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * BLOCK;
+        pk[j] = kSkipBit;
+        if (i < d.n_elem) pk[j] = ep[i];
+    }
+    // ---- gather through the row maps into LDS, clear the accumulators
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        if (l < d.n_node) {
+            nd_xy[l] = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
+            nd_uv[l] = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
+        }
+        if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
+    }
+    __syncthreads();
+
+    // ---- elements: registers + LDS only
+    double e_loc = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t p = pk[j];
+        if (!(p & kSkipBit)) {
+            const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask),
+                      l2 = (int)((p >> (2 * kLocalBits)) & kLocalMask);
+            double2 gx[3], gu[3];
+            const double e = tri3_element<true, HASB>(nd_xy[l0], nd_xy[l1], nd_xy[l2], nd_uv[l0], nd_uv[l1],
+                                                      nd_uv[l2], k, gx, gu);
+            if (p & kHomeBit) e_loc += e;
+            if (l0 < n_owned) {
+                unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
+                unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
+            }
+            if (l1 < n_owned) {
+                unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
+                unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
+            }
+            if (l2 < n_owned) {
+                unsafeAtomicAdd(&acc0[l2], gx[2].x); unsafeAtomicAdd(&acc1[l2], gx[2].y);
+                unsafeAtomicAdd(&acc2[l2], gu[2].x); unsafeAtomicAdd(&acc3[l2], gu[2].y);
+            }
+        }
+    }
+    const int n_edge = skip_edges ? 0 : d.n_edge;
+    for (int i = tid; i < n_edge; i += BLOCK) {          // boundary tiles only
+        const uint32_t p = pd.edge_pack[d.edge_off + i];
+        const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
+        const double4 tt = T_edge ? T_edge[pd.edge_gid[d.edge_off + i]] : Tconst;
+        double2 gx[2], gu[2];
+        const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
+        if (p & kHomeBit) e_loc -= wk;
+        if (l0 < n_owned) {
+            unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
+            unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
+        }
+        if (l1 < n_owned) {
+            unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
+            unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
+        }
+    }
+    __syncthreads();
+
+    // ---- every owned gradient row is written exactly once (row maps are still in registers)
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        if (l < n_owned) {
+            if (gx_free && s[j].x >= 0) gx_free[s[j].x] = make_double2(acc0[l], acc1[l]);
+            if (gu_free && s[j].y >= 0) gu_free[s[j].y] = make_double2(acc2[l], acc3[l]);
+        }
+    }
+    const double tot = block_sum(e_loc, red);
+    if (tid == 0) partials[slot] = tot;
+}
+
 // ------------------------------------------------------------------ persistent, pipelined
 // Same tile algorithm, but a workgroup walks a contiguous run of tiles and overlaps the HBM
 // phase of tile t+1 with the VALU/LDS phase of tile t (register-staged prefetch): the gather of
@@ -459,6 +572,7 @@ static int g_tiled_ablate = 0;
 static int g_plan_elem_order = 3;  // LDS-bank-aware 16-lane groups (plan.cpp order_tile_elements)
 static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
 static int g_tiled_stagger_mode = 0;
+static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
 struct hfem_plan {
@@ -688,7 +802,30 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, g_tiled_stagger,         \
                        g_tiled_stagger_mode, plan->d_stamps)
         const int abl = g_tiled_ablate;
-        if (abl == 0) {
+        bool fast = false;
+        if (abl == 0 && g_tiled_fast) {
+            const HostPlan &h = plan->host;
+            bool hasb = false;
+            for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
+#define HFEM_LAUNCH_FAST(BLK, NPT, EPT, HB)                                                                 \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
+                       pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
+                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
+                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0)
+#define HFEM_FAST_HB(BLK, NPT, EPT) { if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true); else HFEM_LAUNCH_FAST(BLK, NPT, EPT, false); fast = true; }
+            const int blk = g_tiled_block;
+            if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
+            else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) HFEM_FAST_HB(512, 2, 4)
+            else if (blk == 256 && h.max_nodes <= 4 * 256 && h.max_elems <= 6 * 256) HFEM_FAST_HB(256, 4, 6)
+            else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_FAST_HB(1024, 1, 2)
+#undef HFEM_FAST_HB
+#undef HFEM_LAUNCH_FAST
+        }
+        if (fast) {
+        } else if (abl == 0) {
             switch (g_tiled_block) {
                 case 512: HFEM_LAUNCH_TILED(512, 0); break;
                 case 1024: HFEM_LAUNCH_TILED(1024, 0); break;
@@ -743,6 +880,8 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_tiled_stagger = value;
     } else if (n == "tiled_stagger_mode") {
         g_tiled_stagger_mode = value;
+    } else if (n == "tiled_fast") {
+        g_tiled_fast = value ? 1 : 0;
     } else if (n == "tiled_pipe") {
         HFEM_ARG_CHECK(value >= 0 && value <= 8, "tiled_pipe must be 0..8 workgroups per CU");
         g_tiled_pipe = value;
@@ -763,6 +902,7 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "tiled_ablate") return g_tiled_ablate;
     if (n == "plan_elem_order") return g_plan_elem_order;
     if (n == "tiled_pipe") return g_tiled_pipe;
+    if (n == "tiled_fast") return g_tiled_fast;
     if (n == "tiled_stagger") return g_tiled_stagger;
     if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
     return -1;

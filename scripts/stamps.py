@@ -16,7 +16,7 @@ torch.manual_seed(0)
 model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(dev)
 lf = EnergyLoss2D(device=dev, dtype=f64, tile_elems=a.tile)
 plan = TilePlan(model.connectivity, model.Nnodes, coords_hint=model.initial_node_coords, x_src=model._x_src,
-                u_src=model._u_src, edges=model.neumann_edges, tile_elems=a.tile, device=dev, elem_order=2)
+                u_src=model._u_src, edges=model.neumann_edges, tile_elems=a.tile, device=dev, elem_order=3)
 L = _lib.lib(); dv = lambda v: (C.c_double * len(v))(*v)
 xf, uf = model.node_coords_free.detach(), model.u_free.detach(); xfix, ufix = model.node_coords_fixed, model.u_fixed_rows()
 _, Tconst = lf._traction(model, None)

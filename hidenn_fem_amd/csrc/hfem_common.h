@@ -54,6 +54,8 @@ struct HostPlan {
 // Build the owner-computes tiling.  Returns 0 or -1 (message via set_error).
 int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
-                    int64_t ned, int32_t tile_elems, int elem_order, HostPlan &out);
+                    int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, HostPlan &out);
+
+void set_plan_curve(int c);   // 0 Morton, 1 Hilbert (default)
 
 }  // namespace hfem

@@ -42,6 +42,25 @@ inline uint32_t spread16(uint32_t v) {   // 16 bits -> every other bit of 32
     return v;
 }
 
+// Position of cell (x, y) along a Hilbert curve of side 2^16.  Consecutive positions are always
+// edge-adjacent cells, so a run of the sorted element list is one connected, compact patch (Morton
+// runs can fall apart into several pieces): smaller tile perimeter -> fewer halo elements/nodes.
+inline uint32_t hilbert16(uint32_t x, uint32_t y) {
+    uint32_t d = 0;
+    for (uint32_t s = 1u << 15; s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {                       // rotate the quadrant
+            if (rx == 1) { x = 65535u - x; y = 65535u - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
+static int g_curve = 1;   // 0 Morton, 1 Hilbert
+void set_locality_curve(int c) { g_curve = c; }
+
 void morton_order(const int64_t *conn, int64_t ne, int64_t nn, const double *xy,
                   std::vector<int32_t> &order) {
     order.resize(ne);
@@ -74,7 +93,7 @@ void morton_order(const int64_t *conn, int64_t ne, int64_t nn, const double *xy,
             if (v > 65535.0) v = 65535.0;
             q[a] = (uint32_t)v;
         }
-        const uint64_t code = spread16(q[0]) | (spread16(q[1]) << 1);
+        const uint64_t code = g_curve ? hilbert16(q[0], q[1]) : (spread16(q[0]) | (spread16(q[1]) << 1));
         keys[e] = (code << 32) | (uint64_t)(uint32_t)e;   // ties: element id (stable)
     }
     std::sort(keys.begin(), keys.end());
@@ -198,13 +217,52 @@ void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, cons
 }
 
 // returns 0 ok, 1 = a tile exceeded kMaxLocal nodes (retry smaller), -1 error
+// Cut the sorted element list into tiles: at most T elements AND at most `node_cap` distinct nodes
+// among a tile's own elements (node_cap <= 0: no node limit).  Cutting by nodes equalises the LDS
+// footprint of the tiles, so the launch-wide maximum (which sizes every workgroup) sits near the
+// median and more workgroups fit per CU.
+void cut_tiles(const int64_t *conn, int64_t ne, int64_t nn, const std::vector<int32_t> &order, int32_t T,
+               int32_t node_cap, std::vector<int64_t> &bounds) {
+    bounds.assign(1, 0);
+    if (node_cap <= 0) {
+        for (int64_t p = T; p < ne; p += T) bounds.push_back(p);
+        bounds.push_back(ne);
+        return;
+    }
+    std::vector<int32_t> stamp(nn, -1);
+    int32_t tile = 0, distinct = 0;
+    int64_t start = 0;
+    for (int64_t p = 0; p < ne; ++p) {
+        const int64_t e = order[p];
+        int fresh = 0;
+        for (int k = 0; k < 3; ++k)
+            if (stamp[conn[3 * e + k]] != tile) ++fresh;
+        if (p > start && (p - start >= T || distinct + fresh > node_cap)) {
+            bounds.push_back(p);
+            ++tile;
+            start = p;
+            distinct = 0;
+        }
+        for (int k = 0; k < 3; ++k) {
+            int32_t &st = stamp[conn[3 * e + k]];
+            if (st != tile) { st = tile; ++distinct; }
+        }
+    }
+    bounds.push_back(ne);
+}
+
 int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
-              const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T,
+              const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T, int32_t node_cap,
               const std::vector<int32_t> &order, int elem_order, HostPlan &P) {
-    const int32_t nt_main = (int32_t)((ne + T - 1) / T);
+    std::vector<int64_t> bounds;
+    cut_tiles(conn, ne, nn, order, T, node_cap, bounds);
+    const int32_t nt_main = ne > 0 ? (int32_t)bounds.size() - 1 : 0;
+    std::vector<int32_t> tile_of(ne);                    // sorted position -> tile
+    for (int32_t t = 0; t < nt_main; ++t)
+        for (int64_t p = bounds[t]; p < bounds[t + 1]; ++p) tile_of[p] = t;
     std::vector<int32_t> owner(nn, std::numeric_limits<int32_t>::max());
     for (int64_t p = 0; p < ne; ++p) {
-        const int32_t t = (int32_t)(p / T);
+        const int32_t t = tile_of[p];
         const int64_t e = order[p];
         for (int k = 0; k < 3; ++k) {
             int32_t &o = owner[conn[3 * e + k]];
@@ -232,7 +290,7 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
     }
     // home tile of every element
     std::vector<int32_t> home(ne);
-    for (int64_t p = 0; p < ne; ++p) home[order[p]] = (int32_t)(p / T);
+    for (int64_t p = 0; p < ne; ++p) home[order[p]] = tile_of[p];
 
     // owned nodes per tile (ascending node id), edges per tile
     std::vector<int64_t> own_ptr(nt + 1, 0), edg_ptr(nt + 1, 0);
@@ -271,7 +329,7 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
         halo.clear();
         // elements: home first (sorted order), then halo in discovery order
         if (t < nt_main) {
-            const int64_t p0 = (int64_t)t * T, p1 = std::min<int64_t>(ne, p0 + T);
+            const int64_t p0 = bounds[t], p1 = bounds[t + 1];
             for (int64_t p = p0; p < p1; ++p) { stamp_e[order[p]] = t; telems.push_back(order[p]); }
         }
         const int64_t o0 = own_ptr[t], o1 = own_ptr[t + 1];
@@ -348,9 +406,11 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
 
 }  // namespace
 
+void set_plan_curve(int c) { set_locality_curve(c); }
+
 int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
-                    int64_t ned, int32_t tile_elems, int elem_order, HostPlan &out) {
+                    int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, HostPlan &out) {
     if (ne < 0 || nn < 0 || ned < 0 || nn > std::numeric_limits<int32_t>::max() ||
         ne > std::numeric_limits<int32_t>::max() || ned > std::numeric_limits<int32_t>::max()) {
         set_error("plan: sizes must be in [0, 2^31)");
@@ -367,7 +427,7 @@ int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *c
     std::vector<int32_t> order;
     morton_order(conn, ne, nn, coords, order);
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
-        const int rc = try_build(conn, ne, nn, x_src, u_src, edges, ned, T, order, elem_order, out);
+        const int rc = try_build(conn, ne, nn, x_src, u_src, edges, ned, T, node_cap, order, elem_order, out);
         if (rc <= 0) return rc;
     }
     set_error("plan: could not fit a tile into 1024 local nodes (node valence too high?)");

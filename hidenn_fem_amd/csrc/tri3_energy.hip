@@ -239,13 +239,17 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // and the row maps stay in registers for the write-out (no re-load).  HASB compiles the body-force
 // table out.  NPT >= ceil(max nodes/BLOCK), EPT >= ceil(max element slots/BLOCK); the launcher
 // falls back to tri3_energy_tiled_kernel when a plan exceeds them.
-template <int BLOCK, int NPT, int EPT, bool HASB>
+template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false>
 __global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free,
     const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
     const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
-    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges) {
+    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges,
+    unsigned long long *__restrict__ stamps) {
+#define HFEM_FSTAMP(I)                                                                             \
+    if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+    HFEM_FSTAMP(0)
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
     double2 *nd_uv = lds + cap_nodes;
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
     const int slot = xcd_tile(blockIdx.x, gridDim.x);
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
+    if (STAMP && threadIdx.x == 0 && n_owned >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- all index loads first: row maps and element records
     int2 s[NPT];
@@ -285,7 +290,10 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
         }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
+    if (tid == 0) red[0] = 0.0;
+    HFEM_FSTAMP(2)
     __syncthreads();
+    HFEM_FSTAMP(3)
 
     // ---- elements: registers + LDS only
     double e_loc = 0.0;
@@ -330,7 +338,14 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
             unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
         }
     }
+    // tile energy: wave shuffle reduction, one LDS atomic per wave -- rides on the barrier below
+    {
+        const double w = wave_sum(e_loc);
+        if ((tid & 63) == 0) unsafeAtomicAdd(&red[0], w);
+    }
+    HFEM_FSTAMP(4)
     __syncthreads();
+    HFEM_FSTAMP(5)
 
     // ---- every owned gradient row is written exactly once (row maps are still in registers)
 #pragma unroll
@@ -341,8 +356,10 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
             if (gu_free && s[j].y >= 0) gu_free[s[j].y] = make_double2(acc2[l], acc3[l]);
         }
     }
-    const double tot = block_sum(e_loc, red);
-    if (tid == 0) partials[slot] = tot;
+    HFEM_FSTAMP(6)
+    if (tid == 0) partials[slot] = red[0];
+    HFEM_FSTAMP(7)
+#undef HFEM_FSTAMP
 }
 
 // ------------------------------------------------------------------ persistent, pipelined
@@ -572,6 +589,7 @@ static int g_tiled_ablate = 0;
 static int g_plan_elem_order = 3;  // LDS-bank-aware 16-lane groups (plan.cpp order_tile_elements)
 static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
 static int g_tiled_stagger_mode = 0;
+static int g_plan_node_cap = 0;  // max distinct nodes among a tile's own elements (0: cut by element count only)
 static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
@@ -669,7 +687,7 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
     HFEM_ARG_CHECK(out, "null out pointer");
     *out = nullptr;
     std::unique_ptr<hfem_plan> p(new hfem_plan);
-    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, g_plan_elem_order, p->host)) return -1;
+    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, g_plan_node_cap, g_plan_elem_order, p->host)) return -1;
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
@@ -803,6 +821,17 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        g_tiled_stagger_mode, plan->d_stamps)
         const int abl = g_tiled_ablate;
         bool fast = false;
+        if (abl == 64 && g_tiled_fast && g_tiled_block == 512 && plan->host.max_nodes <= 1024 &&
+            plan->host.max_elems <= 2048) {      // lab: stamped instance of the production kernel
+            const HostPlan &h = plan->host;
+            hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, false, true>), dim3(n), dim3(512),
+                               (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const double2 *)x_free,
+                               (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
+                               make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
+                               (double2 *)gx_free, (double2 *)gu_free, h.max_nodes, h.max_owned,
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps);
+            fast = true;
+        }
         if (abl == 0 && g_tiled_fast) {
             const HostPlan &h = plan->host;
             bool hasb = false;
@@ -814,7 +843,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps)
 #define HFEM_FAST_HB(BLK, NPT, EPT) { if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true); else HFEM_LAUNCH_FAST(BLK, NPT, EPT, false); fast = true; }
             const int blk = g_tiled_block;
             if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
@@ -880,6 +909,12 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_tiled_stagger = value;
     } else if (n == "tiled_stagger_mode") {
         g_tiled_stagger_mode = value;
+    } else if (n == "plan_node_cap") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 1024, "plan_node_cap must be 0..1024");
+        g_plan_node_cap = value;
+    } else if (n == "plan_curve") {
+        HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");
+        set_plan_curve(value);
     } else if (n == "tiled_fast") {
         g_tiled_fast = value ? 1 : 0;
     } else if (n == "tiled_pipe") {
@@ -903,6 +938,7 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "plan_elem_order") return g_plan_elem_order;
     if (n == "tiled_pipe") return g_tiled_pipe;
     if (n == "tiled_fast") return g_tiled_fast;
+    if (n == "plan_node_cap") return g_plan_node_cap;
     if (n == "tiled_stagger") return g_tiled_stagger;
     if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
     return -1;

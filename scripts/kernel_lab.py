@@ -30,11 +30,13 @@ def main():
     ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--permute", action="store_true")
     ap.add_argument("--flags", type=int, default=8)
-    ap.add_argument("--orders", default="0")
+    ap.add_argument("--orders", default="3")
     ap.add_argument("--pipes", default="0")
     ap.add_argument("--staggers", default="0", help="total start spread in 10 ns ticks")
     ap.add_argument("--smodes", default="0")
     ap.add_argument("--fast", default="1")
+    ap.add_argument("--curve", type=int, default=1)
+    ap.add_argument("--caps", default="0")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     f64 = torch.float64
@@ -50,9 +52,11 @@ def main():
     ref = None
     rows = []
     from hidenn_fem_amd.plan import TilePlan
-    for T, order, fastv in [(int(t), int(o), int(f)) for t in a.tiles.split(",") for o in a.orders.split(",")
-                            for f in a.fast.split(",")]:
+    _lib.check(L.hfem_set_option(b"plan_curve", a.curve))
+    for T, order, fastv, cap in [(int(t), int(o), int(f), int(c_)) for t in a.tiles.split(",") for o in a.orders.split(",")
+                                 for f in a.fast.split(",") for c_ in a.caps.split(",")]:
         _lib.check(L.hfem_set_option(b"tiled_fast", fastv))
+        _lib.check(L.hfem_set_option(b"plan_node_cap", cap))
         lf = EnergyLoss2D(device=dev, dtype=f64, tile_elems=T)
         plan = TilePlan(model.connectivity, model.Nnodes, coords_hint=model.initial_node_coords,
                         x_src=model._x_src, u_src=model._u_src, edges=model.neumann_edges, tile_elems=T,
@@ -115,7 +119,7 @@ def main():
                     torch.cuda.synchronize()
                     best = min(best, e0.elapsed_time(e1) * 1e3 / a.reps)
                 st = plan.stats
-                row = dict(T=T, order=order, fast=fastv, tiles=st["n_tiles"], lds=st["lds_bytes"], block=B, pipe=pipe, stagger=stg, smode=smode, ablate=abl, us=round(best, 2),
+                row = dict(T=T, cap=cap, curve=a.curve, order=order, fast=fastv, tiles=st["n_tiles"], lds=st["lds_bytes"], block=B, pipe=pipe, stagger=stg, smode=smode, ablate=abl, us=round(best, 2),
                            GBs=round(alg / best / 1e3, 1), frac=round(alg / best / 1e3 / 8000, 3), check=ok)
                 rows.append(row)
                 print(json.dumps(row), flush=True)

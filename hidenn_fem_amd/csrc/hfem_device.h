@@ -85,6 +85,11 @@ __device__ __forceinline__ double fast_rcp(double x) {
 //   e = abs(detJ) (W psi - sum_k U_k.B_k)                 src/loss.py:80-88
 // and the hand-derived backward w.r.t. U (gu[k][i]) and X (gx[k][i]).
 // HASB = false compiles the body-force table out (B_k = 0: the reference's default, loss.py:43-45).
+//
+// Operation count (fp64, HASB = false): 73 + one v_rcp_f64.  Two identities keep it low:
+//   * a,b,c,d are pre-scaled by 1/det once (ai..di); H and dL/dG then need no trailing multiply;
+//   * sum_ij P_ij H_ij = A W (eps . sigma) = 2 A W psi, and A/det = sign(det), so
+//     dL/d(det) = sign(det) (W psi - beta) - 2 W sign(det) psi = -sign(det) (W psi + beta).
 template <bool GRAD, bool HASB = true>
 __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X1, const double2 X2,
                                                const double2 U0, const double2 U1, const double2 U2,
@@ -93,24 +98,27 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
     const double det = a * d - b * c;
     const double inv = fast_rcp(det);
     const double A = fabs(det);
+    const double ai = a * inv, bi = b * inv, ci = c * inv, di = d * inv;      // rows of Jinv (up to sign/placement)
     const double g0x = U0.x - U2.x, g0y = U0.y - U2.y;
     const double g1x = U1.x - U2.x, g1y = U1.y - U2.y;
-    const double h00 = (g0x * d - g1x * b) * inv, h01 = (g1x * a - g0x * c) * inv;
-    const double h10 = (g0y * d - g1y * b) * inv, h11 = (g1y * a - g0y * c) * inv;
+    const double h00 = g0x * di - g1x * bi, h01 = g1x * ai - g0x * ci;      // H = G Jinv^T (reference convention, F4)
+    const double h10 = g0y * di - g1y * bi, h11 = g1y * ai - g0y * ci;
     const double gam = h01 + h10;
     const double sxx = k.c11 * h00 + k.c12 * h11;
     const double syy = k.c12 * h00 + k.c22 * h11;
     const double sxy = k.c33 * gam;
-    const double psi = 0.5 * (h00 * sxx + h11 * syy + gam * sxy);
-    double dens = k.W * psi;
-    if (HASB)
-        dens -= U0.x * k.Bk[0] + U0.y * k.Bk[1] + U1.x * k.Bk[2] + U1.y * k.Bk[3] + U2.x * k.Bk[4] +
-                U2.y * k.Bk[5];
+    const double wpsi = (0.5 * k.W) * (h00 * sxx + h11 * syy + gam * sxy);   // W psi
+    double dens = wpsi;
+    double beta = 0.0;
+    if (HASB) {
+        beta = U0.x * k.Bk[0] + U0.y * k.Bk[1] + U1.x * k.Bk[2] + U1.y * k.Bk[3] + U2.x * k.Bk[4] + U2.y * k.Bk[5];
+        dens -= beta;
+    }
     if (GRAD) {
         const double aw = A * k.W;
-        const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;   // P[1][0] = p01
-        const double dg0x = (p00 * d - p01 * c) * inv, dg0y = (p01 * d - p11 * c) * inv;
-        const double dg1x = (p01 * a - p00 * b) * inv, dg1y = (p11 * a - p01 * b) * inv;
+        const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;         // P = dL/dH (P10 = P01)
+        const double dg0x = p00 * di - p01 * ci, dg0y = p01 * di - p11 * ci;
+        const double dg1x = p01 * ai - p00 * bi, dg1y = p11 * ai - p01 * bi;
         if (HASB) {
             gu[0] = make_double2(dg0x - A * k.Bk[0], dg0y - A * k.Bk[1]);
             gu[1] = make_double2(dg1x - A * k.Bk[2], dg1y - A * k.Bk[3]);
@@ -118,17 +126,18 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
         } else {
             gu[0] = make_double2(dg0x, dg0y);
             gu[1] = make_double2(dg1x, dg1y);
-            gu[2] = make_double2(-(dg0x + dg1x), -(dg0y + dg1y));
+            gu[2] = make_double2(-dg0x - dg1x, -dg0y - dg1y);
         }
-        const double ddet = (det < 0.0 ? -dens : dens) -
-                            (p00 * h00 + p01 * (h01 + h10) + p11 * h11) * inv;
-        const double da = (p01 * g1x + p11 * g1y) * inv + ddet * d;
-        const double db = -(p00 * g1x + p01 * g1y) * inv - ddet * c;
-        const double dc = -(p01 * g0x + p11 * g0y) * inv - ddet * b;
-        const double dd = (p00 * g0x + p01 * g0y) * inv + ddet * a;
+        const double q = det < 0.0 ? -k.W : k.W;                              // W sign(det) = A W / det
+        const double wb = HASB ? wpsi + beta : wpsi;
+        const double ddet = det < 0.0 ? wb : -wb;                             // -sign(det) (W psi + beta)
+        const double da = q * (sxy * g1x + syy * g1y) + ddet * d;
+        const double db = -q * (sxx * g1x + sxy * g1y) - ddet * c;
+        const double dc = -q * (sxy * g0x + syy * g0y) - ddet * b;
+        const double dd = q * (sxx * g0x + sxy * g0y) + ddet * a;
         gx[0] = make_double2(da, dc);
         gx[1] = make_double2(db, dd);
-        gx[2] = make_double2(-(da + db), -(dc + dd));
+        gx[2] = make_double2(-da - db, -dc - dd);
     }
     return A * dens;
 }

@@ -589,7 +589,10 @@ static int g_tiled_ablate = 0;
 static int g_plan_elem_order = 3;  // LDS-bank-aware 16-lane groups (plan.cpp order_tile_elements)
 static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
 static int g_tiled_stagger_mode = 0;
-static int g_plan_node_cap = 0;  // max distinct nodes among a tile's own elements (0: cut by element count only)
+static int g_plan_node_cap = -1; // max distinct nodes among a tile's own elements; 0: cut by element count only;
+                                 // -1 (auto): 557 when tile_elems is left to the library, else 0.  557 nodes keep
+                                 // (n_node + n_owned) * 32 B <= 38.9 KB, the largest footprint that still lets four
+                                 // 512-thread workgroups share a CU's 160 KB of LDS (measured).
 static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
@@ -687,7 +690,10 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
     HFEM_ARG_CHECK(out, "null out pointer");
     *out = nullptr;
     std::unique_ptr<hfem_plan> p(new hfem_plan);
-    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, g_plan_node_cap, g_plan_elem_order, p->host)) return -1;
+    int32_t node_cap = g_plan_node_cap;
+    if (node_cap < 0) node_cap = tile_elems <= 0 ? 557 : 0;
+    if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
+    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, p->host)) return -1;
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
@@ -910,7 +916,7 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "tiled_stagger_mode") {
         g_tiled_stagger_mode = value;
     } else if (n == "plan_node_cap") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 1024, "plan_node_cap must be 0..1024");
+        HFEM_ARG_CHECK(value >= -1 && value <= 1024, "plan_node_cap must be -1 (auto), 0 (off) or 1..1024");
         g_plan_node_cap = value;
     } else if (n == "plan_curve") {
         HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");

@@ -12,7 +12,7 @@ from hidenn_fem_amd.plan import TilePlan
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--tile", type=int, default=1024); ap.add_argument("--block", type=int, default=512)
-ap.add_argument("--order", type=int, default=2); ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--order", type=int, default=3); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--pipe", type=int, default=0); ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--nx", type=int, default=1001); ap.add_argument("--ny", type=int, default=501)
 a = ap.parse_args()

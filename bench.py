@@ -16,7 +16,7 @@ rank evaluates its contiguous tile range and ONE all-reduce of the packed [gX|gU
 follows.
 
 One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel
-(tri3_energy_tiled_kernel): algorithmic bytes (12 Ne + 64 Nn + 8) over its
+(tri3_energy_fast_kernel): algorithmic bytes (12 Ne + 64 Nn + 8) over its
 average back-to-back launch time measured with HIP events on the launch stream.
 ``cpu_baseline`` times the oracle's op-for-op PyTorch restatement of the reference chain on the
 host cores, on the same workload (bounded number of evaluations).
@@ -212,16 +212,19 @@ def main():
     if kgraph is not None:
         kgraph.replay()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    if kgraph is not None:
-        kgraph.replay()
-    else:
-        for _ in range(kreps):
-            kernel_only()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    k_us = ev0.elapsed_time(ev1) * 1e3 / kreps
+    samples = []
+    for _ in range(5):                      # 5 timed regions of `kreps` back-to-back launches each
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        if kgraph is not None:
+            kgraph.replay()
+        else:
+            for _ in range(kreps):
+                kernel_only()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        samples.append(ev0.elapsed_time(ev1) * 1e3 / kreps)
+    k_us = sorted(samples)[len(samples) // 2]       # median region; each value is already a kreps-launch average
     # algorithmic bytes of ONE launch on this rank: its home elements and owned nodes
     ne_launch = int(td[lo:hi, 1].sum()) if world > 1 else ne      # (halo elements are not algorithmic work)
     if world > 1:
@@ -230,8 +233,18 @@ def main():
     nn_launch = int(td[lo:hi, 4].sum())
     alg_bytes = 12 * ne_launch + 64 * nn_launch + 8
     achieved = alg_bytes / (k_us * 1e-6) / 1e9
+    # HBM traffic per launch: PMC numbers cannot be collected from inside this process; they come from the
+    # committed rocprofv3 passes of the SAME kernel/workload (profiles/r01_hbm_traffic_T1M.json), else null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_T1M.json")) as f:
+            tr = json.load(f)
+        if world == 1 and tr["workload"] == dict(elements=ne, nodes=nn, tiles=plan.stats["n_tiles"]):
+            traffic = tr["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=None, kernel="tri3_energy_tiled_kernel", kernel_us=k_us,
+                    traffic=traffic, kernel="tri3_energy_fast_kernel", kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
                     alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
 
     out = None

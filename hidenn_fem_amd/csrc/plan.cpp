@@ -110,55 +110,54 @@ constexpr int kOrphanTileNodes = 512;
 //   mode 3: LDS-bank-aware groups (default).  ds_add_f64 is serviced in groups of 16 consecutive
 //           lanes over 16 eight-byte slots (measured): a group is conflict-free
 //           iff, for each of the three corner positions, the owned nodes' local ids are distinct
-//           mod 16.  Elements are packed greedily into such groups (window of 32 open groups); a
-//           group that cannot be completed is padded with skip records (-1), ~11 % on T1M.
+//           mod 16.  Elements are packed greedily into such groups, most-constrained first; a group
+//           that cannot be completed is padded with skip records (-1), ~2 % on T1M.
 void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, const std::vector<int32_t> &lid,
                          int32_t n_owned, int mode) {
     const int n = (int)telems.size();
     if (mode == 3) {
-        constexpr int G = 16, W = 32;
+        constexpr int G = 16;
         struct Open { std::vector<int32_t> el; uint16_t used[3]; };
+        // most-constrained first: elements with 3 owned corners, then 2, 1, 0 (stable: curve order kept
+        // inside a class).  The flexible ones (halo elements, few owned corners) then fill the holes the
+        // constrained ones leave; with no window limit this brings the padding from ~8 % to ~2 %.
+        std::vector<int32_t> byc[4];
+        for (int i = 0; i < n; ++i) {
+            int owned = 0;
+            for (int k = 0; k < 3; ++k) owned += lid[conn[3 * (int64_t)telems[i] + k]] < n_owned;
+            byc[3 - owned].push_back(telems[i]);
+        }
         std::vector<Open> open;
         std::vector<int32_t> out;
-        out.reserve(n + n / 6 + G);
-        auto close = [&](size_t j) {
-            Open &g = open[j];
-            out.insert(out.end(), g.el.begin(), g.el.end());
-            out.insert(out.end(), G - g.el.size(), -1);          // pad to a whole group
-            open.erase(open.begin() + (long)j);
-        };
-        for (int i = 0; i < n; ++i) {
-            const int32_t e = telems[i];
-            uint16_t bit[3];
-            for (int k = 0; k < 3; ++k) {
-                const int32_t l = lid[conn[3 * (int64_t)e + k]];
-                bit[k] = l < n_owned ? (uint16_t)(1u << (l & 15)) : 0;
-            }
-            bool placed = false;
-            for (Open &g : open) {
-                if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2])) continue;
-                g.el.push_back(e);
-                for (int k = 0; k < 3; ++k) g.used[k] |= bit[k];
-                placed = true;
-                break;
-            }
-            if (!placed) {
-                if ((int)open.size() >= W) {                     // retire the fullest open group
-                    size_t j = 0;
-                    for (size_t q = 1; q < open.size(); ++q)
-                        if (open[q].el.size() > open[j].el.size()) j = q;
-                    close(j);
+        out.reserve(n + n / 8 + G);
+        size_t first_open = 0;                                   // groups before this index are full
+        for (int cls = 0; cls < 4; ++cls)
+            for (int32_t e : byc[cls]) {
+                uint16_t bit[3];
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t l = lid[conn[3 * (int64_t)e + k]];
+                    bit[k] = l < n_owned ? (uint16_t)(1u << (l & 15)) : 0;
                 }
-                Open g;
-                g.el.push_back(e);
-                for (int k = 0; k < 3; ++k) g.used[k] = bit[k];
-                open.push_back(std::move(g));
+                bool placed = false;
+                for (size_t j = first_open; j < open.size(); ++j) {
+                    Open &g = open[j];
+                    if ((int)g.el.size() >= G) continue;
+                    if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2])) continue;
+                    g.el.push_back(e);
+                    for (int k = 0; k < 3; ++k) g.used[k] |= bit[k];
+                    placed = true;
+                    break;
+                }
+                if (!placed) {
+                    Open g;
+                    g.el.push_back(e);
+                    for (int k = 0; k < 3; ++k) g.used[k] = bit[k];
+                    open.push_back(std::move(g));
+                }
+                while (first_open < open.size() && (int)open[first_open].el.size() >= G) ++first_open;
             }
-            for (size_t j = open.size(); j-- > 0;)
-                if ((int)open[j].el.size() >= G) close(j);
-        }
-        // remaining groups: fullest first, the very last one needs no padding
-        std::sort(open.begin(), open.end(), [](const Open &a, const Open &b) { return a.el.size() > b.el.size(); });
+        // emit: full groups first, then partial ones fullest-first (the very last needs no padding)
+        std::stable_sort(open.begin(), open.end(), [](const Open &a, const Open &b) { return a.el.size() > b.el.size(); });
         for (size_t j = 0; j < open.size(); ++j) {
             out.insert(out.end(), open[j].el.begin(), open[j].el.end());
             if (j + 1 < open.size()) out.insert(out.end(), G - open[j].el.size(), -1);

@@ -239,8 +239,12 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // and the row maps stay in registers for the write-out (no re-load).  HASB compiles the body-force
 // table out.  NPT >= ceil(max nodes/BLOCK), EPT >= ceil(max element slots/BLOCK); the launcher
 // falls back to tri3_energy_tiled_kernel when a plan exceeds them.
+// __launch_bounds__(BLOCK, 8) on the default instances (no body force, >= 512 threads): 8 waves per
+// SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
+// residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
+// (forcing 64 VGPRs on them spills).
 template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false>
-__global__ __launch_bounds__(BLOCK) void tri3_energy_fast_kernel(
+__global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free,
     const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
     const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
 // residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
 // (forcing 64 VGPRs on them spills).
-template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false>
+template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free,
     const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
@@ -352,12 +352,32 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     HFEM_FSTAMP(5)
 
     // ---- every owned gradient row is written exactly once (row maps are still in registers)
+    // SP: cache policy of the gradient stores.  0 plain; 16 = sc1 (write-through, the line is dropped
+    // from the XCD's L2, so the once-written gradients do not evict the re-read inputs / plan arrays);
+    // 2 = nt.  (aux bits of the buffer store: sc0 = 1, nt = 2, sc1 = 16.)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rx, ru;
+    if (SP != 0) {
+        rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
+        ru = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
+    }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
         if (l < n_owned) {
-            if (gx_free && s[j].x >= 0) gx_free[s[j].x] = make_double2(acc0[l], acc1[l]);
-            if (gu_free && s[j].y >= 0) gu_free[s[j].y] = make_double2(acc2[l], acc3[l]);
+            if (SP == 0) {
+                if (gx_free && s[j].x >= 0) gx_free[s[j].x] = make_double2(acc0[l], acc1[l]);
+                if (gu_free && s[j].y >= 0) gu_free[s[j].y] = make_double2(acc2[l], acc3[l]);
+            } else {
+                if (gx_free && s[j].x >= 0) {
+                    const double2 v = make_double2(acc0[l], acc1[l]);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, SP);
+                }
+                if (gu_free && s[j].y >= 0) {
+                    const double2 v = make_double2(acc2[l], acc3[l]);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, SP);
+                }
+            }
         }
     }
     HFEM_FSTAMP(6)
@@ -597,6 +617,8 @@ static int g_plan_node_cap = -1; // max distinct nodes among a tile's own elemen
                                  // -1 (auto): 557 when tile_elems is left to the library, else 0.  557 nodes keep
                                  // (n_node + n_owned) * 32 B <= 38.9 KB, the largest footprint that still lets four
                                  // 512-thread workgroups share a CU's 160 KB of LDS (measured).
+static int g_store_policy = 16;  // gradient stores of the fast kernel: 16 = sc1 (write-through: the line is dropped from
+                                 // the XCD's L2 and does not evict the re-read inputs / plan arrays), 0 = plain
 static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
@@ -846,6 +868,14 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             const HostPlan &h = plan->host;
             bool hasb = false;
             for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
+#define HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, HB, SPV)                                                         \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, false, SPV>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
+                       pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
+                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
+                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps)
 #define HFEM_LAUNCH_FAST(BLK, NPT, EPT, HB)                                                                 \
     hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
@@ -854,7 +884,13 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
                        (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps)
-#define HFEM_FAST_HB(BLK, NPT, EPT) { if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true); else HFEM_LAUNCH_FAST(BLK, NPT, EPT, false); fast = true; }
+#define HFEM_FAST_HB(BLK, NPT, EPT)                                                   \
+    {                                                                                 \
+        if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true);                              \
+        else if (g_store_policy == 0) HFEM_LAUNCH_FAST(BLK, NPT, EPT, false);         \
+        else HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, false, 16);                           \
+        fast = true;                                                                  \
+    }
             const int blk = g_tiled_block;
             if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
             else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) HFEM_FAST_HB(512, 2, 4)
@@ -862,6 +898,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_FAST_HB(1024, 1, 2)
 #undef HFEM_FAST_HB
 #undef HFEM_LAUNCH_FAST
+#undef HFEM_LAUNCH_FAST_SP
         }
         if (fast) {
         } else if (abl == 0) {
@@ -925,6 +962,9 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "plan_curve") {
         HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");
         set_plan_curve(value);
+    } else if (n == "store_policy") {
+        HFEM_ARG_CHECK(value == 0 || value == 16, "store_policy: 0 (plain) or 16 (sc1 write-through)");
+        g_store_policy = value;
     } else if (n == "tiled_fast") {
         g_tiled_fast = value ? 1 : 0;
     } else if (n == "tiled_pipe") {
@@ -948,6 +988,7 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "plan_elem_order") return g_plan_elem_order;
     if (n == "tiled_pipe") return g_tiled_pipe;
     if (n == "tiled_fast") return g_tiled_fast;
+    if (n == "store_policy") return g_store_policy;
     if (n == "plan_node_cap") return g_plan_node_cap;
     if (n == "tiled_stagger") return g_tiled_stagger;
     if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;

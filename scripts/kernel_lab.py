@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--fast", default="1")
     ap.add_argument("--curve", type=int, default=1)
     ap.add_argument("--caps", default="0")
+    ap.add_argument("--stores", default="16")
+    ap.add_argument("--rewrite", action="store_true",
+                    help="rewrite x_free/u_free between launches (optimizer-like); reports the energy kernel time "
+                         "as (rewrite+energy) - (rewrite only)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     f64 = torch.float64
@@ -74,9 +78,10 @@ def main():
                                                gx.data_ptr(), gu.data_ptr(), flags, stream))
 
         for B in [int(b) for b in a.blocks.split(",")]:
-            for abl, pipe, stg, smode in [(int(x), int(q), int(g_), int(m_)) for x in a.ablate.split(",")
-                                          for q in a.pipes.split(",") for g_ in a.staggers.split(",")
-                                          for m_ in a.smodes.split(",")]:
+            for abl, pipe, stg, smode, sp in [(int(x), int(q), int(g_), int(m_), int(s_)) for x in a.ablate.split(",")
+                                              for q in a.pipes.split(",") for g_ in a.staggers.split(",")
+                                              for m_ in a.smodes.split(",") for s_ in a.stores.split(",")]:
+                _lib.check(L.hfem_set_option(b"store_policy", sp))
                 if pipe and (abl or stg):
                     continue
                 if stg == 0 and smode != int(a.smodes.split(",")[0]):
@@ -104,22 +109,39 @@ def main():
                     launch(a.flags, s.cuda_stream)
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for _ in range(a.reps):
-                        launch(a.flags, torch.cuda.current_stream().cuda_stream)
-                g.replay()
-                torch.cuda.synchronize()
-                best = 1e9
-                for _ in range(5):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+                def timed(body):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(a.reps):
+                            body()
                     g.replay()
-                    e1.record()
                     torch.cuda.synchronize()
-                    best = min(best, e0.elapsed_time(e1) * 1e3 / a.reps)
+                    b_ = 1e9
+                    for _ in range(5):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        g.replay()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        b_ = min(b_, e0.elapsed_time(e1) * 1e3 / a.reps)
+                    return b_
+
+                def energy():
+                    launch(a.flags, torch.cuda.current_stream().cuda_stream)
+
+                def rewrite():                 # what an optimiser step does to the inputs: read-modify-write
+                    xf.mul_(1.0)
+                    uf.mul_(1.0)
+
+                if a.rewrite:
+                    rewrite(); torch.cuda.synchronize()
+                    t_rw = timed(rewrite)
+                    t_both = timed(lambda: (rewrite(), energy()))
+                    best = t_both - t_rw
+                else:
+                    best = timed(energy)
                 st = plan.stats
-                row = dict(T=T, cap=cap, curve=a.curve, order=order, fast=fastv, tiles=st["n_tiles"], lds=st["lds_bytes"], block=B, pipe=pipe, stagger=stg, smode=smode, ablate=abl, us=round(best, 2),
+                row = dict(T=T, cap=cap, curve=a.curve, order=order, fast=fastv, tiles=st["n_tiles"], lds=st["lds_bytes"], block=B, store=sp, pipe=pipe, stagger=stg, smode=smode, ablate=abl, us=round(best, 2),
                            GBs=round(alg / best / 1e3, 1), frac=round(alg / best / 1e3 / 8000, 3), check=ok)
                 rows.append(row)
                 print(json.dumps(row), flush=True)
@@ -127,6 +149,7 @@ def main():
     _lib.check(L.hfem_set_option(b"tiled_ablate", 0))
     _lib.check(L.hfem_set_option(b"tiled_pipe", 0))
     _lib.check(L.hfem_set_option(b"tiled_stagger", 0))
+    _lib.check(L.hfem_set_option(b"store_policy", 0))
 
 
 if __name__ == "__main__":

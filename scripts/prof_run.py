@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tile", type=int, default=1024); ap.add_argument("--block", type=int, default=512)
 ap.add_argument("--order", type=int, default=3); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--pipe", type=int, default=0); ap.add_argument("--ablate", type=int, default=0)
+ap.add_argument("--rewrite", action="store_true"); ap.add_argument("--store", type=int, default=16)
 ap.add_argument("--nx", type=int, default=1001); ap.add_argument("--ny", type=int, default=501)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); f64 = torch.float64
@@ -29,8 +30,10 @@ xfix, ufix = model.node_coords_fixed, model.u_fixed_rows()
 _, Tconst = lf._traction(model, None)
 loss = torch.zeros((), dtype=f64, device=dev); gx, gu = torch.zeros_like(xf), torch.zeros_like(uf)
 _lib.check(L.hfem_set_option(b"tiled_block", a.block)); _lib.check(L.hfem_set_option(b"tiled_pipe", a.pipe))
-_lib.check(L.hfem_set_option(b"tiled_ablate", a.ablate))
+_lib.check(L.hfem_set_option(b"tiled_ablate", a.ablate)); _lib.check(L.hfem_set_option(b"store_policy", a.store))
 for _ in range(a.reps):
+    if a.rewrite:
+        xf.mul_(1.0); uf.mul_(1.0)
     _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr(), uf.data_ptr(), ufix.data_ptr(),
                                        dv(lf._mat), lf._W, dv([0.0] * 6), None, dv(Tconst), 0, -1, loss.data_ptr(),
                                        gx.data_ptr(), gu.data_ptr(), 0, torch.cuda.current_stream().cuda_stream))

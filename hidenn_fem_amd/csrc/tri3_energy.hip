@@ -856,7 +856,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         if (abl == 64 && g_tiled_fast && g_tiled_block == 512 && plan->host.max_nodes <= 1024 &&
             plan->host.max_elems <= 2048) {      // lab: stamped instance of the production kernel
             const HostPlan &h = plan->host;
-            hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, false, true>), dim3(n), dim3(512),
+            hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, false, true, 16>), dim3(n), dim3(512),
                                (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const double2 *)x_free,
                                (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
                                make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin,

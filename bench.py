@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--cpu-evals", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                                                      "for rehearsing the multi-rank path on fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -83,12 +85,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a ROCm device; there is no CPU fallback"
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and world > ndev:
+        sys.exit(f"bench.py: {world} ranks but {ndev} GPU(s) visible (RCCL needs one GPU per rank)")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     import __graft_entry__
     if rank == 0:
@@ -268,7 +277,7 @@ def main():
                         elements=ne, nodes=nn, elements_per_gpu=ne // world, tiles=st["n_tiles"],
                         tile_elems=st["tile_elems"], halo_elem_factor=st["tile_elem_total"] / max(ne, 1),
                         lds_bytes=st["lds_bytes"], launch="hipgraph" if graph is not None else "eager",
-                        exchange="none" if world == 1 else "all_reduce(gX|gU|loss) fp64 dense",
+                        exchange="none" if world == 1 else f"all_reduce(gX|gU|loss) fp64 dense, backend {a.backend}",
                         loss=loss_gpu),
             roofline=roofline,
         )

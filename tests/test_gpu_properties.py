@@ -1,0 +1,145 @@
+"""Size-independent properties of the fused energy kernel on MI355X (run with -m gpu):
+invariance to element order and to global node renumbering, NON-invariance to the local node
+order of an element (the reference's J^-1 . D_N convention), finite-difference
+gradient check, additivity over tile ranges at full size, and the unstructured 'cfg5-like'
+4M-element mesh (random diagonals, random element permutation + node renumbering) against the
+plain-C oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _energy(coords, conn, geom, bc, edges, u_free=None, seed=0, tile_elems=0):
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                 neumann_edges=edges).to(d)
+    if u_free is not None:
+        with torch.no_grad():
+            m.u_free.copy_(u_free.to(d))
+    lf = EnergyLoss2D(device=d, dtype=F64, tile_elems=tile_elems)
+    loss = lf(m)
+    loss.backward()
+    return m, loss.item()
+
+
+def _full(m, which):
+    """Scatter a free-row gradient back to full node numbering (zeros on fixed rows)."""
+    g = torch.zeros(m.Nnodes, 2, dtype=F64)
+    if which == "x":
+        g[m.free_mask.cpu()] = m.node_coords_free.grad.cpu()
+    else:
+        g[m.u_free_mask.cpu()] = m.u_free.grad.cpu()
+    return g.numpy()
+
+
+def test_invariance_to_element_order_and_node_renumbering():
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(61, 37, jitter=0.25, seed=7, dtype=F64)
+    rng = np.random.default_rng(0)
+    m0, l0 = _energy(coords, conn, geom, bc, edges)
+    u_full = torch.zeros(coords.shape[0], 2, dtype=F64)
+    u_full[~bc] = m0.u_free.detach().cpu()
+    # (1) permute the elements
+    perm = torch.from_numpy(rng.permutation(conn.shape[0]))
+    m1, l1 = _energy(coords, conn[perm], geom, bc, edges, u_free=u_full[~bc])
+    assert abs(l1 - l0) <= 1e-12 * abs(l0)
+    assert np.abs(_full(m1, "x") - _full(m0, "x")).max() <= 1e-10 * np.abs(_full(m0, "x")).max()
+    # (2) renumber the nodes globally (connectivity, masks, edges, coords and u follow)
+    new_of_old = torch.from_numpy(rng.permutation(coords.shape[0]))
+    old_of_new = torch.argsort(new_of_old)
+    e2 = new_of_old[edges]
+    e2 = torch.sort(e2, dim=1).values                      # edges stay index-sorted (mesh.py:130,255) ...
+    # ... but sorting swaps the (i, j) roles of an edge, and the reference's raw-Legendre xi (F3) is
+    # not symmetric in i<->j: only compare when the traction work is symmetric -> drop the edges here
+    none = torch.zeros((0, 2), dtype=torch.long)
+    m0b, l0b = _energy(coords, conn, geom, bc, none, u_free=u_full[~bc])
+    m2, l2 = _energy(coords[old_of_new], new_of_old[conn], geom[old_of_new], bc[old_of_new], none,
+                     u_free=u_full[old_of_new][~bc[old_of_new]])
+    assert abs(l2 - l0b) <= 1e-12 * abs(l0b)
+    gx0, gx2 = _full(m0b, "x"), _full(m2, "x")
+    assert np.abs(gx2[new_of_old.numpy()] - gx0).max() <= 1e-10 * np.abs(gx0).max()
+    gu0, gu2 = _full(m0b, "u"), _full(m2, "u")
+    assert np.abs(gu2[new_of_old.numpy()] - gu0).max() <= 1e-10 * np.abs(gu0).max()
+    # (3) the local node order of an element is NOT a symmetry of the reference energy (F4)
+    flipped = conn.clone()
+    flipped[::2] = flipped[::2][:, [1, 2, 0]]              # cyclic shift keeps det > 0
+    m3, l3 = _energy(coords, flipped, geom, bc, none, u_free=u_full[~bc])
+    assert abs(l3 - l0b) > 1e-6 * abs(l0b)
+
+
+def test_finite_difference_gradients():
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(13, 9, jitter=0.2, seed=2, dtype=F64)
+    m, l0 = _energy(coords, conn, geom, bc, edges)
+    with torch.no_grad():
+        m.u_free.mul_(1e3)                                   # make strain energy and traction work comparable
+    m.zero_grad()
+    lf = EnergyLoss2D(device=torch.device("cuda:0"), dtype=F64)
+    lf(m).backward()
+    rng = np.random.default_rng(1)
+    for p, h in ((m.u_free, 1e-9), (m.node_coords_free, 1e-7)):
+        g = p.grad.clone()
+        for _ in range(6):
+            i, j = int(rng.integers(p.shape[0])), int(rng.integers(2))
+            with torch.no_grad():
+                p[i, j] += h
+                lp = lf(m).item()
+                p[i, j] -= 2 * h
+                lm = lf(m).item()
+                p[i, j] += h
+            fd = (lp - lm) / (2 * h)
+            assert abs(fd - g[i, j].item()) <= 1e-5 * max(abs(g[i, j].item()), g.abs().max().item() * 1e-3)
+
+
+def test_cfg5_like_unstructured_4m_elements_vs_oracle():
+    """BASELINE config 5 shape: 2001x1001 nodes -> 4,000,000 TRI3, jitter 0.3, random diagonals, random
+    element permutation + global node renumbering (worst-case locality); C-ABI called directly."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.plan import TilePlan
+    from oracle import closed_form as CF
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random",
+                                                            permute=True, dtype=F64)
+    X = coords.numpy()
+    U = 1e-5 * np.random.default_rng(3).standard_normal(X.shape)
+    mat, W, Tc = CF.plane_stress(), 0.25, np.array([2e5, 0.0, 0.0, 0.0])
+    e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn.numpy(), mat, W)
+    e_ref -= CF.edge2_energy(X, U, edges.numpy(), Tconst=Tc, gX=gX_ref, gU=gU_ref)
+    plan = TilePlan(conn, X.shape[0], coords_hint=X, edges=edges, device=d)
+    assert plan.stats["max_tile_nodes"] <= 1024
+    L = _lib.lib()
+    dv = lambda a: (C.c_double * len(a))(*a)
+    Xd, Ud = torch.from_numpy(X).to(d), torch.from_numpy(U).to(d)
+    s = _lib.stream_ptr(d)
+    loss = torch.full((), 3.0, dtype=F64, device=d)
+    gX, gU = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+    _lib.check(L.hfem_tri3_energy_plan(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv([0.0] * 6),
+                                       None, dv(Tc), 0, -1, loss.data_ptr(), gX.data_ptr(), gU.data_ptr(), 0, s))
+    assert abs(loss.item() - e_ref) <= 1e-12 * abs(e_ref)
+    assert (gX.cpu().numpy() - gX_ref).__abs__().max() <= 1e-10 * np.abs(gX_ref).max()
+    assert (gU.cpu().numpy() - gU_ref).__abs__().max() <= 1e-10 * np.abs(gU_ref).max()
+    # additivity over 8 tile ranges (the 8-GPU element sharding), rows written exactly once overall
+    acc = 0.0
+    cover = torch.zeros(X.shape[0], dtype=torch.int32, device=d)
+    for r in range(8):
+        lo, hi = plan.shard_range(r, 8)
+        l = torch.zeros((), dtype=F64, device=d)
+        gx, gu = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W,
+                                           dv([0.0] * 6), None, dv(Tc), lo, hi, l.data_ptr(), gx.data_ptr(),
+                                           gu.data_ptr(), 0, s))
+        acc += l.item()
+        cover += (~torch.isnan(gx[:, 0])).int()
+    assert abs(acc - e_ref) <= 1e-12 * abs(e_ref)
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+    plan.close()

@@ -181,6 +181,27 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
+    # ---- N > 1 only, reported beside the headline: owner-sharded exchange (scalar loss all-reduce only;
+    #      each rank keeps the complete gradient rows of its own nodes -- what a node-sharded optimiser needs)
+    alt = None
+    if world > 1:
+        def step_owner():
+            sh.evaluate_local()
+            sh.exchange_loss_only()
+        for _ in range(a.warmup):
+            step_owner()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_owner()
+        sync_all()
+        el2 = time.perf_counter() - t0
+        t = torch.tensor([el2], dtype=f64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = t.item()
+        alt = dict(mode="owner-sharded: all_reduce(loss) only, gradient rows stay with their owner rank",
+                   value=ne / (el2 / a.steps), ms_per_step=el2 / a.steps * 1e3)
+
     # ---- roofline leg: the dominant kernel alone, K back-to-back launches, HIP events on its stream
     L = _lib.lib()
     dv = lambda v: (C.c_double * len(v))(*v)
@@ -281,6 +302,8 @@ def main():
                         loss=loss_gpu),
             roofline=roofline,
         )
+        if alt is not None:
+            out["config"]["alt_exchange"] = alt
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -110,8 +110,19 @@ class EnergyLoss2D:
         t_edge = t_force(xq_flat) if t_force is not None else self.uniform_edge_force(xq_flat)
         return torch.sum((u_edge * t_edge).sum(dim=1) * (wq_flat * ds))
 
+    def _quad4(self, model, b_force, t_force):
+        """QUAD4 extension: 2x2 Gauss (gauss_order is a triangle-rule setting and does not apply), zero
+        body force, constant traction; planless fused kernels on the assembled arrays."""
+        if b_force is not None or t_force is not None:
+            raise NotImplementedError("QUAD4 extension: body force / custom traction are not built")
+        _, Tconst = self._traction(model, None)
+        edges = model._edges32 if model.N_edges else None
+        return ops.Quad4EnergyFn.apply(model.coords, model.u_full, model._conn32, edges, self._mat, Tconst)
+
     def __call__(self, model, b_force=None, t_force=None) -> torch.Tensor:
         """Total potential = domain - edge (loss.py:113-116), one fused launch."""
+        if getattr(model, "nodes_per_element", 3) == 4:
+            return self._quad4(model, b_force, t_force)
         if model.neumann_edges is None or model.N_edges == 0:
             return self._fused(model, b_force, None, [0.0] * 4, HFEM_FLAG_NO_EDGES)
         if t_force is not None and model.node_coords_free.requires_grad and self._edge_nodes_free(model):

@@ -139,6 +139,35 @@ def structured_tri_mesh(
     )
 
 
+def structured_quad_mesh(nx: int, ny: int, length: float = 2.0, height: float = 1.0, jitter: float = 0.0,
+                         seed: int = 0, boundaries: Optional[Dict[str, int]] = None,
+                         dtype: torch.dtype = torch.float32):
+    """``nx x ny`` nodes -> ``(nx-1)(ny-1)`` QUAD4 cells, local nodes CCW ``(a, b, c, d)`` with
+    ``a=(i,j) b=(i+1,j) c=(i+1,j+1) d=(i,j+1)`` (node id ``i*ny + j``).  Same 6-tuple as the
+    triangular generators, with ``connectivity [Ne,4]``.  QUAD4 is this build's extension element
+    (the reference has none)."""
+    rng = np.random.default_rng(seed)
+    boundaries = dict(_DEFAULT_BOUNDARIES if boundaries is None else boundaries)
+    xs, ys = np.linspace(0.0, length, nx), np.linspace(0.0, height, ny)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    pts0 = np.stack([X.ravel(), Y.ravel()], axis=1)
+    idx = np.arange(nx * ny, dtype=np.int64).reshape(nx, ny)
+    geom = np.zeros((nx, ny), dtype=bool)
+    geom[0, :] = geom[-1, :] = geom[:, 0] = geom[:, -1] = True
+    geom = geom.ravel()
+    pts = pts0.copy()
+    if jitter > 0.0:
+        h = np.array([length / (nx - 1), height / (ny - 1)])
+        pts = pts + rng.uniform(-jitter, jitter, size=pts.shape) * h * (~geom)[:, None]
+    cells = np.stack([idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()], axis=1)
+    bc, mn = _face_masks(pts0, length, height, boundaries)
+    e = np.vstack([cells[:, [0, 1]], cells[:, [1, 2]], cells[:, [2, 3]], cells[:, [3, 0]]])
+    e = e[mn[e].all(axis=1)]
+    edges = np.unique(np.sort(e, axis=1), axis=0).astype(np.int64) if len(e) else np.zeros((0, 2), dtype=np.int64)
+    return (torch.tensor(pts, dtype=dtype), torch.tensor(cells, dtype=torch.long), torch.tensor(geom),
+            torch.tensor(bc), torch.tensor(mn), torch.tensor(edges, dtype=torch.long))
+
+
 def generate_mesh(
     length: float = 2.0,
     height: float = 1.0,

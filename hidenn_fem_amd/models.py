@@ -289,6 +289,24 @@ class TriangularShapeNN2D(nn.Module):
         return ops.Edge2EvalFn.apply(self.coords, self.u_full, self._edges32, x_eval[:, 0], elem_id)
 
 
+class QuadShapeNN2D(TriangularShapeNN2D):
+    """QUAD4-iso extension element: same construction API, parameters, buffers and
+    attribute surface as the triangular model, ``connectivity [Ne,4]`` (local nodes CCW), reference
+    square ``[-1,1]^2``.  ``forward(x_eval, elem_id)`` keeps the ``(x_ref, element_id)`` contract.  The
+    fused energy is planless this round (fp64 global atomics); there is no reference counterpart."""
+
+    nodes_per_element = 4
+
+    def tile_plan(self, tile_elems: int = 0):
+        raise NotImplementedError("the owner-computes tile plan is TRI3-only in this round; QUAD4 uses the planless "
+                                  "fused kernel (hfem_quad4_energy_atomic)")
+
+    def forward(self, x_eval, elem_id, edge=False):
+        if not edge:
+            return ops.Quad4EvalFn.apply(self.coords, self.u_full, self._conn32, x_eval, elem_id)
+        return super().forward(x_eval, elem_id, edge=True)
+
+
 def PiecewiseLinearShapeNN2D(*args, **kwargs):
     """One name, two element families, like the reference module.
 
@@ -299,8 +317,11 @@ def PiecewiseLinearShapeNN2D(*args, **kwargs):
     tri_kw = {"node_coords", "connectivity", "boundary_mask", "dirichlet_mask", "neumann_edges"}
     if structured_kw & kwargs.keys():
         return StructuredShapeNN2D(*args, **kwargs)
-    if tri_kw & kwargs.keys():
+    conn = kwargs.get("connectivity", args[1] if len(args) >= 2 else None)
+    unstructured = bool(tri_kw & kwargs.keys()) or (
+        len(args) >= 2 and args[1].dim() == 2 and not torch.is_floating_point(args[1]))
+    if unstructured:                                         # (node_coords [N,2], connectivity [Ne,3|4] int)
+        if conn is not None and conn.dim() == 2 and conn.shape[1] == 4:
+            return QuadShapeNN2D(*args, **kwargs)            # extension element
         return TriangularShapeNN2D(*args, **kwargs)
-    if len(args) >= 2 and args[1].dim() == 2 and not torch.is_floating_point(args[1]):
-        return TriangularShapeNN2D(*args, **kwargs)          # (node_coords [N,2], connectivity [Ne,3] int)
     return StructuredShapeNN2D(*args, **kwargs)              # (grid_x [Nx], grid_y [Ny])

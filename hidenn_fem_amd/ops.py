@@ -348,3 +348,65 @@ class RectQ4MseFn(torch.autograd.Function):
     def backward(ctx, g):
         g64 = g.to(F64)
         return tuple((t * g64).to(dt) for t, dt in zip(ctx.unit, ctx.dts)) + (None, None)
+
+
+# ---------------------------------------------------------------- QUAD4-iso extension (planless)
+class Quad4EnergyFn(torch.autograd.Function):
+    """Fused QUAD4 domain energy (2x2 Gauss) + Neumann edge work, fwd + bwd, on assembled X, U.
+    Extension element: no reference counterpart; oracle = oracle/quad4.py."""
+
+    @staticmethod
+    def forward(ctx, X, U, conn32, edges32, mat, Tconst):
+        dev = X.device
+        Xd, Ud = _f64(X, "coords"), _f64(U, "u_full")
+        loss = torch.zeros((), dtype=F64, device=dev)
+        gX, gU = torch.zeros_like(Xd), torch.zeros_like(Ud)
+        L = _lib.lib()
+        check(L.hfem_quad4_energy_atomic(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), 0, conn32.shape[0], Xd.shape[0],
+                                         _dvec(mat), ptr(loss), ptr(gX), ptr(gU), stream_ptr(dev)),
+              "hfem_quad4_energy_atomic")
+        if edges32 is not None and edges32.shape[0] > 0:
+            check(L.hfem_edge2_energy_atomic(dev_index(dev), ptr(Xd), ptr(Ud), ptr(edges32), edges32.shape[0], None,
+                                             _dvec(Tconst), ptr(loss), ptr(gX), ptr(gU), stream_ptr(dev)),
+                  "hfem_edge2_energy_atomic")
+        ctx.unit, ctx.dt = (gX, gU), X.dtype
+        return loss.to(X.dtype) if X.dtype != F64 else loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gX, gU = ctx.unit
+        g64 = g.to(F64)
+        return (gX * g64).to(ctx.dt), (gU * g64).to(ctx.dt), None, None, None, None
+
+
+class Quad4EvalFn(torch.autograd.Function):
+    """(u_h, detJ, grad_u) at reference points (xi, eta) in [-1,1]^2 of given QUAD4 elements."""
+
+    @staticmethod
+    def forward(ctx, X, U, conn32, x_eval, elem_id):
+        dev = X.device
+        Xd, Ud, xe = _f64(X, "coords"), _f64(U, "u_full"), _f64(x_eval, "x_eval")
+        eid = require_gpu_tensor(elem_id.contiguous(), "elem_id", torch.int64)
+        m = eid.shape[0]
+        u_h = torch.empty((m, 2), dtype=F64, device=dev)
+        detJ = torch.empty((m,), dtype=F64, device=dev)
+        grad_u = torch.empty((m, 2, 2), dtype=F64, device=dev)
+        check(_lib.lib().hfem_quad4_eval_fwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid), m,
+                                             ptr(u_h), ptr(detJ), ptr(grad_u), stream_ptr(dev)), "hfem_quad4_eval_fwd")
+        ctx.save_for_backward(Xd, Ud, conn32, xe, eid)
+        ctx.dt = X.dtype
+        if X.dtype != F64:
+            return u_h.to(X.dtype), detJ.to(X.dtype), grad_u.to(X.dtype)
+        return u_h, detJ, grad_u
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, cu, cd, cg):
+        Xd, Ud, conn32, xe, eid = ctx.saved_tensors
+        dev = Xd.device
+        gX, gU = torch.zeros_like(Xd), torch.zeros_like(Ud)
+        check(_lib.lib().hfem_quad4_eval_bwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid),
+                                             eid.shape[0], ptr(_f64(cu, "cu")), ptr(_f64(cd, "cd")), ptr(_f64(cg, "cg")),
+                                             ptr(gX), ptr(gU), stream_ptr(dev)), "hfem_quad4_eval_bwd")
+        return gX.to(ctx.dt), gU.to(ctx.dt), None, None, None

@@ -82,6 +82,21 @@ class ShardedTri3Energy:
             dist.all_reduce(self.recv, op=dist.ReduceOp.SUM, group=self.group)
         return self._views(self.recv)
 
+    def exchange_loss_only(self):
+        """Owner-sharded mode: every rank keeps only the gradient rows its own tiles produced (they are
+        complete -- owner-computes with halo recompute -- so no other rank contributes to them) and the
+        ranks exchange just the scalar energy (8 bytes).  This is what a node-sharded optimiser needs;
+        the parameters' interface rows are then exchanged after the optimiser step.
+        Returns (global loss 0-d view, local gx view, local gu view) on the SEND buffer."""
+        loss_v, gx_v, gu_v = self._views(self.send)
+        self._loss_red = getattr(self, "_loss_red", None)
+        if self._loss_red is None:
+            self._loss_red = torch.empty(1, dtype=F64, device=self.send.device)
+        self._loss_red.copy_(loss_v)
+        if self.world > 1:
+            dist.all_reduce(self._loss_red, op=dist.ReduceOp.SUM, group=self.group)
+        return self._loss_red[0], gx_v, gu_v
+
     def value_and_grad(self):
         """One sharded fwd+bwd pass -> (loss, d/d node_coords_free, d/d u_free), identical on all ranks."""
         self.evaluate_local()

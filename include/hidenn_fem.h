@@ -149,6 +149,25 @@ int hfem_edge2_eval_bwd(int device, const double *X, const double *U, const int3
                         const double *cu, const double *cds, double *gX, double *gU,
                         void *stream);
 
+/* ------------------------------------------------------------------ QUAD4-iso (extension)
+ * The reference has no isoparametric quadrilateral; these follow the SURVEY section 8a
+ * spec with the reference's conventions (J[i][j] = d x_i/d xi_j, dN_dx = Jinv*D_N as
+ * src/models.py:339-351, abs(detJ) as src/loss.py:84): reference square [-1,1]^2, local nodes CCW from
+ * (-1,-1), 2x2 Gauss (+-1/sqrt(3), weights 1), zero body force.  conn4 [Ne][4] int32.
+ * Planless (fp64 global atomics): ACCUMULATES loss_acc[0], gX, gU (caller zeroes); gX/gU may be NULL. */
+int hfem_quad4_energy_atomic(int device, const double *X, const double *U, const int32_t *conn4,
+                             int64_t e_begin, int64_t e_end, int64_t nn, const double mat[4],
+                             double *loss_acc, double *gX, double *gU, void *stream);
+/* Per-point forward/backward with the (x_ref, element_id) contract of src/models.py:316:
+ * x_eval [M][2] in [-1,1]^2 -> u_h [M][2], detJ [M], grad_u [M][2][2]; backward ACCUMULATES gX,gU. */
+int hfem_quad4_eval_fwd(int device, const double *X, const double *U, const int32_t *conn4,
+                        const double *x_eval, const int64_t *elem_id, int64_t m,
+                        double *u_h, double *detJ, double *grad_u, void *stream);
+int hfem_quad4_eval_bwd(int device, const double *X, const double *U, const int32_t *conn4,
+                        const double *x_eval, const int64_t *elem_id, int64_t m,
+                        const double *cu, const double *cd, const double *cg,
+                        double *gX, double *gU, void *stream);
+
 /* ------------------------------------------------------------------ row gather/scatter
  * src/models.py:292-305 as index lists instead of bool-mask index_put (which
  * runs aten::nonzero on every call): dst[idx[r]][0..w) = src[r][0..w).         */

@@ -1,0 +1,108 @@
+"""QUAD4-iso EXTENSION (no reference counterpart, SURVEY F11: "parity unpinned by reference").
+CPU: sanity of the test-side oracle (oracle/quad4.py).  GPU (-m gpu): kernels vs that oracle."""
+import numpy as np
+import pytest
+import torch
+
+F64 = torch.float64
+
+
+def test_quad4_oracle_sanity_on_rectilinear_cells():
+    """For axis-aligned rectangles J is diagonal, so the reference convention (Jinv * D_N) and the textbook
+    one coincide: a linear field must give its exact gradient, and detJ = cell area / 4."""
+    from oracle import quad4 as Q
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    coords, conn, *_ = structured_quad_mesh(5, 4, length=2.0, height=1.5, dtype=F64)
+    A = torch.tensor([[2.0, 3.0], [-1.0, 5.0]], dtype=F64)
+    U = coords @ A.T
+    g = torch.Generator().manual_seed(0)
+    x_eval = torch.rand(conn.shape[0], 2, generator=g, dtype=F64) * 2 - 1
+    elem_id = torch.arange(conn.shape[0])
+    u_h, detJ, grad_u = Q.quad4_forward(coords, U, conn, x_eval, elem_id)
+    assert torch.allclose(grad_u, A.expand_as(grad_u), atol=1e-12)
+    assert torch.allclose(detJ, torch.full_like(detJ, (2.0 / 4) * (1.5 / 3) / 4), atol=1e-14)
+    # interpolation reproduces the linear field at the mapped physical point
+    xk, ek = Q.XI.to(F64)[None, :], Q.ETA.to(F64)[None, :]
+    N = 0.25 * (1 + xk * x_eval[:, 0:1]) * (1 + ek * x_eval[:, 1:2])
+    xp = torch.sum(N.unsqueeze(2) * coords[conn], dim=1)
+    assert torch.allclose(u_h, xp @ A.T, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_quad4_kernels_match_the_autograd_oracle():
+    from oracle import quad4 as Q, ref_chain as R
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D, QuadShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_quad_mesh(23, 17, jitter=0.25, seed=4, dtype=F64)
+    torch.manual_seed(1)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                 neumann_edges=edges).to(d)
+    assert isinstance(m, QuadShapeNN2D)
+    with torch.no_grad():
+        m.u_free.mul_(50.0)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    loss = lf(m)
+    loss.backward()
+    # oracle: same assembly, autograd through the op chain (domain) + reference edge work
+    xf = m.node_coords_free.detach().cpu().clone().requires_grad_(True)
+    uf = m.u_free.detach().cpu().clone().requires_grad_(True)
+    X = R.assemble_coords(coords.shape[0], ~geom, xf, geom, coords[geom])
+    U = R.assemble_u(coords.shape[0], ~bc, uf, bc, torch.tensor(0.0, dtype=F64))
+    ref = Q.quad4_domain_energy(X, U, conn, R.plane_stress_C()) - R.edge_energy(X, U, edges, *R.interval_gauss(2))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-12 * abs(ref.item())
+    gx, gu = m.node_coords_free.grad.cpu().numpy(), m.u_free.grad.cpu().numpy()
+    assert np.abs(gx - xf.grad.numpy()).max() <= 1e-10 * np.abs(xf.grad.numpy()).max()
+    assert np.abs(gu - uf.grad.numpy()).max() <= 1e-10 * np.abs(uf.grad.numpy()).max()
+    # per-point forward / backward with the (x_ref, element_id) contract
+    g = torch.Generator().manual_seed(5)
+    M = 700
+    x_eval = torch.rand(M, 2, generator=g, dtype=F64) * 2 - 1
+    elem_id = torch.randint(0, conn.shape[0], (M,), generator=g)
+    cu, cd, cg = (torch.randn(s, generator=g, dtype=F64) for s in ((M, 2), (M,), (M, 2, 2)))
+    m.zero_grad()
+    u_h, detJ, grad_u = m(x_eval.to(d), elem_id.to(d))
+    ((u_h * cu.to(d)).sum() + (detJ * cd.to(d)).sum() + (grad_u * cg.to(d)).sum()).backward()
+    xf.grad = None
+    uf.grad = None
+    X = R.assemble_coords(coords.shape[0], ~geom, xf, geom, coords[geom])
+    U = R.assemble_u(coords.shape[0], ~bc, uf, bc, torch.tensor(0.0, dtype=F64))
+    ru, rd, rg = Q.quad4_forward(X, U, conn, x_eval, elem_id)
+    ((ru * cu).sum() + (rd * cd).sum() + (rg * cg).sum()).backward()
+    np.testing.assert_allclose(u_h.detach().cpu().numpy(), ru.detach().numpy(), rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(detJ.detach().cpu().numpy(), rd.detach().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(grad_u.detach().cpu().numpy(), rg.detach().numpy(), rtol=1e-10, atol=1e-14)
+    gx, gu = m.node_coords_free.grad.cpu().numpy(), m.u_free.grad.cpu().numpy()
+    assert np.abs(gx - xf.grad.numpy()).max() <= 1e-10 * np.abs(xf.grad.numpy()).max()
+    assert np.abs(gu - uf.grad.numpy()).max() <= 1e-10 * np.abs(uf.grad.numpy()).max()
+
+
+@pytest.mark.gpu
+def test_quad4_one_million_elements_runs_and_matches_sampled_oracle():
+    """cfg4-Q shape (1001x1001 nodes -> 10^6 QUAD4): full-size run; oracle on a 60k-element sub-mesh."""
+    from oracle import quad4 as Q, ref_chain as R
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_quad_mesh(1001, 1001, length=2.0, height=2.0, jitter=0.2, seed=0, dtype=F64)
+    torch.manual_seed(0)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    loss = lf(m)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(m.u_free.grad).all() and torch.isfinite(m.node_coords_free.grad).all()
+    # domain energy of the first 60 columns of cells == oracle on that sub-mesh (energy is additive over elements)
+    sub = conn[: 60 * 1000]
+    X, U = m.coords.detach().cpu(), m.u_full.detach().cpu()
+    e_sub = Q.quad4_domain_energy(X, U, sub, R.plane_stress_C()).item()
+    from hidenn_fem_amd import _lib
+    import ctypes as C
+    acc = torch.zeros((), dtype=F64, device=d)
+    Xd, Ud = m.coords.detach(), m.u_full.detach()
+    _lib.check(_lib.lib().hfem_quad4_energy_atomic(0, Xd.data_ptr(), Ud.data_ptr(), m._conn32.data_ptr(), 0, sub.shape[0],
+                                                   Xd.shape[0], (C.c_double * 4)(*lf._mat), acc.data_ptr(), None, None,
+                                                   _lib.stream_ptr(d)))
+    assert abs(acc.item() - e_sub) <= 1e-12 * abs(e_sub)

@@ -92,6 +92,12 @@ def _worker(rank, world, port, q):
               and np.abs(model.node_coords_free.grad.numpy() - gx_ref).max() <= 1e-11 * np.abs(gx_ref).max()
               and np.abs(model.u_free.grad.numpy() - gu_ref).max() <= 1e-11 * np.abs(gu_ref).max())
         # every rank must hold bit-identical reduced results (identical optimiser steps follow)
+        # owner-sharded mode: 8-byte exchange, local rows complete for the nodes this rank's tiles own
+        sh.evaluate_local()
+        loss_o, gx_o, gu_o = sh.exchange_loss_only()
+        rows = (gx_o != 0).any(dim=1).numpy()
+        ok = ok and abs(loss_o.item() - e_ref) <= 1e-12 * abs(e_ref) \
+            and np.abs(gx_o.numpy()[rows] - gx_ref[rows]).max() <= 1e-11 * np.abs(gx_ref).max()
         mine = torch.cat([model.node_coords_free.grad.reshape(-1), model.u_free.grad.reshape(-1), loss.detach().reshape(1)])
         other = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(other, mine)

@@ -402,3 +402,58 @@ def test_examples_run_against_the_drop_in_api(g_lbfgs):
     # later ones agree to line-search accuracy
     np.testing.assert_allclose(trace[:3], want[:3], rtol=1e-10)
     np.testing.assert_allclose(trace[:n], want[:n], rtol=1e-5)
+
+
+def test_kernel_variants_agree(g_tri):
+    """Every launch variant of the tiled energy (register-prefetched 'fast' kernel with sc1 or plain stores,
+    generic loop kernel at 256/512/1024 threads, experimental persistent pipelined kernel) gives the same
+    numbers on a mid-size mesh with free boundary nodes, a body force and Neumann edges."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from conftest import b_force_fn
+    d = dev()
+    L = _lib.lib()
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(181, 95, jitter=0.25, seed=9, dtype=F64)
+    results = {}
+    settings = {
+        "fast_sc1": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0),
+        "fast_plain": dict(tiled_fast=1, store_policy=0, tiled_block=512, tiled_pipe=0),
+        "loop_256": dict(tiled_fast=0, store_policy=16, tiled_block=256, tiled_pipe=0),
+        "loop_1024": dict(tiled_fast=0, store_policy=16, tiled_block=1024, tiled_pipe=0),
+        "pipe_512x2": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=2),
+    }
+    try:
+        for body in (None, b_force_fn):
+            for name, opts in settings.items():
+                for k, v in opts.items():
+                    _lib.check(L.hfem_set_option(k.encode(), v))
+                torch.manual_seed(4)
+                m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=None, dirichlet_mask=bc, u_fixed=0.0,
+                                             neumann_edges=edges).to(d)
+                with torch.no_grad():
+                    m.u_free.mul_(30.0)
+                lf = EnergyLoss2D(device=d, dtype=F64)
+                loss = lf(m, b_force=body)
+                loss.backward()
+                results[(body is None, name)] = (loss.item(), m.node_coords_free.grad.cpu().numpy(),
+                                                 m.u_free.grad.cpu().numpy())
+            ref = results[(body is None, "loop_256")]
+            for name in settings:
+                got = results[(body is None, name)]
+                assert abs(got[0] - ref[0]) <= 1e-13 * abs(ref[0]), name
+                assert np.abs(got[1] - ref[1]).max() <= 1e-12 * np.abs(ref[1]).max(), name
+                assert np.abs(got[2] - ref[2]).max() <= 1e-12 * np.abs(ref[2]).max(), name
+    finally:
+        for k, v in dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0).items():
+            L.hfem_set_option(k.encode(), v)
+
+
+def test_example3_converges_to_the_analytic_bar_solution():
+    """Acceptance: examples/example3.py at full length (4000 Adam epochs, fp32 model as the reference runs it):
+    the reference reaches loss -0.03138 and max |u_h - u_exact| = 1.9e-4."""
+    import examples.example3 as e3
+    _, loss, err = e3.run(epochs=4000, log_every=100000)
+    assert abs(loss - (-0.03138)) < 2e-4
+    assert err < 4e-4

@@ -38,12 +38,16 @@ def energy_reference_form(model, xi, wi):
     return torch.sum(wq * (0.5 * E_MOD * du ** 2 - body_force(xq) * u))
 
 
-def run(epochs=4000, nodes=89, reference_form=False, log_every=500):
+def run(epochs=4000, nodes=89, reference_form=False, log_every=500, fused_adam=False):
     dev = torch.device("cuda")
     grid = torch.linspace(0, LENGTH, nodes, device=dev)
     xi, wi = gauss_legendre_points_weights(2, device=dev)
     model = PiecewiseLinearShapeNN(grid, r_adapt=True, u0=0.0, uN=0.0).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    if fused_adam:                      # one HIP launch per parameter tensor
+        from hidenn_fem_amd.optim import FusedAdam
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     for epoch in range(epochs):
         opt.zero_grad()
         loss = energy_reference_form(model, xi, wi) if reference_form else \
@@ -63,5 +67,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=4000)
     ap.add_argument("--reference-form", action="store_true")
+    ap.add_argument("--fused-adam", action="store_true")
     a = ap.parse_args()
-    run(a.epochs, reference_form=a.reference_form)
+    run(a.epochs, reference_form=a.reference_form, fused_adam=a.fused_adam)

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "hfem_quad4_energy_atomic": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hfem_quad4_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hfem_quad4_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hfem_adam_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _i64, _vp]),
     "hfem_scatter_rows": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hfem_gather_rows": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hfem_grid_param_fwd": (C.c_int, [C.c_int, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp]),

@@ -168,6 +168,14 @@ int hfem_quad4_eval_bwd(int device, const double *X, const double *U, const int3
                         const double *cu, const double *cd, const double *cg,
                         double *gX, double *gU, void *stream);
 
+/* ------------------------------------------------------------------ fused optimiser step
+ * One launch of torch.optim.Adam's update (examples/example1.py:31, example2.py:37, example3.py:89;
+ * default betas/eps, no weight decay, no amsgrad) on a flat tensor of n parameters:
+ * m += (g-m)(1-b1); v = v b2 + (1-b2) g g; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).
+ * dtype: 0 = fp64, 1 = fp32 (p, g, m, v all of that type).  step counts from 1.            */
+int hfem_adam_step(int device, void *p, const void *g, void *m, void *v, int64_t n, int32_t dtype,
+                   double lr, double beta1, double beta2, double eps, int64_t step, void *stream);
+
 /* ------------------------------------------------------------------ row gather/scatter
  * src/models.py:292-305 as index lists instead of bool-mask index_put (which
  * runs aten::nonzero on every call): dst[idx[r]][0..w) = src[r][0..w).         */

@@ -457,3 +457,25 @@ def test_example3_converges_to_the_analytic_bar_solution():
     _, loss, err = e3.run(epochs=4000, log_every=100000)
     assert abs(loss - (-0.03138)) < 2e-4
     assert err < 4e-4
+    _, loss_f, err_f = e3.run(epochs=4000, log_every=100000, fused_adam=True)     # fused Adam: same trajectory
+    assert abs(loss_f - loss) < 2e-5 and err_f < 4e-4
+
+
+def test_fused_adam_matches_torch_adam():
+    from hidenn_fem_amd.optim import FusedAdam
+    d = dev()
+    for dt, tol in ((F64, 1e-14), (torch.float32, 2e-6)):
+        g = torch.Generator().manual_seed(2)
+        p0 = [torch.randn(1000, 2, generator=g, dtype=dt), torch.randn(333, generator=g, dtype=dt)]
+        grads = [[torch.randn(t.shape, generator=g, dtype=dt) * 10 ** float(k % 5 - 2) for t in p0] for k in range(25)]
+        pa = [t.clone().to(d).requires_grad_(True) for t in p0]
+        pb = [t.clone().to(d).requires_grad_(True) for t in p0]
+        oa, ob = torch.optim.Adam(pa, lr=3e-3), FusedAdam(pb, lr=3e-3)
+        for gs in grads:
+            for a, b, gi in zip(pa, pb, gs):
+                a.grad, b.grad = gi.to(d).clone(), gi.to(d).clone()
+            oa.step()
+            ob.step()
+        for a, b in zip(pa, pb):
+            err = (a - b).abs().max().item() / a.abs().max().item()
+            assert err <= tol, (dt, err)

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "hfem_tri3_energy_atomic": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _f64, _vp, _vp, _vp, _vp, _vp]),
     "hfem_edge2_energy_atomic": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hfem_plan_create": (C.c_int, [C.c_int, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(_vp)]),
+    "hfem_plan_create_ex": (C.c_int, [C.c_int, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(_vp)]),
     "hfem_plan_destroy": (C.c_int, [_vp]),
     "hfem_plan_get_stats": (C.c_int, [_vp, C.POINTER(PlanStats)]),
     "hfem_plan_export": (_i64, [_vp, C.c_int, _vp, _i64]),
@@ -50,6 +51,7 @@ PROTOTYPES = {
     "hfem_edge2_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "hfem_edge2_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hfem_quad4_energy_atomic": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "hfem_quad4_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hfem_quad4_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hfem_adam_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _i64, _vp]),

@@ -28,6 +28,7 @@ constexpr int kMaxLocal = 1 << kLocalBits;
 constexpr uint32_t kLocalMask = kMaxLocal - 1;
 constexpr uint32_t kHomeBit = 1u << 30;   // element/edge energy is counted by this tile
 constexpr uint32_t kSkipBit = 1u << 31;   // padding record: the lane has no element
+constexpr int32_t kMaxQuadSlots = 1024;   // element slots per tile the tiled QUAD4 kernel can hold in registers
 
 // tile_desc[t] = 8 x int32
 struct TileDesc {
@@ -42,8 +43,10 @@ static_assert(sizeof(TileDesc) == 32, "TileDesc must be 8 x int32");
 struct HostPlan {
     int64_t ne = 0, nn = 0, ned = 0;
     int32_t tile_elems = 0;
+    int32_t npe = 3;                   // nodes per element: 3 (TRI3) or 4 (QUAD4 extension)
     std::vector<TileDesc> tiles;
-    std::vector<uint32_t> elem_pack;   // l0 | l1<<10 | l2<<20 | home<<30
+    std::vector<uint32_t> elem_pack;   // l0 | l1<<10 | l2<<20 | home<<30 | skip<<31
+    std::vector<uint32_t> elem_pack_hi;  // QUAD4 only: l3 of the same slot
     std::vector<int32_t> elem_gid;     // global element id (tests / debugging)
     std::vector<int32_t> node_src;     // [.][2] = {x_src, u_src} of each local node
     std::vector<uint32_t> edge_pack;   // li | lj<<10 | home<<30
@@ -52,7 +55,7 @@ struct HostPlan {
 };
 
 // Build the owner-computes tiling.  Returns 0 or -1 (message via set_error).
-int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
+int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
                     int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, HostPlan &out);
 

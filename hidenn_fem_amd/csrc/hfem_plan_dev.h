@@ -1,0 +1,61 @@
+// Device-side view of the tile plan + the opaque plan object, shared by the TRI3 and QUAD4 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hfem_device.h"
+
+namespace hfem {
+
+struct PlanDev {
+    const TileDesc *tiles;
+    const uint32_t *elem_pack;
+    const int2 *node_src;
+    const uint32_t *edge_pack;
+    const int32_t *edge_gid;
+    const uint32_t *elem_pack_hi;   // QUAD4 plans only: 4th local node id of every slot
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Map block -> tile so that each XCD walks one contiguous run of the
+// Morton-ordered tiles: neighbouring tiles share halo nodes, which then hit the
+// same L2.  Bijective for any grid size; placement only affects speed.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+}  // namespace hfem
+
+struct hfem_plan {
+    hfem::HostPlan host;
+    int device = -1;
+    // device mirrors
+    hfem::TileDesc *d_tiles = nullptr;
+    uint32_t *d_elem_pack = nullptr;
+    uint32_t *d_elem_pack_hi = nullptr;
+    int2 *d_node_src = nullptr;
+    uint32_t *d_edge_pack = nullptr;
+    int32_t *d_edge_gid = nullptr;
+    double *d_partials = nullptr;
+    unsigned long long *d_stamps = nullptr;   // lab only: [n_tiles][8] s_memrealtime stamps
+    int64_t device_bytes = 0;
+    int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
+    int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
+};
+
+namespace hfem {
+inline PlanDev plan_dev(const hfem_plan *p) {
+    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi};
+}
+inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6]) {
+    Tri3Consts k;
+    k.c11 = mat[0]; k.c12 = mat[1]; k.c22 = mat[2]; k.c33 = mat[3];
+    k.W = W;
+    for (int i = 0; i < 6; ++i) k.Bk[i] = Bk ? Bk[i] : 0.0;
+    return k;
+}
+extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
+extern int g_quad4_ablate;   // quad4.hip (lab option "quad4_ablate")
+
+}  // namespace hfem
+

@@ -61,7 +61,7 @@ inline uint32_t hilbert16(uint32_t x, uint32_t y) {
 static int g_curve = 1;   // 0 Morton, 1 Hilbert
 void set_locality_curve(int c) { g_curve = c; }
 
-void morton_order(const int64_t *conn, int64_t ne, int64_t nn, const double *xy,
+void morton_order(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *xy,
                   std::vector<int32_t> &order) {
     order.resize(ne);
     if (!xy || ne == 0) {
@@ -81,14 +81,14 @@ void morton_order(const int64_t *conn, int64_t ne, int64_t nn, const double *xy,
     std::vector<uint64_t> keys(ne);
     for (int64_t e = 0; e < ne; ++e) {
         double c[2] = {0, 0};
-        for (int k = 0; k < 3; ++k) {
-            const int64_t n = conn[3 * e + k];
+        for (int k = 0; k < npe; ++k) {
+            const int64_t n = conn[npe * e + k];
             c[0] += xy[2 * n];
             c[1] += xy[2 * n + 1];
         }
         uint32_t q[2];
         for (int a = 0; a < 2; ++a) {
-            double v = (c[a] / 3.0 - lo[a]) * scale;
+            double v = (c[a] / npe - lo[a]) * scale;
             if (!(v > 0)) v = 0;
             if (v > 65535.0) v = 65535.0;
             q[a] = (uint32_t)v;
@@ -112,46 +112,47 @@ constexpr int kOrphanTileNodes = 512;
 //           iff, for each of the three corner positions, the owned nodes' local ids are distinct
 //           mod 16.  Elements are packed greedily into such groups, most-constrained first; a group
 //           that cannot be completed is padded with skip records (-1), ~2 % on T1M.
-void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, const std::vector<int32_t> &lid,
-                         int32_t n_owned, int mode) {
+void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, int npe,
+                         const std::vector<int32_t> &lid, int32_t n_owned, int mode) {
     const int n = (int)telems.size();
+    if (npe != 3 && mode != 3) mode = 3;                 // the legacy orders are TRI3-only lab variants
     if (mode == 3) {
         constexpr int G = 16;
-        struct Open { std::vector<int32_t> el; uint16_t used[3]; };
+        struct Open { std::vector<int32_t> el; uint16_t used[4]; };
         // most-constrained first: elements with 3 owned corners, then 2, 1, 0 (stable: curve order kept
         // inside a class).  The flexible ones (halo elements, few owned corners) then fill the holes the
         // constrained ones leave; with no window limit this brings the padding from ~8 % to ~2 %.
-        std::vector<int32_t> byc[4];
+        std::vector<int32_t> byc[5];
         for (int i = 0; i < n; ++i) {
             int owned = 0;
-            for (int k = 0; k < 3; ++k) owned += lid[conn[3 * (int64_t)telems[i] + k]] < n_owned;
-            byc[3 - owned].push_back(telems[i]);
+            for (int k = 0; k < npe; ++k) owned += lid[conn[npe * (int64_t)telems[i] + k]] < n_owned;
+            byc[npe - owned].push_back(telems[i]);
         }
         std::vector<Open> open;
         std::vector<int32_t> out;
         out.reserve(n + n / 8 + G);
         size_t first_open = 0;                                   // groups before this index are full
-        for (int cls = 0; cls < 4; ++cls)
+        for (int cls = 0; cls <= npe; ++cls)
             for (int32_t e : byc[cls]) {
-                uint16_t bit[3];
-                for (int k = 0; k < 3; ++k) {
-                    const int32_t l = lid[conn[3 * (int64_t)e + k]];
+                uint16_t bit[4] = {0, 0, 0, 0};
+                for (int k = 0; k < npe; ++k) {
+                    const int32_t l = lid[conn[npe * (int64_t)e + k]];
                     bit[k] = l < n_owned ? (uint16_t)(1u << (l & 15)) : 0;
                 }
                 bool placed = false;
                 for (size_t j = first_open; j < open.size(); ++j) {
                     Open &g = open[j];
                     if ((int)g.el.size() >= G) continue;
-                    if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2])) continue;
+                    if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2]) | (g.used[3] & bit[3])) continue;
                     g.el.push_back(e);
-                    for (int k = 0; k < 3; ++k) g.used[k] |= bit[k];
+                    for (int k = 0; k < 4; ++k) g.used[k] |= bit[k];
                     placed = true;
                     break;
                 }
                 if (!placed) {
                     Open g;
                     g.el.push_back(e);
-                    for (int k = 0; k < 3; ++k) g.used[k] = bit[k];
+                    for (int k = 0; k < 4; ++k) g.used[k] = bit[k];
                     open.push_back(std::move(g));
                 }
                 while (first_open < open.size() && (int)open[first_open].el.size() >= G) ++first_open;
@@ -220,7 +221,7 @@ void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, cons
 // among a tile's own elements (node_cap <= 0: no node limit).  Cutting by nodes equalises the LDS
 // footprint of the tiles, so the launch-wide maximum (which sizes every workgroup) sits near the
 // median and more workgroups fit per CU.
-void cut_tiles(const int64_t *conn, int64_t ne, int64_t nn, const std::vector<int32_t> &order, int32_t T,
+void cut_tiles(const int64_t *conn, int npe, int64_t ne, int64_t nn, const std::vector<int32_t> &order, int32_t T,
                int32_t node_cap, std::vector<int64_t> &bounds) {
     bounds.assign(1, 0);
     if (node_cap <= 0) {
@@ -234,27 +235,27 @@ void cut_tiles(const int64_t *conn, int64_t ne, int64_t nn, const std::vector<in
     for (int64_t p = 0; p < ne; ++p) {
         const int64_t e = order[p];
         int fresh = 0;
-        for (int k = 0; k < 3; ++k)
-            if (stamp[conn[3 * e + k]] != tile) ++fresh;
+        for (int k = 0; k < npe; ++k)
+            if (stamp[conn[npe * e + k]] != tile) ++fresh;
         if (p > start && (p - start >= T || distinct + fresh > node_cap)) {
             bounds.push_back(p);
             ++tile;
             start = p;
             distinct = 0;
         }
-        for (int k = 0; k < 3; ++k) {
-            int32_t &st = stamp[conn[3 * e + k]];
+        for (int k = 0; k < npe; ++k) {
+            int32_t &st = stamp[conn[npe * e + k]];
             if (st != tile) { st = tile; ++distinct; }
         }
     }
     bounds.push_back(ne);
 }
 
-int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
+int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const int32_t *x_src,
               const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T, int32_t node_cap,
               const std::vector<int32_t> &order, int elem_order, HostPlan &P) {
     std::vector<int64_t> bounds;
-    cut_tiles(conn, ne, nn, order, T, node_cap, bounds);
+    cut_tiles(conn, npe, ne, nn, order, T, node_cap, bounds);
     const int32_t nt_main = ne > 0 ? (int32_t)bounds.size() - 1 : 0;
     std::vector<int32_t> tile_of(ne);                    // sorted position -> tile
     for (int32_t t = 0; t < nt_main; ++t)
@@ -263,8 +264,8 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
     for (int64_t p = 0; p < ne; ++p) {
         const int32_t t = tile_of[p];
         const int64_t e = order[p];
-        for (int k = 0; k < 3; ++k) {
-            int32_t &o = owner[conn[3 * e + k]];
+        for (int k = 0; k < npe; ++k) {
+            int32_t &o = owner[conn[npe * e + k]];
             if (t < o) o = t;
         }
     }
@@ -277,14 +278,14 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
     // node -> element adjacency (CSR), elements listed in sorted-position order
     std::vector<int64_t> adj_ptr(nn + 1, 0);
     for (int64_t e = 0; e < ne; ++e)
-        for (int k = 0; k < 3; ++k) adj_ptr[conn[3 * e + k] + 1]++;
+        for (int k = 0; k < npe; ++k) adj_ptr[conn[npe * e + k] + 1]++;
     for (int64_t n = 0; n < nn; ++n) adj_ptr[n + 1] += adj_ptr[n];
     std::vector<int32_t> adj(adj_ptr[nn]);
     {
         std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
         for (int64_t p = 0; p < ne; ++p) {
             const int32_t e = order[p];
-            for (int k = 0; k < 3; ++k) adj[fill[conn[3 * e + k]]++] = e;
+            for (int k = 0; k < npe; ++k) adj[fill[conn[npe * e + k]]++] = e;
         }
     }
     // home tile of every element
@@ -313,7 +314,7 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
     }
 
     P = HostPlan();
-    P.ne = ne; P.nn = nn; P.ned = ned; P.tile_elems = T;
+    P.ne = ne; P.nn = nn; P.ned = ned; P.tile_elems = T; P.npe = npe;
     P.tiles.resize(nt);
     P.elem_pack.reserve(ne + ne / 4);
     P.elem_gid.reserve(ne + ne / 4);
@@ -344,11 +345,10 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
         for (int64_t i = o0; i < o1; ++i) { stamp_n[own[i]] = t; lid[own[i]] = nloc++; }
         d.n_owned = nloc;
         for (int32_t e : telems)
-            for (int k = 0; k < 3; ++k) {
-                const int32_t n = (int32_t)conn[3 * (int64_t)e + k];
+            for (int k = 0; k < npe; ++k) {
+                const int32_t n = (int32_t)conn[npe * (int64_t)e + k];
                 if (stamp_n[n] != t) { stamp_n[n] = t; halo.push_back(n); }
             }
-        const int32_t n_real_elems = (int32_t)telems.size();
         for (int64_t i = edg_ptr[t]; i < edg_ptr[t + 1]; ++i)
             for (int k = 0; k < 2; ++k) {
                 const int32_t n = (int32_t)edges[2 * (int64_t)tedge[i] + k];
@@ -357,7 +357,7 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
         std::sort(halo.begin(), halo.end());
         for (int32_t n : halo) lid[n] = nloc++;
         if (nloc > kMaxLocal) return 1;
-        order_tile_elements(telems, conn, lid, d.n_owned, elem_order);
+        order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
 
         d.elem_off = (int32_t)P.elem_pack.size();
         d.n_elem = (int32_t)telems.size();
@@ -368,13 +368,15 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
         for (int32_t e : telems) {
             if (e < 0) {                                   // padding of a bank-conflict-free group
                 P.elem_pack.push_back(kSkipBit);
+                if (npe == 4) P.elem_pack_hi.push_back(0u);
                 P.elem_gid.push_back(-1);
                 continue;
             }
-            const uint32_t l0 = lid[conn[3 * (int64_t)e]], l1 = lid[conn[3 * (int64_t)e + 1]],
-                           l2 = lid[conn[3 * (int64_t)e + 2]];
+            const uint32_t l0 = lid[conn[npe * (int64_t)e]], l1 = lid[conn[npe * (int64_t)e + 1]],
+                           l2 = lid[conn[npe * (int64_t)e + 2]];
             P.elem_pack.push_back(l0 | (l1 << kLocalBits) | (l2 << (2 * kLocalBits)) |
                                   (home[e] == t ? kHomeBit : 0u));
+            if (npe == 4) P.elem_pack_hi.push_back((uint32_t)lid[conn[npe * (int64_t)e + 3]]);
             P.elem_gid.push_back(e);
         }
         auto push_node = [&](int32_t n) {
@@ -407,16 +409,17 @@ int try_build(const int64_t *conn, int64_t ne, int64_t nn, const int32_t *x_src,
 
 void set_plan_curve(int c) { set_locality_curve(c); }
 
-int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *coords,
+int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
                     int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, HostPlan &out) {
+    if (npe != 3 && npe != 4) { set_error("plan: nodes per element must be 3 (TRI3) or 4 (QUAD4)"); return -1; }
     if (ne < 0 || nn < 0 || ned < 0 || nn > std::numeric_limits<int32_t>::max() ||
         ne > std::numeric_limits<int32_t>::max() || ned > std::numeric_limits<int32_t>::max()) {
         set_error("plan: sizes must be in [0, 2^31)");
         return -1;
     }
     if ((ne > 0 && !conn) || (ned > 0 && !edges)) { set_error("plan: null connectivity/edges"); return -1; }
-    for (int64_t i = 0; i < 3 * ne; ++i)
+    for (int64_t i = 0; i < npe * ne; ++i)
         if (conn[i] < 0 || conn[i] >= nn) { set_error("plan: connectivity index out of range"); return -1; }
     for (int64_t i = 0; i < 2 * ned; ++i)
         if (edges[i] < 0 || edges[i] >= nn) { set_error("plan: edge index out of range"); return -1; }
@@ -424,12 +427,13 @@ int build_host_plan(const int64_t *conn, int64_t ne, int64_t nn, const double *c
     if (tile_elems > 4096) tile_elems = 4096;
 
     std::vector<int32_t> order;
-    morton_order(conn, ne, nn, coords, order);
+    morton_order(conn, npe, ne, nn, coords, order);
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
-        const int rc = try_build(conn, ne, nn, x_src, u_src, edges, ned, T, node_cap, order, elem_order, out);
+        const int rc = try_build(conn, npe, ne, nn, x_src, u_src, edges, ned, T, node_cap, order, elem_order, out);
+        if (rc == 0 && npe == 4 && out.max_elems > kMaxQuadSlots) continue;   // QUAD4 kernel: <= 4 slots x 256 threads
         if (rc <= 0) return rc;
     }
-    set_error("plan: could not fit a tile into 1024 local nodes (node valence too high?)");
+    set_error("plan: could not fit a tile into 1024 local nodes / element slots (node valence too high?)");
     return -1;
 }
 

@@ -12,10 +12,18 @@
 #include <hip/hip_runtime.h>
 
 #include "hfem_device.h"
+#include "hfem_plan_dev.h"
 
 namespace hfem {
 
 constexpr int kBlockQ = 256;
+
+int g_quad4_stagger_groups = 2;
+// Phase offset of half the resident workgroups (those with bit `shift` of the launch index set), in 10 ns ticks.
+// -1 (auto): 2 us when the launch has at least 1.5 rounds of tiles, else none.  Measured on Q1M (2031 tiles, 1024
+// resident): 30.0 us without, 27.2 us with -- the delayed half gathers while the other half is in its fp64 stage.
+int g_quad4_stagger = -1, g_quad4_stagger_shift = 8;
+int g_quad4_ablate = 0;   // lab only: bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
 
 struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1
     double da, db, dc, dd;
@@ -40,12 +48,12 @@ __device__ __forceinline__ double jac_point(double a, double b, double c, double
         const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;
         o.dg0 = make_double2(p00 * di - p01 * ci, p01 * di - p11 * ci);
         o.dg1 = make_double2(p01 * ai - p00 * bi, p11 * ai - p01 * bi);
-        const double q = det < 0.0 ? -w : w;
-        const double ddet = det < 0.0 ? wpsi : -wpsi;
-        o.da = q * (sxy * g1.x + syy * g1.y) + ddet * d;
-        o.db = -q * (sxx * g1.x + sxy * g1.y) - ddet * c;
-        o.dc = -q * (sxy * g0.x + syy * g0.y) - ddet * b;
-        o.dd = q * (sxx * g0.x + sxy * g0.y) + ddet * a;
+        // dJ = -dG^T H + sign(det) w psi cof(J)
+        const double sd = det < 0.0 ? -wpsi : wpsi;
+        o.da = sd * d - (o.dg0.x * h00 + o.dg0.y * h10);
+        o.db = -sd * c - (o.dg0.x * h01 + o.dg0.y * h11);
+        o.dc = -sd * b - (o.dg1.x * h00 + o.dg1.y * h10);
+        o.dd = sd * a - (o.dg1.x * h01 + o.dg1.y * h11);
     }
     return A * wpsi;
 }
@@ -60,6 +68,69 @@ __device__ __forceinline__ void shape_derivs(double xi, double eta, double (&D0)
         D0[k] = 0.25 * corner_xi(k) * (1.0 + corner_eta(k) * eta);
         D1[k] = 0.25 * corner_eta(k) * (1.0 + corner_xi(k) * xi);
     }
+}
+
+// Whole-element energy (2x2 Gauss, weights 1) and its gradient w.r.t. the four nodes, in the bilinear
+// coefficient form.  For a nodal field v_0..v_3:  4 dv/dxi = a1 + eta a3,  4 dv/deta = a2 + xi a3  with
+//   a1 = (v1-v0)+(v2-v3),  a2 = (v3-v0)+(v2-v1),  a3 = (v2-v3)-(v1-v0).
+// H = G J^-T does not see the common factor 4 and |det| sees 16, so the points are evaluated on the unscaled
+// coefficients with weight 1/16; cotangents are accumulated per coefficient (the a3 part as +-da +-db, scaled by
+// 1/sqrt(3) once) and spread to the nodes with +-1 at the end.  ~370 fp64 instructions per element with
+// gradients (the node-by-node D_N form above costs ~490).
+template <bool GRAD>
+__device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const double2 (&Un)[4], const Tri3Consts &k,
+                                                double2 (&gx)[4], double2 (&gu)[4]) {
+    const double gp = 0.57735026918962576451;   // 1/sqrt(3)
+    double a1[4], a2[4], a3[4];                  // components: x, y, ux, uy
+    {
+        const double v[4][4] = {{Xn[0].x, Xn[1].x, Xn[2].x, Xn[3].x}, {Xn[0].y, Xn[1].y, Xn[2].y, Xn[3].y},
+                                {Un[0].x, Un[1].x, Un[2].x, Un[3].x}, {Un[0].y, Un[1].y, Un[2].y, Un[3].y}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double s = v[i][1] - v[i][0], t = v[i][2] - v[i][3];
+            a1[i] = s + t;
+            a3[i] = t - s;
+            a2[i] = (v[i][3] - v[i][0]) + (v[i][2] - v[i][1]);
+        }
+    }
+    // Points in the order (-,-) (+,-) (-,+) (+,+).  With u_q = dE/d(4 dv/dxi) and v_q = dE/d(4 dv/deta) at point q:
+    //   d a1 = sum u_q, d a2 = sum v_q, d a3 = gp ((u2+u3) - (u0+u1) + (v1+v3) - (v0+v2)); the pair sums are shared.
+    double U[4][4], V[4][4];
+    double e = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp;
+        const double a = a1[0] + eta * a3[0], b = a2[0] + xi * a3[0];
+        const double c = a1[1] + eta * a3[1], d = a2[1] + xi * a3[1];
+        const double2 g0 = make_double2(a1[2] + eta * a3[2], a1[3] + eta * a3[3]);
+        const double2 g1 = make_double2(a2[2] + xi * a3[2], a2[3] + xi * a3[3]);
+        JacGrad o;
+        e += jac_point<GRAD>(a, b, c, d, g0, g1, 0.0625, k, o);
+        if (GRAD) {
+            U[q][0] = o.da; U[q][1] = o.dc; U[q][2] = o.dg0.x; U[q][3] = o.dg0.y;
+            V[q][0] = o.db; V[q][1] = o.dd; V[q][2] = o.dg1.x; V[q][3] = o.dg1.y;
+        }
+    }
+    if (GRAD) {
+        double g[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double u01 = U[0][i] + U[1][i], u23 = U[2][i] + U[3][i];
+            const double v02 = V[0][i] + V[2][i], v13 = V[1][i] + V[3][i];
+            const double d1 = u01 + u23, d2 = v02 + v13;
+            const double d3 = gp * ((u23 - u01) + (v13 - v02)), p = d1 + d2, m = d1 - d2;
+            g[0][i] = d3 - p;
+            g[1][i] = m - d3;
+            g[2][i] = p + d3;
+            g[3][i] = -m - d3;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gx[j] = make_double2(g[j][0], g[j][1]);
+            gu[j] = make_double2(g[j][2], g[j][3]);
+        }
+    }
+    return e;
 }
 
 // fused QUAD4 energy: sum over 2x2 Gauss points (+-1/sqrt(3), weights 1) of |detJ| psi, fwd + bwd
@@ -197,6 +268,169 @@ __global__ __launch_bounds__(kBlockQ) void quad4_eval_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------ tiled (owner-computes plan)
+// Same structure as tri3_energy_fast_kernel (tri3_energy.hip): row maps + element records requested
+// up front, nodes gathered into LDS through the free/fixed maps, one thread per element slot
+// (8 x ds_read_b128, 4 Gauss points in registers, 16 conflict-free ds_add_f64 on owned corners),
+// every owned gradient row written once with an sc1 (write-through) store.  Element records are two
+// words per slot: {l0 | l1<<10 | l2<<20 | home<<30 | skip<<31} and {l3}.
+template <int BLOCK, int NPT, int EPT, int ABL>
+__global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
+    PlanDev pd, int tile_begin, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
+    const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
+    const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
+    double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges,
+    int stagger_ticks, int stagger_shift, unsigned long long *__restrict__ stamps) {
+#define HFEM_QSTAMP(I)                                                                              \
+    if ((ABL & 4) && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+    HFEM_QSTAMP(0)
+    extern __shared__ double2 lds[];
+    double2 *nd_xy = lds;
+    double2 *nd_uv = lds + cap_nodes;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
+
+    const int tid = threadIdx.x;
+    const int slot = xcd_tile(blockIdx.x, gridDim.x);
+    // Phase offset between co-resident workgroups: without it every resident tile gathers at the same time and
+    // then computes at the same time (HBM idle while the fp64 VALU works and vice versa).
+    if (stagger_ticks > 0) {
+        const int grp = (blockIdx.x >> (stagger_shift & 31)) & (stagger_shift >> 8);   // shift | (groups-1) << 8
+        const long long wait = (long long)stagger_ticks * grp / (stagger_shift >> 8);
+        const long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz: 10 ns ticks
+        while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
+    }
+    const TileDesc d = pd.tiles[tile_begin + slot];
+    const int n_owned = d.n_owned;
+    if ((ABL & 4) && threadIdx.x == 0 && n_owned >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+
+    int2 s[NPT];
+    uint32_t pk[EPT], pk3[EPT];
+    const int2 *src = pd.node_src + d.node_off;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        s[j] = make_int2(0, 0);
+        if (l < d.n_node) s[j] = src[l];
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * BLOCK;
+        pk[j] = kSkipBit;
+        pk3[j] = 0u;
+        if (i < d.n_elem) { pk[j] = pd.elem_pack[d.elem_off + i]; pk3[j] = pd.elem_pack_hi[d.elem_off + i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        if (l < d.n_node) {
+            nd_xy[l] = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
+            nd_uv[l] = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
+        }
+        if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
+    }
+    if (tid == 0) red[0] = 0.0;
+    HFEM_QSTAMP(2)
+    __syncthreads();
+    HFEM_QSTAMP(3)
+
+    double e_loc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < EPT; ++jj) {
+        const uint32_t p = pk[jj];
+        if (!(p & kSkipBit)) {
+            const int l[4] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask),
+                              (int)((p >> (2 * kLocalBits)) & kLocalMask), (int)(pk3[jj] & kLocalMask)};
+            double2 Xn[4], Un[4], gx[4], gu[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Xn[j] = nd_xy[l[j]];
+                Un[j] = nd_uv[l[j]];
+            }
+            double e;
+            if (ABL & 1) {          // lab: no element math
+                e = Xn[0].x + Un[3].y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { gx[j] = Xn[j]; gu[j] = Un[j]; }
+            } else {
+                e = quad4_element<true>(Xn, Un, k, gx, gu);
+            }
+            if (ABL & 2) {          // lab: no LDS atomics (keep the math live)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e += gx[j].x + gx[j].y + gu[j].x + gu[j].y;
+            }
+            if (p & kHomeBit) e_loc += e;
+            if (!(ABL & 2)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (l[j] < n_owned) {
+                        unsafeAtomicAdd(&acc0[l[j]], gx[j].x); unsafeAtomicAdd(&acc1[l[j]], gx[j].y);
+                        unsafeAtomicAdd(&acc2[l[j]], gu[j].x); unsafeAtomicAdd(&acc3[l[j]], gu[j].y);
+                    }
+            }
+        }
+    }
+    const int n_edge = skip_edges ? 0 : d.n_edge;
+    for (int i = tid; i < n_edge; i += BLOCK) {          // boundary tiles only
+        const uint32_t p = pd.edge_pack[d.edge_off + i];
+        const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
+        const double4 tt = T_edge ? T_edge[pd.edge_gid[d.edge_off + i]] : Tconst;
+        double2 gx[2], gu[2];
+        const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
+        if (p & kHomeBit) e_loc -= wk;
+        if (l0 < n_owned) {
+            unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
+            unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
+        }
+        if (l1 < n_owned) {
+            unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
+            unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
+        }
+    }
+    {
+        const double w = wave_sum(e_loc);
+        if ((tid & 63) == 0) unsafeAtomicAdd(&red[0], w);
+    }
+    HFEM_QSTAMP(4)
+    __syncthreads();
+    HFEM_QSTAMP(5)
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
+    __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        if (l < n_owned) {
+            if (gx_free && s[j].x >= 0) {
+                const double2 v = make_double2(acc0[l], acc1[l]);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, 16);
+            }
+            if (gu_free && s[j].y >= 0) {
+                const double2 v = make_double2(acc2[l], acc3[l]);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, 16);
+            }
+        }
+    }
+    if (tid == 0) partials[slot] = red[0];
+    HFEM_QSTAMP(6)
+    if (ABL & 4) {
+        __builtin_amdgcn_s_waitcnt(0);
+        HFEM_QSTAMP(7)
+    }
+#undef HFEM_QSTAMP
+}
+
+__global__ __launch_bounds__(256) void quad4_sum_partials_kernel(const double *__restrict__ partials, int n,
+                                                                 double *__restrict__ out) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
 static int grid_q(int64_t n) {
     int64_t g = (n + kBlockQ - 1) / kBlockQ;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -248,4 +482,48 @@ extern "C" int hfem_quad4_eval_bwd(int device, const double *X, const double *U,
                        (const double2 *)X, (const double2 *)U, conn, (const double2 *)x_eval, elem_id, m,
                        (const double2 *)cu, cd, (const double4 *)cg, gX, gU);
     return launch_status("hfem_quad4_eval_bwd");
+}
+
+extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                                      const double *u_free, const double *u_fixed, const double mat[4],
+                                      const double *T_edge, const double Tconst[4], int32_t tile_begin,
+                                      int32_t tile_end, double *loss_out, double *gx_free, double *gu_free,
+                                      int32_t flags, void *stream) {
+    HFEM_ARG_CHECK(plan && mat && loss_out, "null pointer");
+    HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    HFEM_ARG_CHECK(plan->host.npe == 4, "this plan was built for TRI3: use hfem_tri3_energy_plan");
+    HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
+    const HostPlan &h = plan->host;
+    const int32_t nt = (int32_t)h.tiles.size();
+    if (tile_end < 0) tile_end = nt;
+    HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
+    HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
+    HFEM_ARG_CHECK(h.max_nodes <= 4 * 256 && h.max_elems <= 4 * 256, "QUAD4 tile exceeds the kernel's register tiling");
+    if (int rc = use_device(plan->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = tile_end - tile_begin;
+    if (n > 0) {
+        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+        Tri3Consts k = make_consts(mat, 1.0, nullptr);
+#define HFEM_LAUNCH_Q4(NPT, EPT, ...)                                                                       \
+    hipLaunchKernelGGL((quad4_energy_fast_kernel<256, NPT, EPT, __VA_ARGS__>), dim3(n), dim3(256), (size_t)plan->lds_bytes, s, \
+                       plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,  \
+                       (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,   \
+                       plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free, \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger, g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps)
+        const int abl = g_quad4_ablate;
+        const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
+        if (abl == 1) HFEM_LAUNCH_Q4(4, 4, 1);                       // lab instances (hfem_set_option("quad4_ablate"))
+        else if (abl == 2) HFEM_LAUNCH_Q4(4, 4, 2);
+        else if (abl == 3) HFEM_LAUNCH_Q4(4, 4, 3);
+        else if (abl == 4) HFEM_LAUNCH_Q4(4, 4, 4);                  // s_memrealtime phase stamps (scripts/stamps.py)
+        else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
+        else HFEM_LAUNCH_Q4(4, 4, 0);
+#undef HFEM_LAUNCH_Q4
+        if (int rc = launch_status("hfem_quad4_energy_plan")) return rc;
+    }
+    if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
+    hipLaunchKernelGGL(quad4_sum_partials_kernel, dim3(1), dim3(256), 0, s, plan->d_partials + tile_begin, n, loss_out);
+    return launch_status("hfem_quad4_energy_plan(sum)");
 }

@@ -17,6 +17,7 @@
 #include <memory>
 
 #include "hfem_device.h"
+#include "hfem_plan_dev.h"
 
 namespace hfem {
 
@@ -81,23 +82,6 @@ __global__ __launch_bounds__(kBlock) void edge2_energy_atomic_kernel(
 }
 
 // ------------------------------------------------------------------ tiled plan
-struct PlanDev {
-    const TileDesc *tiles;
-    const uint32_t *elem_pack;
-    const int2 *node_src;
-    const uint32_t *edge_pack;
-    const int32_t *edge_gid;
-};
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
-// L2).  Map block -> tile so that each XCD walks one contiguous run of the
-// Morton-ordered tiles: neighbouring tiles share halo nodes, which then hit the
-// same L2.  Bijective for any grid size; placement only affects speed.
-__device__ __forceinline__ int xcd_tile(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-
 // Ablation bits of the lab build (hfem_set_option("tiled_ablate", bits)); 0 in production.
 //   1: LDS atomics -> plain LDS stores    2: skip the element/edge phase
 //   4: skip the global node gather        8: skip the gradient write-out
@@ -622,30 +606,6 @@ static int g_store_policy = 16;  // gradient stores of the fast kernel: 16 = sc1
 static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
-struct hfem_plan {
-    HostPlan host;
-    int device = -1;
-    // device mirrors
-    TileDesc *d_tiles = nullptr;
-    uint32_t *d_elem_pack = nullptr;
-    int2 *d_node_src = nullptr;
-    uint32_t *d_edge_pack = nullptr;
-    int32_t *d_edge_gid = nullptr;
-    double *d_partials = nullptr;
-    unsigned long long *d_stamps = nullptr;   // lab only: [n_tiles][8] s_memrealtime stamps
-    int64_t device_bytes = 0;
-    int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
-    int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
-};
-
-static Tri3Consts make_consts(const double mat[4], double W, const double Bk[6]) {
-    Tri3Consts k;
-    k.c11 = mat[0]; k.c12 = mat[1]; k.c22 = mat[2]; k.c33 = mat[3];
-    k.W = W;
-    for (int i = 0; i < 6; ++i) k.Bk[i] = Bk ? Bk[i] : 0.0;
-    return k;
-}
-
 static int grid_for(int64_t n, int cap = 256 * 8) {
     int64_t g = (n + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
@@ -685,7 +645,7 @@ extern "C" int hfem_edge2_energy_atomic(int device, const double *X, const doubl
 }
 
 template <typename T>
-static int upload(T **dst, const void *src, size_t count, int64_t &bytes) {
+int hfem_upload(T **dst, const void *src, size_t count, int64_t &bytes) {
     const size_t nb = std::max<size_t>(count, 1) * sizeof(T);
     HFEM_HIP_CHECK(hipMalloc((void **)dst, nb));
     if (count && src) HFEM_HIP_CHECK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
@@ -700,6 +660,7 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
         (void)hipSetDevice(plan->device);
         (void)hipFree(plan->d_tiles);
         (void)hipFree(plan->d_elem_pack);
+        (void)hipFree(plan->d_elem_pack_hi);
         (void)hipFree(plan->d_node_src);
         (void)hipFree(plan->d_edge_pack);
         (void)hipFree(plan->d_edge_gid);
@@ -710,16 +671,26 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
     return 0;
 }
 
+extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, int64_t nn, int32_t nodes_per_elem,
+                                   const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
+                                   const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out);
+
 extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
                                 const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
                                 const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out) {
+    return hfem_plan_create_ex(device, conn, ne, nn, 3, coords_hint, x_src, u_src, edges, ned, tile_elems, out);
+}
+
+extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, int64_t nn, int32_t nodes_per_elem,
+                                   const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
+                                   const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out) {
     HFEM_ARG_CHECK(out, "null out pointer");
     *out = nullptr;
     std::unique_ptr<hfem_plan> p(new hfem_plan);
     int32_t node_cap = g_plan_node_cap;
     if (node_cap < 0) node_cap = tile_elems <= 0 ? 557 : 0;
     if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
-    if (build_host_plan(conn, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, p->host)) return -1;
+    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, p->host)) return -1;
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
@@ -728,13 +699,14 @@ extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int
         p->device = device;
         hfem_plan *raw = p.get();
         int rc = 0;
-        if (!rc) rc = upload(&raw->d_tiles, h.tiles.data(), h.tiles.size(), raw->device_bytes);
-        if (!rc) rc = upload(&raw->d_elem_pack, h.elem_pack.data(), h.elem_pack.size(), raw->device_bytes);
-        if (!rc) rc = upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
-        if (!rc) rc = upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
-        if (!rc) rc = upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
-        if (!rc) rc = upload(&raw->d_partials, nullptr, h.tiles.size(), raw->device_bytes);
-        if (!rc) rc = upload(&raw->d_stamps, nullptr, h.tiles.size() * 8, raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_tiles, h.tiles.data(), h.tiles.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_elem_pack, h.elem_pack.data(), h.elem_pack.size(), raw->device_bytes);
+        if (!rc && h.npe == 4) rc = hfem_upload(&raw->d_elem_pack_hi, h.elem_pack_hi.data(), h.elem_pack_hi.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, h.tiles.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, h.tiles.size() * 8, raw->device_bytes);
         if (!rc && p->lds_bytes_pipe > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
             rc = -1;
@@ -774,6 +746,7 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 3: src = h.edge_pack.data(); n = (int64_t)h.edge_pack.size(); break;
         case 4: src = h.edge_gid.data(); n = (int64_t)h.edge_gid.size(); break;
         case 5: src = h.elem_gid.data(); n = (int64_t)h.elem_gid.size(); break;
+        case 7: src = h.elem_pack_hi.data(); n = (int64_t)h.elem_pack_hi.size(); break;
         case 6: {   // lab: device stamps, 8 x uint64 per tile, returned as 16 x int32 per tile
             n = (int64_t)h.tiles.size() * 16;
             if (buf) {
@@ -800,6 +773,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                                      void *stream) {
     HFEM_ARG_CHECK(plan && mat && loss_out, "null pointer");
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4: use hfem_quad4_energy_plan");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
     const int32_t nt = (int32_t)plan->host.tiles.size();
     if (tile_end < 0) tile_end = nt;
@@ -809,7 +783,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
     if (n > 0) {
-        PlanDev pd{plan->d_tiles, plan->d_elem_pack, plan->d_node_src, plan->d_edge_pack, plan->d_edge_gid};
+        PlanDev pd = plan_dev(plan);
         const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
         int n_partials = n;
         bool launched = false;
@@ -951,6 +925,18 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_tiled_block = value;
     } else if (n == "tiled_ablate") {
         g_tiled_ablate = value;
+    } else if (n == "quad4_stagger") {
+        HFEM_ARG_CHECK(value >= -1 && value <= 100000, "quad4_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
+        g_quad4_stagger = value;
+    } else if (n == "quad4_stagger_groups") {
+        HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "quad4_stagger_groups: 2, 4 or 8");
+        g_quad4_stagger_groups = value;
+    } else if (n == "quad4_stagger_shift") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 20, "quad4_stagger_shift: bit of the workgroup index, 0..20");
+        g_quad4_stagger_shift = value;
+    } else if (n == "quad4_ablate") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 4, "quad4_ablate: lab variants 0..4");
+        g_quad4_ablate = value;
     } else if (n == "tiled_stagger") {
         HFEM_ARG_CHECK(value >= 0 && value <= 100000, "tiled_stagger is in 10 ns ticks, 0..100000");
         g_tiled_stagger = value;
@@ -985,6 +971,7 @@ extern "C" int hfem_get_option(const char *name) {
     const std::string n(name);
     if (n == "tiled_block") return g_tiled_block;
     if (n == "tiled_ablate") return g_tiled_ablate;
+    if (n == "quad4_ablate") return g_quad4_ablate;
     if (n == "plan_elem_order") return g_plan_elem_order;
     if (n == "tiled_pipe") return g_tiled_pipe;
     if (n == "tiled_fast") return g_tiled_fast;

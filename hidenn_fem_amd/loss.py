@@ -29,6 +29,7 @@ class EnergyLoss2D:
         self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.dtype = dtype
         self.tile_elems = tile_elems
+        self.quad4_planless = False       # True: QUAD4 energy through the planless atomic kernel (cross-check)
         factor = E / (1 - nu ** 2)
         self.C = torch.tensor([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, (1.0 - nu) / 2.0]],
                               dtype=dtype, device=self.device) * factor          # loss.py:29-32
@@ -116,8 +117,12 @@ class EnergyLoss2D:
         if b_force is not None or t_force is not None:
             raise NotImplementedError("QUAD4 extension: body force / custom traction are not built")
         _, Tconst = self._traction(model, None)
-        edges = model._edges32 if model.N_edges else None
-        return ops.Quad4EnergyFn.apply(model.coords, model.u_full, model._conn32, edges, self._mat, Tconst)
+        if self.quad4_planless:                                    # cross-check path: fp64 global atomics
+            edges = model._edges32 if model.N_edges else None
+            return ops.Quad4EnergyFn.apply(model.coords, model.u_full, model._conn32, edges, self._mat, Tconst)
+        plan = model.tile_plan(self.tile_elems)
+        return ops.Quad4PlanEnergyFn.apply(model.node_coords_free, model.u_free, model.node_coords_fixed.to(model.dtype),
+                                           model.u_fixed_rows(), plan, self._mat, Tconst)
 
     def __call__(self, model, b_force=None, t_force=None) -> torch.Tensor:
         """Total potential = domain - edge (loss.py:113-116), one fused launch."""

@@ -277,7 +277,8 @@ class TriangularShapeNN2D(nn.Module):
         if key not in self._plans:
             self._plans[key] = TilePlan(self.connectivity, self.Nnodes, coords_hint=self.initial_node_coords,
                                         x_src=self._x_src, u_src=self._u_src, edges=self.neumann_edges,
-                                        tile_elems=tile_elems, device=self.device)
+                                        tile_elems=tile_elems, device=self.device,
+                                        nodes_per_elem=getattr(self, "nodes_per_element", 3))
         return self._plans[key]
 
     # -- the (x_ref, element_id) forward contract -------------------------------------------
@@ -293,13 +294,9 @@ class QuadShapeNN2D(TriangularShapeNN2D):
     """QUAD4-iso extension element: same construction API, parameters, buffers and
     attribute surface as the triangular model, ``connectivity [Ne,4]`` (local nodes CCW), reference
     square ``[-1,1]^2``.  ``forward(x_eval, elem_id)`` keeps the ``(x_ref, element_id)`` contract.  The
-    fused energy is planless this round (fp64 global atomics); there is no reference counterpart."""
+    fused energy runs on the same owner-computes tile plan as TRI3; there is no reference counterpart."""
 
     nodes_per_element = 4
-
-    def tile_plan(self, tile_elems: int = 0):
-        raise NotImplementedError("the owner-computes tile plan is TRI3-only in this round; QUAD4 uses the planless "
-                                  "fused kernel (hfem_quad4_energy_atomic)")
 
     def forward(self, x_eval, elem_id, edge=False):
         if not edge:

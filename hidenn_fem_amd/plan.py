@@ -16,7 +16,7 @@ import torch
 from . import _lib
 
 EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
-              "stamps": 6}
+              "stamps": 6, "elem_pack_hi": 7}
 
 
 def _np(a, dtype):
@@ -42,8 +42,11 @@ class TilePlan:
 
     def __init__(self, connectivity, n_nodes: int, coords_hint=None, x_src=None, u_src=None,
                  edges=None, tile_elems: int = 0, device: Optional[torch.device] = None,
-                 elem_order: Optional[int] = None):
-        conn = _np(connectivity, np.int64).reshape(-1, 3)
+                 elem_order: Optional[int] = None, nodes_per_elem: int = 3):
+        if nodes_per_elem not in (3, 4):
+            raise ValueError("nodes_per_elem must be 3 (TRI3) or 4 (QUAD4)")
+        self.nodes_per_elem = nodes_per_elem
+        conn = _np(connectivity, np.int64).reshape(-1, nodes_per_elem)
         hint = _np(coords_hint, np.float64)
         xs, us = _np(x_src, np.int32), _np(u_src, np.int32)
         ed = _np(edges, np.int64)
@@ -64,8 +67,8 @@ class TilePlan:
 
         if elem_order is not None:
             _lib.check(_lib.lib().hfem_set_option(b"plan_elem_order", int(elem_order)), "hfem_set_option")
-        rc = _lib.lib().hfem_plan_create(dev, p(conn), self.n_elems, self.n_nodes, p(hint), p(xs), p(us),
-                                         p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
+        rc = _lib.lib().hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
+                                            p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
         _lib.check(rc, "hfem_plan_create")
         st = _lib.PlanStats()
         _lib.check(_lib.lib().hfem_plan_get_stats(self._h, C.byref(st)), "hfem_plan_get_stats")
@@ -81,7 +84,7 @@ class TilePlan:
         n = _lib.lib().hfem_plan_export(self._h, which, None, 0)
         if n < 0:
             _lib.check(-1, "hfem_plan_export")
-        dt = np.uint32 if name in ("elem_pack", "edge_pack") else np.int32
+        dt = np.uint32 if name in ("elem_pack", "edge_pack", "elem_pack_hi") else np.int32
         out = np.empty(int(n), dtype=dt)
         if n:
             got = _lib.lib().hfem_plan_export(self._h, which, out.ctypes.data_as(C.c_void_p), n)

@@ -93,11 +93,17 @@ int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
                      const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
                      const int64_t *edges, int64_t ned, int32_t tile_elems,
                      hfem_plan **out);
+/* Same with an explicit element type: nodes_per_elem = 3 (TRI3, conn [Ne][3]) or 4 (QUAD4 extension,
+ * conn [Ne][4], local nodes CCW).                                                          */
+int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, int64_t nn, int32_t nodes_per_elem,
+                        const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
+                        const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out);
 int hfem_plan_destroy(hfem_plan *plan);
 int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
 /* Copy a host-side plan array out (for tests).  which: 0 tile_desc [n_tiles][8]
  * i32, 1 elem_pack u32, 2 node_src [.][2] i32, 3 edge_pack u32, 4 edge_gid i32,
- * 5 elem_gid i32 (global element id of every tile element).
+ * 5 elem_gid i32 (global element id of every tile element; -1 = padding), 6 lab stamps,
+ * 7 elem_pack_hi u32 (QUAD4 plans: 4th local node of every slot).
  * Returns the element count, or <0.  buf may be NULL to query the size.       */
 int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t cap_elems);
 
@@ -158,6 +164,13 @@ int hfem_edge2_eval_bwd(int device, const double *X, const double *U, const int3
 int hfem_quad4_energy_atomic(int device, const double *X, const double *U, const int32_t *conn4,
                              int64_t e_begin, int64_t e_end, int64_t nn, const double mat[4],
                              double *loss_acc, double *gX, double *gU, void *stream);
+/* Tiled QUAD4 (plan from hfem_plan_create_ex(..., 4, ...)): same contract as hfem_tri3_energy_plan --
+ * loss_out / gx_free / gu_free rows of the tile range OVERWRITTEN, free/fixed row maps fused.      */
+int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                           const double *u_free, const double *u_fixed, const double mat[4],
+                           const double *T_edge, const double Tconst[4], int32_t tile_begin,
+                           int32_t tile_end, double *loss_out, double *gx_free, double *gu_free,
+                           int32_t flags, void *stream);
 /* Per-point forward/backward with the (x_ref, element_id) contract of src/models.py:316:
  * x_eval [M][2] in [-1,1]^2 -> u_h [M][2], detJ [M], grad_u [M][2][2]; backward ACCUMULATES gX,gU. */
 int hfem_quad4_eval_fwd(int device, const double *X, const double *U, const int32_t *conn4,

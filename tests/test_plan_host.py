@@ -17,7 +17,8 @@ SKIP = 1 << 31
 def decode(plan):
     td = plan.export("tile_desc")
     return dict(td=td, ep=plan.export("elem_pack"), ns=plan.export("node_src"),
-                gp=plan.export("edge_pack"), gg=plan.export("edge_gid"), eg=plan.export("elem_gid"))
+                gp=plan.export("edge_pack"), gg=plan.export("edge_gid"), eg=plan.export("elem_gid"),
+                hi=plan.export("elem_pack_hi") if plan.nodes_per_elem == 4 else None)
 
 
 def check_invariants(conn, edges, nn, plan):
@@ -37,8 +38,10 @@ def check_invariants(conn, edges, nn, plan):
         real = (a["ep"][eo:eo + nel] & SKIP) == 0          # padding records of bank-aware groups
         assert (a["eg"][eo:eo + nel][~real] == -1).all()
         pk = a["ep"][eo:eo + nel][real]
-        nel = int(real.sum())
         loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1)
+        if a["hi"] is not None:                              # QUAD4 plans: 4th local node in the second word
+            loc = np.concatenate([loc, (a["hi"][eo:eo + nel][real] & MASK)[:, None]], axis=1)
+        nel = int(real.sum())
         assert loc.max(initial=0) < max(nno, 1)
         eg = a["eg"][eo:eo + a["td"][t][1]][real]
         # the local node ORDER of every element is preserved (reference energy depends on it, F4)
@@ -103,11 +106,12 @@ def bank_passes(a):
     tot = ninstr = 0
     for (eo, nel, no, nno, nown, go, ned, _) in a["td"]:
         pk = a["ep"][eo:eo + nel]
+        hi = a["hi"][eo:eo + nel] if a["hi"] is not None else None
         for g0 in range(0, nel, 16):
-            blk = pk[g0:g0 + 16]
-            blk = blk[(blk & SKIP) == 0]
-            for c in range(3):
-                l = (blk >> (10 * c)) & MASK
+            keep = (pk[g0:g0 + 16] & SKIP) == 0
+            blk = pk[g0:g0 + 16][keep]
+            for c in range(3 if hi is None else 4):
+                l = ((blk >> (10 * c)) & MASK) if c < 3 else (hi[g0:g0 + 16][keep] & MASK)
                 l = l[l < nown]
                 if len(l):
                     tot += np.bincount(l % 16, minlength=16).max()
@@ -149,6 +153,21 @@ def test_plan_invariants_and_emulation(name, tile_elems):
     assert not np.isnan(gX).any() and not np.isnan(gU).any(), "every gradient row written"
     assert np.abs(gX - gX_ref).max() <= 1e-11 * np.abs(gX_ref).max()
     assert np.abs(gU - gU_ref).max() <= 1e-11 * np.abs(gU_ref).max()
+
+
+@pytest.mark.parametrize("tile_elems", [16, 0])
+def test_quad4_plan_invariants_and_bank_groups(tile_elems):
+    """QUAD4 plans (nodes_per_elem = 4): same partition invariants, 4th local id in elem_pack_hi, and the
+    default record order is conflict-free for all four corner positions."""
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    coords, conn, geom, bc, mn, edges = structured_quad_mesh(61, 47, jitter=0.2, seed=2, dtype=torch.float64)
+    plan = TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges, tile_elems=tile_elems, nodes_per_elem=4)
+    assert plan.stats["n_elems"] == conn.shape[0]
+    a = check_invariants(conn.numpy(), edges.numpy(), coords.shape[0], plan)
+    assert bank_passes(a) == 1.0
+    assert plan.stats["tile_elem_total"] <= 1.25 * conn.shape[0] + 16 * plan.n_tiles
+    with pytest.raises(ValueError):
+        TilePlan(conn, coords.shape[0], nodes_per_elem=5)
 
 
 def test_plan_without_hint_and_with_maps():

@@ -56,6 +56,15 @@ def test_quad4_kernels_match_the_autograd_oracle():
     gx, gu = m.node_coords_free.grad.cpu().numpy(), m.u_free.grad.cpu().numpy()
     assert np.abs(gx - xf.grad.numpy()).max() <= 1e-10 * np.abs(xf.grad.numpy()).max()
     assert np.abs(gu - uf.grad.numpy()).max() <= 1e-10 * np.abs(uf.grad.numpy()).max()
+    # the planless (global fp64 atomics) kernel is kept as a cross-check of the tiled one
+    m.zero_grad()
+    lf.quad4_planless = True
+    loss_a = lf(m)
+    loss_a.backward()
+    lf.quad4_planless = False
+    assert abs(loss_a.item() - ref.item()) <= 1e-12 * abs(ref.item())
+    assert np.abs(m.node_coords_free.grad.cpu().numpy() - gx).max() <= 1e-10 * np.abs(gx).max()
+    assert np.abs(m.u_free.grad.cpu().numpy() - gu).max() <= 1e-10 * np.abs(gu).max()
     # per-point forward / backward with the (x_ref, element_id) contract
     g = torch.Generator().manual_seed(5)
     M = 700
@@ -106,3 +115,14 @@ def test_quad4_one_million_elements_runs_and_matches_sampled_oracle():
                                                    Xd.shape[0], (C.c_double * 4)(*lf._mat), acc.data_ptr(), None, None,
                                                    _lib.stream_ptr(d)))
     assert abs(acc.item() - e_sub) <= 1e-12 * abs(e_sub)
+    # tiled (default) vs planless at full size: same loss and gradients up to fp64 summation order
+    gx, gu = m.node_coords_free.grad.clone(), m.u_free.grad.clone()
+    m.zero_grad()
+    lf.quad4_planless = True
+    loss_a = lf(m)
+    loss_a.backward()
+    assert abs(loss_a.item() - loss.item()) <= 1e-12 * abs(loss.item())
+    assert (m.node_coords_free.grad - gx).abs().max() <= 1e-10 * gx.abs().max()
+    assert (m.u_free.grad - gu).abs().max() <= 1e-10 * gu.abs().max()
+    st = m.tile_plan().stats
+    assert st["n_elems"] == 10 ** 6 and st["lds_bytes"] <= 40 * 1024

@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--cpu-evals", type=int, default=2)
+    ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed replays before each timed leg")
+    ap.add_argument("--option", action="append", default=[], help="name=value for hfem_set_option (lab A/B runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the multi-rank path on fewer GPUs than ranks)")
     return ap.parse_args()
@@ -118,6 +120,9 @@ def main():
     torch.manual_seed(0)
     model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
                                      neumann_edges=edges).to(dev)
+    for kv in a.option:
+        name, val = kv.split("=")
+        _lib.check(_lib.lib().hfem_set_option(name.encode(), int(val)), "hfem_set_option")
     loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
     sh = ShardedTri3Energy(model, loss_fn)
     plan = sh.plan
@@ -161,6 +166,17 @@ def main():
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
             graph = None
+    # untimed pre-warm on top of the W warm-up steps: the whole default run is a few ms of GPU time, shorter than
+    # the clock ramp of an idle chip (the first timed regions read 5-7 % slow without it).  Fixed count when N > 1
+    # (every rank must issue the same number of collectives).
+    if graph is not None:
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < a.prewarm:
+            graph.replay()
+            torch.cuda.synchronize()
+    else:
+        for _ in range(int(a.prewarm * 400)):
+            step()
     for _ in range(a.warmup):
         step()
     if graph is not None:
@@ -239,9 +255,10 @@ def main():
     stream = torch.cuda.current_stream()
     for _ in range(5):
         kernel_only()
-    if kgraph is not None:
+    t_pw = time.perf_counter()
+    while kgraph is not None and time.perf_counter() - t_pw < a.prewarm:
         kgraph.replay()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     samples = []
     for _ in range(5):                      # 5 timed regions of `kreps` back-to-back launches each
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

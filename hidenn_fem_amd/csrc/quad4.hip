@@ -19,10 +19,10 @@ namespace hfem {
 constexpr int kBlockQ = 256;
 
 int g_quad4_stagger_groups = 2;
-// Phase offset of half the resident workgroups (those with bit `shift` of the launch index set), in 10 ns ticks.
-// -1 (auto): 2 us when the launch has at least 1.5 rounds of tiles, else none.  Measured on Q1M (2031 tiles, 1024
-// resident): 30.0 us without, 27.2 us with -- the delayed half gathers while the other half is in its fp64 stage.
-int g_quad4_stagger = -1, g_quad4_stagger_shift = 8;
+// Lab: phase offset of groups of resident workgroups (bit `shift` of the launch index upward), in 10 ns ticks;
+// -1 = 2 us when the launch has at least 1.5 rounds of tiles.  On a warm chip it changes nothing on Q1M (27.8 us
+// with and without; the gain first read on a cold chip was clock ramp), so the default is off.
+int g_quad4_stagger = 0, g_quad4_stagger_shift = 8;
 int g_quad4_ablate = 0;   // lab only: bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
 
 struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1

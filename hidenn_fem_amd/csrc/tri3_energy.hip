@@ -233,7 +233,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
     const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
-    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges,
+    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges, int stagger_ticks, int stagger_cfg,
     unsigned long long *__restrict__ stamps) {
 #define HFEM_FSTAMP(I)                                                                             \
     if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
@@ -247,6 +247,14 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
 
     const int tid = threadIdx.x;
     const int slot = xcd_tile(blockIdx.x, gridDim.x);
+    // lab (hfem_set_option("fast_stagger")): phase offset between groups of co-resident workgroups, so that one
+    // group gathers while another is in its element stage.  stagger_cfg = bit | (groups - 1) << 8.
+    if (stagger_ticks > 0) {
+        const int grp = (blockIdx.x >> (stagger_cfg & 31)) & (stagger_cfg >> 8);
+        const long long wait = (long long)stagger_ticks * grp / (stagger_cfg >> 8);
+        const long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz: 10 ns ticks
+        while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
+    }
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
     if (STAMP && threadIdx.x == 0 && n_owned >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -604,6 +612,11 @@ static int g_plan_node_cap = -1; // max distinct nodes among a tile's own elemen
 static int g_store_policy = 16;  // gradient stores of the fast kernel: 16 = sc1 (write-through: the line is dropped from
                                  // the XCD's L2 and does not evict the re-read inputs / plan arrays), 0 = plain
 static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
+// Lab: phase offset between groups of co-resident workgroups of the fast kernel (group = bits [shift, shift+log2
+// groups) of the launch index; group g starts g/(groups-1) * ticks later), in 10 ns ticks; -1 = 1.5 us when the
+// launch fills the chip.  Measured on a warm chip (bench.py A/B, T1M): 11.25 us without, 11.3 us with -- no gain
+// for TRI3 (its element stage is short), so the default is off.  (The tiled QUAD4 kernel does gain, quad4.hip.)
+static int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
 static int grid_for(int64_t n, int cap = 256 * 8) {
@@ -826,6 +839,8 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, g_tiled_stagger,         \
                        g_tiled_stagger_mode, plan->d_stamps)
         const int abl = g_tiled_ablate;
+        const int fast_stagger_cfg = g_fast_stagger_shift | ((g_fast_stagger_groups - 1) << 8);
+        const int fast_stagger = g_fast_stagger >= 0 ? g_fast_stagger : (n >= 768 ? 150 : 0);
         bool fast = false;
         if (abl == 64 && g_tiled_fast && g_tiled_block == 512 && plan->host.max_nodes <= 1024 &&
             plan->host.max_elems <= 2048) {      // lab: stamped instance of the production kernel
@@ -835,7 +850,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                                (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
                                make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
                                (double2 *)gx_free, (double2 *)gu_free, h.max_nodes, h.max_owned,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps);
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps);
             fast = true;
         }
         if (abl == 0 && g_tiled_fast) {
@@ -849,7 +864,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
 #define HFEM_LAUNCH_FAST(BLK, NPT, EPT, HB)                                                                 \
     hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
@@ -857,7 +872,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
 #define HFEM_FAST_HB(BLK, NPT, EPT)                                                   \
     {                                                                                 \
         if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true);                              \
@@ -866,7 +881,9 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         fast = true;                                                                  \
     }
             const int blk = g_tiled_block;
-            if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
+            if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_FAST_HB(512, 1, 2)
+            else if (blk == 256 && h.max_nodes <= 2 * 256 && h.max_elems <= 4 * 256) HFEM_FAST_HB(256, 2, 4)
+            else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
             else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) HFEM_FAST_HB(512, 2, 4)
             else if (blk == 256 && h.max_nodes <= 4 * 256 && h.max_elems <= 6 * 256) HFEM_FAST_HB(256, 4, 6)
             else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_FAST_HB(1024, 1, 2)
@@ -940,6 +957,15 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "tiled_stagger") {
         HFEM_ARG_CHECK(value >= 0 && value <= 100000, "tiled_stagger is in 10 ns ticks, 0..100000");
         g_tiled_stagger = value;
+    } else if (n == "fast_stagger") {
+        HFEM_ARG_CHECK(value >= -1 && value <= 100000, "fast_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
+        g_fast_stagger = value;
+    } else if (n == "fast_stagger_shift") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 20, "fast_stagger_shift: bit of the workgroup index, 0..20");
+        g_fast_stagger_shift = value;
+    } else if (n == "fast_stagger_groups") {
+        HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "fast_stagger_groups: 2, 4 or 8");
+        g_fast_stagger_groups = value;
     } else if (n == "tiled_stagger_mode") {
         g_tiled_stagger_mode = value;
     } else if (n == "plan_node_cap") {
@@ -978,6 +1004,8 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "store_policy") return g_store_policy;
     if (n == "plan_node_cap") return g_plan_node_cap;
     if (n == "tiled_stagger") return g_tiled_stagger;
+    if (n == "fast_stagger") return g_fast_stagger;
+    if (n == "quad4_stagger") return g_quad4_stagger;
     if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
     return -1;
 }

@@ -34,6 +34,10 @@ def main():
     ap.add_argument("--pipes", default="0")
     ap.add_argument("--staggers", default="0", help="total start spread in 10 ns ticks")
     ap.add_argument("--smodes", default="0")
+    ap.add_argument("--fstaggers", default="0", help="fast kernel: phase offset in 10 ns ticks")
+    ap.add_argument("--fshifts", default="8")
+    ap.add_argument("--fgroups", default="2")
+    ap.add_argument("--prewarm", type=float, default=0.3, help="seconds of untimed replays before each timing")
     ap.add_argument("--fast", default="1")
     ap.add_argument("--curve", type=int, default=1)
     ap.add_argument("--caps", default="0")
@@ -78,10 +82,16 @@ def main():
                                                gx.data_ptr(), gu.data_ptr(), flags, stream))
 
         for B in [int(b) for b in a.blocks.split(",")]:
-            for abl, pipe, stg, smode, sp in [(int(x), int(q), int(g_), int(m_), int(s_)) for x in a.ablate.split(",")
-                                              for q in a.pipes.split(",") for g_ in a.staggers.split(",")
-                                              for m_ in a.smodes.split(",") for s_ in a.stores.split(",")]:
+            for abl, pipe, stg, smode, sp, fst, fsh, fgr in [
+                    (int(x), int(q), int(g_), int(m_), int(s_), int(f1), int(f2), int(f3)) for x in a.ablate.split(",")
+                    for q in a.pipes.split(",") for g_ in a.staggers.split(",") for m_ in a.smodes.split(",")
+                    for s_ in a.stores.split(",") for f1 in a.fstaggers.split(",")
+                    for f2 in (a.fshifts.split(",") if int(f1) else ["8"])
+                    for f3 in (a.fgroups.split(",") if int(f1) else ["2"])]:
                 _lib.check(L.hfem_set_option(b"store_policy", sp))
+                _lib.check(L.hfem_set_option(b"fast_stagger", fst))
+                _lib.check(L.hfem_set_option(b"fast_stagger_shift", fsh))
+                _lib.check(L.hfem_set_option(b"fast_stagger_groups", fgr))
                 if pipe and (abl or stg):
                     continue
                 if stg == 0 and smode != int(a.smodes.split(",")[0]):
@@ -114,8 +124,11 @@ def main():
                     with torch.cuda.graph(g):
                         for _ in range(a.reps):
                             body()
-                    g.replay()
-                    torch.cuda.synchronize()
+                    import time as _t
+                    t_pw = _t.perf_counter()              # warm clocks: a cold chip reads 5-7 % slow
+                    while _t.perf_counter() - t_pw < a.prewarm:
+                        g.replay()
+                        torch.cuda.synchronize()
                     b_ = 1e9
                     for _ in range(5):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,7 +154,7 @@ def main():
                 else:
                     best = timed(energy)
                 st = plan.stats
-                row = dict(T=T, cap=cap, curve=a.curve, order=order, fast=fastv, tiles=st["n_tiles"], lds=st["lds_bytes"], block=B, store=sp, pipe=pipe, stagger=stg, smode=smode, ablate=abl, us=round(best, 2),
+                row = dict(T=T, cap=cap, curve=a.curve, order=order, fast=fastv, tiles=st["n_tiles"], lds=st["lds_bytes"], block=B, store=sp, pipe=pipe, stagger=stg, smode=smode, fstagger=fst, fshift=fsh, fgroups=fgr, ablate=abl, us=round(best, 2),
                            GBs=round(alg / best / 1e3, 1), frac=round(alg / best / 1e3 / 8000, 3), check=ok)
                 rows.append(row)
                 print(json.dumps(row), flush=True)

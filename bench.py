@@ -130,10 +130,18 @@ def main():
     td = plan.export("tile_desc")
     ne_local_home = ne if world == 1 else None
 
-    def step():
+    if world > 1:
+        sh.setup_interfaces()
+
+    def step_dense():           # north-star literal: one all-reduce of [gX|gU|loss] (every rank gets everything)
         sh.evaluate_local()
-        if world > 1:
-            sh.exchange()
+        sh.exchange()
+
+    def step_owner():           # owner-sharded: gradient rows stay with their owner; ONE all_gather of the
+        sh.evaluate_owner()     # interface parameter rows + partial energies (what the next evaluation needs)
+        sh.exchange_halo()
+
+    step = sh.evaluate_local if world == 1 else step_owner
 
     def sync_all():
         if world > 1:
@@ -143,8 +151,14 @@ def main():
     # ---- correctness guard: the benchmarked path must produce the oracle's numbers
     step()
     torch.cuda.synchronize()
-    loss_v, gx_v, gu_v = sh._views(sh.recv if world > 1 else sh.send)
-    loss_gpu = loss_v.item()
+    if world == 1:
+        loss_gpu = sh._views(sh.send)[0].item()
+    else:                       # the two independent exchange paths must agree on the global energy
+        loss_gpu = sh.loss_global.item()
+        step_dense()
+        torch.cuda.synchronize()
+        loss_dense = sh._views(sh.recv)[0].item()
+        assert abs(loss_gpu - loss_dense) <= 1e-12 * abs(loss_dense), (loss_gpu, loss_dense)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier+synchronize
     use_graph = (world == 1) and not a.no_graph
@@ -197,25 +211,22 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
-    # ---- N > 1 only, reported beside the headline: owner-sharded exchange (scalar loss all-reduce only;
-    #      each rank keeps the complete gradient rows of its own nodes -- what a node-sharded optimiser needs)
+    # ---- N > 1 only, reported beside the headline: the north-star's literal exchange, a dense all-reduce of the
+    #      full gradient + loss (every rank ends with everything; 16 B x 2 x nodes x N on the wire)
     alt = None
     if world > 1:
-        def step_owner():
-            sh.evaluate_local()
-            sh.exchange_loss_only()
         for _ in range(a.warmup):
-            step_owner()
+            step_dense()
         sync_all()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            step_owner()
+            step_dense()
         sync_all()
         el2 = time.perf_counter() - t0
         t = torch.tensor([el2], dtype=f64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el2 = t.item()
-        alt = dict(mode="owner-sharded: all_reduce(loss) only, gradient rows stay with their owner rank",
+        alt = dict(mode=f"dense: all_reduce([gX|gU|loss]) fp64, {sh.send.numel() * 8} B per rank, backend {a.backend}",
                    value=ne / (el2 / a.steps), ms_per_step=el2 / a.steps * 1e3)
 
     # ---- roofline leg: the dominant kernel alone, K back-to-back launches, HIP events on its stream
@@ -315,7 +326,10 @@ def main():
                         elements=ne, nodes=nn, elements_per_gpu=ne // world, tiles=st["n_tiles"],
                         tile_elems=st["tile_elems"], halo_elem_factor=st["tile_elem_total"] / max(ne, 1),
                         lds_bytes=st["lds_bytes"], launch="hipgraph" if graph is not None else "eager",
-                        exchange="none" if world == 1 else f"all_reduce(gX|gU|loss) fp64 dense, backend {a.backend}",
+                        exchange="none" if world == 1 else
+                        f"owner-sharded: gradient rows stay with the rank whose tiles own the node; one all_gather per "
+                        f"step of interface parameter rows + partial energy ({sh.interface_stats['payload_bytes']} B "
+                        f"per rank), backend {a.backend}",
                         loss=loss_gpu),
             roofline=roofline,
         )

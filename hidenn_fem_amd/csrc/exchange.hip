@@ -1,0 +1,70 @@
+// Interface exchange of the owner-sharded multi-GPU mode (the reference has no
+// distributed code).  Elements are sharded by contiguous tile ranges; owner-computes tiles with halo
+// recompute give every rank COMPLETE gradient rows for the nodes its tiles own, so gradients never cross
+// ranks.  What does cross, once per step, is (a) each rank's partial energy and (b) the parameter rows
+// (x, u) of the nodes a rank owns that other ranks' tiles read as halo -- O(sqrt(elements per rank)) rows.
+// Both travel in ONE all_gather of a fixed-size payload per rank:
+//     [ x rows of my interface | u rows of my interface | padding ]  [ loss partial, 0 ]      (double2 units)
+// iface_pack fills the payload from the local parameters (the energy kernel writes the loss slot itself),
+// iface_unpack copies the rows this rank needs out of the gathered payloads into its local parameter
+// arrays and adds the partial energies in rank order (deterministic).  Pure data movement, a few KB..MB.
+#include <hip/hip_runtime.h>
+
+#include "hfem_device.h"
+
+namespace hfem {
+
+__global__ __launch_bounds__(256) void iface_pack_kernel(const double2 *__restrict__ x_free,
+                                                         const double2 *__restrict__ u_free,
+                                                         const int32_t *__restrict__ rows, int n_x, int n_u,
+                                                         double2 *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_x) out[i] = x_free[rows[i]];
+    else if (i < n_x + n_u) out[i] = u_free[rows[i]];
+}
+
+__global__ __launch_bounds__(256) void iface_unpack_kernel(const double2 *__restrict__ recv,
+                                                           const int32_t *__restrict__ src,
+                                                           const int32_t *__restrict__ dst, int n_x, int n_u,
+                                                           double2 *__restrict__ x_free, double2 *__restrict__ u_free,
+                                                           int world, int64_t stride, int64_t loss_slot,
+                                                           double *__restrict__ loss_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_x) x_free[dst[i]] = recv[src[i]];
+    else if (i < n_x + n_u) u_free[dst[i]] = recv[src[i]];
+    if (i == 0 && loss_out) {
+        double tot = 0.0;
+        for (int r = 0; r < world; ++r) tot += recv[(int64_t)r * stride + loss_slot].x;   // fixed order
+        loss_out[0] = tot;
+    }
+}
+
+}  // namespace hfem
+
+using namespace hfem;
+
+extern "C" int hfem_iface_pack(int device, const double *x_free, const double *u_free, const int32_t *rows,
+                               int32_t n_x, int32_t n_u, double *out, void *stream) {
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0, "negative row count");
+    if (n_x + n_u == 0) return 0;
+    HFEM_ARG_CHECK(rows && out && (n_x == 0 || x_free) && (n_u == 0 || u_free), "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(iface_pack_kernel, dim3((n_x + n_u + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const double2 *)x_free, (const double2 *)u_free, rows, n_x, n_u, (double2 *)out);
+    return launch_status("hfem_iface_pack");
+}
+
+extern "C" int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const int32_t *dst, int32_t n_x,
+                                 int32_t n_u, double *x_free, double *u_free, int32_t world, int64_t stride,
+                                 int64_t loss_slot, double *loss_out, void *stream) {
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && world >= 1 && stride >= 1 && loss_slot >= 0 && loss_slot < stride,
+                   "bad sizes");
+    HFEM_ARG_CHECK(recv && (n_x + n_u == 0 || (src && dst)) && (n_x == 0 || x_free) && (n_u == 0 || u_free),
+                   "null pointer");
+    if (int rc = use_device(device)) return rc;
+    const int n = n_x + n_u > 0 ? n_x + n_u : 1;
+    hipLaunchKernelGGL(iface_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const double2 *)recv, src, dst, n_x, n_u, (double2 *)x_free, (double2 *)u_free, world, stride,
+                       loss_slot, loss_out);
+    return launch_status("hfem_iface_unpack");
+}

@@ -14,12 +14,21 @@ and the gradients are sums of per-element contributions, so:
 
 Rows a rank does not own stay zero in its send buffer (the kernel never writes them),
 so the reduction is exact: each row has exactly one non-zero contributor.
+
+Owner-sharded mode (``exchange_halo``).  Because tiles are owner-computes with halo
+recompute, the gradient rows a rank produces for the nodes its tiles own are already complete:
+gradients never need to cross ranks.  A node-sharded optimiser updates exactly those rows; what the
+next evaluation then needs from the other ranks is the *parameter* rows of their interface nodes
+(the nodes one rank owns and another rank's tiles read as halo -- O(sqrt(elements per rank)) rows)
+and the partial energies.  Both travel in ONE ``all_gather`` of a small fixed-size payload per rank
+(``csrc/exchange.hip``), instead of an all-reduce of the full gradient (16 B x 2 x nodes x ranks).
 """
 from __future__ import annotations
 
 import ctypes as C
 from typing import Callable, Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -35,10 +44,13 @@ class ShardedTri3Energy:
     collective) can be exercised by the multi-process CPU tests with the oracle standing in
     for the kernel."""
 
-    def __init__(self, model, loss_fn, group=None, evaluate: Optional[Callable] = None, plan=None):
+    def __init__(self, model, loss_fn, group=None, evaluate: Optional[Callable] = None, plan=None,
+                 rank: Optional[int] = None, world: Optional[int] = None):
         self.model, self.loss_fn, self.group = model, loss_fn, group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if rank is not None and world is not None:      # planning / single-process tests: act as rank of world
+            self.rank, self.world = rank, world
         self.plan = plan if plan is not None else model.tile_plan(loss_fn.tile_elems)
         self.lo, self.hi = self.plan.shard_range(self.rank, self.world)
         self._evaluate = evaluate or self._evaluate_hip
@@ -56,18 +68,19 @@ class ShardedTri3Energy:
     def _evaluate_hip(self, lo, hi, loss_v, gx_v, gu_v):
         m, lf = self.model, self.loss_fn
         dev = m.node_coords_free.device
-        T_edge, Tconst = lf._traction(m, None)
-        dv = lambda a: (C.c_double * len(a))(*a)
-        xf = m.node_coords_free.detach()
-        uf = m.u_free.detach()
-        if xf.dtype != F64 or uf.dtype != F64:
-            raise RuntimeError("sharded evaluation needs an fp64 model (model.double())")
-        xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()      # cached by the model: no per-step allocation
-        rc = _lib.lib().hfem_tri3_energy_plan(
-            self.plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),
-            ufix.data_ptr() if ufix.numel() else None, dv(lf._mat), lf._W, dv(lf._body_table(None)), None,
-            dv(Tconst), int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), 0,
-            _lib.stream_ptr(dev))
+        c = getattr(self, "_consts", None)
+        if c is None:                                   # per-step host work is pointer reads only
+            if m.node_coords_free.dtype != F64 or m.u_free.dtype != F64:
+                raise RuntimeError("sharded evaluation needs an fp64 model (model.double())")
+            _, Tconst = lf._traction(m, None)
+            dv = lambda a: (C.c_double * len(a))(*a)
+            xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()  # cached by the model: no per-step allocation
+            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst),
+                                xfix.data_ptr() if xfix.numel() else None, ufix.data_ptr() if ufix.numel() else None,
+                                (xfix, ufix), _lib.lib().hfem_tri3_energy_plan)
+        mat, W, Bk, Tc, pxfix, pufix, _, fn = c
+        rc = fn(self.plan.handle, m.node_coords_free.data_ptr(), pxfix, m.u_free.data_ptr(), pufix, mat, W, Bk, None,
+                Tc, int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), 0, _lib.stream_ptr(dev))
         _lib.check(rc, "hfem_tri3_energy_plan")
 
     def evaluate_local(self):
@@ -96,6 +109,107 @@ class ShardedTri3Energy:
         if self.world > 1:
             dist.all_reduce(self._loss_red, op=dist.ReduceOp.SUM, group=self.group)
         return self._loss_red[0], gx_v, gu_v
+
+    # ------------------------------------------------------------------ owner-sharded mode
+    def setup_interfaces(self, pack_unpack=None):
+        """Host-side, once: which parameter rows this rank must publish (rows its tiles own that other ranks'
+        tiles read) and which published rows it must copy in (rows its tiles read that another rank owns).
+        Every rank derives the same tables from the shared plan -- no communication.  ``pack_unpack`` is the
+        test seam for the CPU multi-process tests (torch indexing standing in for csrc/exchange.hip)."""
+        plan, world = self.plan, self.world
+        td, ns = plan.export("tile_desc").astype(np.int64), plan.export("node_src").astype(np.int64)
+        n_tiles = td.shape[0]
+        bounds = np.array([plan.shard_range(r, world)[0] for r in range(world)] + [n_tiles], dtype=np.int64)
+        tile_rank = np.searchsorted(bounds, np.arange(n_tiles), side="right") - 1
+        if not np.array_equal(td[:, 2], np.concatenate([[0], np.cumsum(td[:, 3])[:-1]])):
+            raise RuntimeError("tile plan: node slots are not laid out tile after tile")
+        slot_tile = np.repeat(np.arange(n_tiles), td[:, 3])                      # tile of every node slot
+        slot_local = np.arange(ns.shape[0]) - np.repeat(td[:, 2], td[:, 3])
+        slot_owned = slot_local < td[slot_tile, 4]
+        slot_rank = tile_rank[slot_tile]
+        publish, need = [], []                      # per array (x, u): publish[r] rows, need = (rows, owner rank)
+        for col, nrows in ((0, self._nx // 2), (1, self._nu // 2)):
+            rows = ns[:, col]
+            free = rows >= 0
+            owner = np.full(nrows, -1, dtype=np.int64)
+            owner[rows[free & slot_owned]] = slot_rank[free & slot_owned]
+            foreign = free & ~slot_owned
+            foreign[foreign] = owner[rows[foreign]] != slot_rank[foreign]        # read here, owned by another rank
+            pairs = np.unique(np.stack([slot_rank[foreign], rows[foreign]], axis=1), axis=0)   # (reader, row)
+            pub_rows = np.unique(pairs[:, 1]) if len(pairs) else np.zeros(0, dtype=np.int64)
+            publish.append([pub_rows[owner[pub_rows] == r] for r in range(world)])             # sorted per owner
+            mine = pairs[pairs[:, 0] == self.rank, 1] if len(pairs) else np.zeros(0, dtype=np.int64)
+            need.append((mine, owner[mine]))
+        n_pub = np.array([[len(publish[c][r]) for r in range(world)] for c in (0, 1)])         # [2, world]
+        self.iface_rows = int((n_pub[0] + n_pub[1]).max()) if world > 1 else 0
+        self.iface_stride = self.iface_rows + 1                                  # double2 units; last = [loss, 0]
+        dev = self.send.device
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        r = self.rank
+        self._pub_rows = i32(np.concatenate([publish[0][r], publish[1][r]]))
+        self._pub_n = (len(publish[0][r]), len(publish[1][r]))
+        src, dst = [], []
+        for c in (0, 1):
+            rows, own = need[c]
+            pos = np.zeros(len(rows), dtype=np.int64)
+            for s_ in range(world):
+                sel = own == s_
+                pos[sel] = s_ * self.iface_stride + (n_pub[0][s_] if c == 1 else 0) + np.searchsorted(publish[c][s_], rows[sel])
+            src.append(pos)
+            dst.append(rows)
+        self._need_n = (len(dst[0]), len(dst[1]))
+        self._need_src, self._need_dst = i32(np.concatenate(src)), i32(np.concatenate(dst))
+        self.payload = torch.zeros(self.iface_stride, 2, dtype=F64, device=dev)
+        self.gathered = torch.zeros(world * self.iface_stride, 2, dtype=F64, device=dev)
+        self.loss_global = torch.zeros((), dtype=F64, device=dev)
+        self._pack, self._unpack = pack_unpack or (self._pack_hip, self._unpack_hip)
+        self.interface_stats = dict(publish_x=int(n_pub[0][r]), publish_u=int(n_pub[1][r]), need_x=self._need_n[0],
+                                    need_u=self._need_n[1], payload_bytes=int(self.iface_stride * 16))
+        return self
+
+    def _pack_hip(self):
+        m, dev = self.model, self.send.device
+        _lib.check(_lib.lib().hfem_iface_pack(_lib.dev_index(dev), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
+                                              self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1],
+                                              self.payload.data_ptr(), _lib.stream_ptr(dev)), "hfem_iface_pack")
+
+    def _unpack_hip(self):
+        m, dev = self.model, self.send.device
+        _lib.check(_lib.lib().hfem_iface_unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(),
+                                                self._need_dst.data_ptr(), self._need_n[0], self._need_n[1],
+                                                m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.world,
+                                                self.iface_stride, self.iface_rows, self.loss_global.data_ptr(),
+                                                _lib.stream_ptr(dev)), "hfem_iface_unpack")
+
+    def evaluate_owner(self):
+        """Kernel over this rank's tiles: gradient rows of the owned nodes into the local (send) buffer, the
+        partial energy straight into the payload's loss slot."""
+        _, gx_v, gu_v = self._views(self.send)
+        self._evaluate(self.lo, self.hi, self.payload[self.iface_rows, 0:1], gx_v, gu_v)
+
+    def exchange_halo(self):
+        """ONE all_gather per step: publish my interface parameter rows + my partial energy, copy in the
+        interface rows my tiles read, sum the partial energies in rank order.  Call after the optimiser has
+        updated the owned rows (and once before the first evaluation if ranks do not start from identical
+        parameters).  Returns (global loss, local gx view, local gu view)."""
+        _, gx_v, gu_v = self._views(self.send)
+        self._pack()
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
+        else:
+            self.gathered.copy_(self.payload)
+        self._unpack()
+        return self.loss_global, gx_v, gu_v
+
+    def owned_rows(self):
+        """(x rows, u rows) of node_coords_free / u_free that this rank's tiles own (int64 tensors)."""
+        td, ns = self.plan.export("tile_desc").astype(np.int64), self.plan.export("node_src").astype(np.int64)
+        out = []
+        for col in (0, 1):
+            rows = [ns[no:no + nown, col] for (_, _, no, _, nown, _, _, _) in td[self.lo:self.hi]]
+            rows = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+            out.append(torch.from_numpy(np.unique(rows[rows >= 0])).to(self.send.device))
+        return tuple(out)
 
     def value_and_grad(self):
         """One sharded fwd+bwd pass -> (loss, d/d node_coords_free, d/d u_free), identical on all ranks."""

@@ -197,6 +197,19 @@ int hfem_scatter_rows(int device, const double *src, const int32_t *idx, int64_t
 int hfem_gather_rows(int device, const double *src, const int32_t *idx, int64_t rows,
                      int32_t width, double *dst, void *stream);
 
+/* ------------------------------------------------------------------ multi-GPU interface exchange
+ * Owner-sharded mode (no reference counterpart): one all_gather per step of a fixed-size
+ * payload per rank, in double2 units:  [x rows | u rows | padding][loss partial, 0].
+ * hfem_iface_pack: out[i] = x_free[rows[i]] (i < n_x), u_free[rows[i]] (n_x <= i < n_x + n_u).
+ * hfem_iface_unpack: x_free[dst[i]] = recv[src[i]] (i < n_x), u_free[dst[i]] = recv[src[i]] (next n_u);
+ * src indexes the gathered buffer (world payloads of `stride` double2 each); loss_out (may be NULL)
+ * = sum over ranks, in rank order, of recv[r * stride + loss_slot].x.                               */
+int hfem_iface_pack(int device, const double *x_free, const double *u_free, const int32_t *rows,
+                    int32_t n_x, int32_t n_u, double *out, void *stream);
+int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const int32_t *dst, int32_t n_x,
+                      int32_t n_u, double *x_free, double *u_free, int32_t world, int64_t stride,
+                      int64_t loss_slot, double *loss_out, void *stream);
+
 /* ------------------------------------------------------------------ 1D / structured
  * Grid parametrisation softplus -> clamp(1e-6) -> cumsum -> renormalise
  * (src/models.py:45-56, 146-168): p[n] -> grid[n+1]; backward ggrid[n+1] -> gp[n].

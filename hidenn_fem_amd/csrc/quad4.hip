@@ -330,7 +330,6 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
         }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
-    if (tid == 0) red[0] = 0.0;
     HFEM_QSTAMP(2)
     __syncthreads();
     HFEM_QSTAMP(3)
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     }
     {
         const double w = wave_sum(e_loc);
-        if ((tid & 63) == 0) unsafeAtomicAdd(&red[0], w);
+        if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
     }
     HFEM_QSTAMP(4)
     __syncthreads();
@@ -413,7 +412,12 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
             }
         }
     }
-    if (tid == 0) partials[slot] = red[0];
+    if (tid == 0) {                                     // fixed order: the tile energy is bit-reproducible
+        double tile_e = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
+        partials[slot] = tile_e;
+    }
     HFEM_QSTAMP(6)
     if (ABL & 4) {
         __builtin_amdgcn_s_waitcnt(0);

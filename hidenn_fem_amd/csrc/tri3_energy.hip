@@ -286,7 +286,6 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
-    if (tid == 0) red[0] = 0.0;
     HFEM_FSTAMP(2)
     __syncthreads();
     HFEM_FSTAMP(3)
@@ -334,10 +333,10 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
             unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
         }
     }
-    // tile energy: wave shuffle reduction, one LDS atomic per wave -- rides on the barrier below
+    // tile energy: wave shuffle reduction, one LDS slot per wave -- rides on the barrier below
     {
         const double w = wave_sum(e_loc);
-        if ((tid & 63) == 0) unsafeAtomicAdd(&red[0], w);
+        if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
     }
     HFEM_FSTAMP(4)
     __syncthreads();
@@ -373,7 +372,12 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         }
     }
     HFEM_FSTAMP(6)
-    if (tid == 0) partials[slot] = red[0];
+    if (tid == 0) {                                     // fixed order: the tile energy is bit-reproducible
+        double tile_e = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
+        partials[slot] = tile_e;
+    }
     HFEM_FSTAMP(7)
 #undef HFEM_FSTAMP
 }
@@ -932,6 +936,22 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
     return launch_status("hfem_tri3_energy_plan(sum)");
+}
+
+// Sum, in tile order, of the per-tile partial energies a launch with HFEM_FLAG_NO_LOSS_SUM left in the plan
+// (what the energy entry points do themselves unless that flag is set): for gradient-driven callers that
+// want the scalar only now and then.
+extern "C" int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, double *loss_out,
+                                  void *stream) {
+    HFEM_ARG_CHECK(plan && loss_out, "null pointer");
+    HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    const int32_t nt = (int32_t)plan->host.tiles.size();
+    if (tile_end < 0) tile_end = nt;
+    HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
+    if (int rc = use_device(plan->device)) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       plan->d_partials + tile_begin, tile_end - tile_begin, loss_out);
+    return launch_status("hfem_plan_loss_sum");
 }
 
 extern "C" int hfem_set_option(const char *name, int value) {

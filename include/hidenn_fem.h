@@ -126,6 +126,9 @@ int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, const double *x
                           const double *T_edge, const double Tconst[4],
                           int32_t tile_begin, int32_t tile_end, double *loss_out,
                           double *gx_free, double *gu_free, int32_t flags, void *stream);
+/* loss_out[0] = sum, in tile order, of the per-tile partial energies that a launch with
+ * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
+int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, double *loss_out, void *stream);
 
 /* Process-wide tuning knobs of the tiled kernel: "tiled_block" (threads per tile: 256, 512,
  * 1024) and "tiled_ablate" (lab-only ablation bits, 0 in production; see tri3_energy.hip).

@@ -69,3 +69,47 @@ def test_two_emulated_ranks_match_unsharded_step():
     other = ranks[1][0]
     halo_rows = ranks[0][1]._need_dst[:ranks[0][1]._need_n[0]].long()
     assert torch.equal(ranks[0][0].node_coords_free[halo_rows], other.node_coords_free[halo_rows])
+
+
+@pytest.mark.gpu
+def test_loss_is_bit_reproducible_and_deferred_sum_matches():
+    """The energy is summed in fixed order at every level (lanes by shuffle tree, waves in wave order, tiles in tile
+    order): two launches on the same inputs give the same bits.  HFEM_FLAG_NO_LOSS_SUM + hfem_plan_loss_sum is the
+    same sum, deferred (also on a tile sub-range)."""
+    import ctypes as C
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(401, 251, jitter=0.2, seed=4, dtype=F64)
+    torch.manual_seed(1)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    with torch.no_grad():
+        m.u_free.mul_(100.0)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    plan = m.tile_plan(lf.tile_elems)
+    L = _lib.lib()
+    dv = lambda v: (C.c_double * len(v))(*v)
+    _, Tconst = lf._traction(m, None)
+    xf, uf, xfix, ufix = m.node_coords_free.detach(), m.u_free.detach(), m.node_coords_fixed, m.u_fixed_rows()
+    gx, gu = torch.empty_like(xf), torch.empty_like(uf)
+    out = torch.zeros(8, dtype=F64, device=d)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(slot, lo, hi, flags):
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr(), uf.data_ptr(), ufix.data_ptr(),
+                                           dv(lf._mat), lf._W, dv([0.0] * 6), None, dv(Tconst), lo, hi,
+                                           out[slot:slot + 1].data_ptr(), gx.data_ptr(), gu.data_ptr(), flags, st))
+
+    nt = plan.n_tiles
+    for rep in range(20):
+        run(0, 0, -1, 0)
+        run(1, 0, -1, 0)
+        run(2, 0, -1, 8)                                   # NO_LOSS_SUM: out[2] untouched ...
+        _lib.check(L.hfem_plan_loss_sum(plan.handle, 0, -1, out[3:4].data_ptr(), st))
+        run(4, 5, nt - 9, 0)
+        run(5, 5, nt - 9, 8)
+        _lib.check(L.hfem_plan_loss_sum(plan.handle, 5, nt - 9, out[6:7].data_ptr(), st))
+        o = out.tolist()
+        assert o[0] == o[1] == o[3] and o[2] == 0.0 and o[4] == o[6] and o[5] == 0.0 and o[4] != o[0]

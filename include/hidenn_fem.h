@@ -200,6 +200,17 @@ int hfem_scatter_rows(int device, const double *src, const int32_t *idx, int64_t
 int hfem_gather_rows(int device, const double *src, const int32_t *idx, int64_t rows,
                      int32_t width, double *dst, void *stream);
 
+/* ------------------------------------------------------------------ post-processing
+ * hfem_tri3_von_mises: per element, grad_u at the centroid (constant on a P1 triangle; reference
+ * convention, src/models.py:351-355) -> strain -> plane-stress stress -> von Mises, exactly the chain of
+ * src/plots.py:183-198 (sigma_xy = E/(1+nu) eps_xy).  von_mises[Ne]; grad_u[Ne][2][2] optional (NULL).
+ * hfem_line2_slopes: out[i][c] = (u[i+1][c] - u[i][c]) / (grid[i+1] - grid[i]), i < n_nodes - 1: the
+ * per-element du/dx that src/plots.py:5-27 obtains with one autograd call per element.               */
+int hfem_tri3_von_mises(int device, const double *X, const double *U, const int32_t *conn, int64_t ne,
+                        double E, double nu, double *von_mises, double *grad_u, void *stream);
+int hfem_line2_slopes(int device, const double *grid, const double *u, int64_t n_nodes, int32_t dim_u,
+                      double *out, void *stream);
+
 /* ------------------------------------------------------------------ multi-GPU interface exchange
  * Owner-sharded mode (no reference counterpart): one all_gather per step of a fixed-size
  * payload per rank, in double2 units:  [x rows | u rows | padding][loss partial, 0].

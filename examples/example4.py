@@ -11,7 +11,7 @@ from src.mesh import generate_mesh
 from src.models import PiecewiseLinearShapeNN2D
 
 
-def run(nx=200, ny=100, steps=30, dtype=torch.float32, log_every=5):
+def run(nx=200, ny=100, steps=30, dtype=torch.float32, log_every=5, fused_lbfgs=False):
     dev = torch.device("cuda")
     length, height = 2.0, 1.0
     holes = [(0.5, 0.7, 0.12), (1.0, 0.3, 0.15), (1.4, 0.6, 0.1)]
@@ -22,7 +22,11 @@ def run(nx=200, ny=100, steps=30, dtype=torch.float32, log_every=5):
     model = PiecewiseLinearShapeNN2D(nodes.to(dtype), conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
                                      neumann_edges=edges).to(dev)
     loss_fn = EnergyLoss2D(E=10e9, nu=0.3, length=length, height=height, device=dev, dtype=dtype)
-    opt = torch.optim.LBFGS(model.parameters())
+    if fused_lbfgs:                      # same algorithm and defaults, device-resident (hidenn_fem_amd/optim.py)
+        from hidenn_fem_amd.optim import FusedLBFGS
+        opt = FusedLBFGS(model.parameters())
+    else:
+        opt = torch.optim.LBFGS(model.parameters())
     calls = [0]
 
     def closure():
@@ -32,11 +36,16 @@ def run(nx=200, ny=100, steps=30, dtype=torch.float32, log_every=5):
         calls[0] += 1
         return value
 
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for step in range(steps):
         value = opt.step(closure)
         if step % log_every == 0:
             print(f"Epoch {step:04d}: Loss = {value.item():.6e}")
-    print(f"{calls[0]} closure calls, final loss {value.item():.6e}")
+    torch.cuda.synchronize()
+    print(f"{calls[0]} closure calls, final loss {value.item():.6e}, {time.perf_counter() - t0:.3f} s "
+          f"({'FusedLBFGS' if fused_lbfgs else 'torch.optim.LBFGS'})")
     return model, value.item()
 
 
@@ -46,5 +55,6 @@ if __name__ == "__main__":
     ap.add_argument("--ny", type=int, default=100)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--fused-lbfgs", action="store_true")
     a = ap.parse_args()
-    run(a.nx, a.ny, a.steps, torch.float64 if a.fp64 else torch.float32)
+    run(a.nx, a.ny, a.steps, torch.float64 if a.fp64 else torch.float32, fused_lbfgs=a.fused_lbfgs)

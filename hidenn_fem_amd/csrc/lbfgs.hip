@@ -1,0 +1,509 @@
+// L-BFGS on the flat parameter vector, device-resident (the reference drives example 4
+// with torch.optim.LBFGS(model.parameters()) -- /root/reference/examples/example4.py:68-78 -- i.e. lr 1,
+// max_iter 20, history 100, no line search).  torch's step is ~4*history small vector ops plus ~6 host syncs
+// per inner iteration; once the energy is one 14 us launch that is the whole run time.
+//
+// Same algorithm (torch/optim/lbfgs.py: memory update if y.s > 1e-10, H_diag = y.s / y.y, two-loop recursion,
+// first step t = min(1, 1/|g|_1) lr, break tests), different evaluation order: the two-loop recursion only
+// ever needs inner products between g and the history vectors, so it is run in COEFFICIENT space.  With
+//   q = -g - sum_j al_j y_j,   r = H q + sum_j c_j s_j,   c_j = al_j - be_j
+//   al_i = ro_i ( -s_i.g - sum_{j newer} al_j s_i.y_j )
+//   be_i = ro_i ( H ( -y_i.g - sum_j al_j y_i.y_j ) + sum_{j older} c_j s_j.y_i )
+// only S^T g, Y^T g and the Gram blocks S^T Y, Y^T Y are needed.  Per iteration:
+//   pair_kernel        y = g - g_prev, s = t d into the spare ring slot (+ y.s, y.y partials)      [1 pass over N]
+//   multidot_kernel    ONE pass over the history: per slot j  Y_j.g, S_j.g and, for a new pair,
+//                      Y_j.s_new, Y_j.y_new, S_j.y_new (row/column of the Gram blocks)              [2m vectors read once]
+//   recursion_kernel   one workgroup: the two loops on (m+1)^2 Gram entries, gtd = g.d, t, break flag
+//   direction_kernel   ONE pass: d = -H g + sum_j (-H al_j) y_j + sum_j c_j s_j (+ max|d| partials) [2m vectors read once]
+// i.e. the history is streamed twice (the two-loop recursion also reads every vector twice) in 2 launches instead
+// of 4m, all scalars stay on the device, and the host reads one status record per iteration.  Dots accumulate in
+// fp64 for fp32 and fp64 vectors alike; every reduction has a fixed order (bit-reproducible).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+
+#include "hfem_device.h"
+
+namespace hfem {
+
+constexpr int kLb = 256;           // threads per block everywhere
+constexpr int kLbPer = 8;          // elements per thread per chunk
+constexpr int kLbChunk = kLb * kLbPer;
+
+struct LbfgsState {                // one record in device memory
+    int n_iter;                    // torch state["n_iter"]
+    int count, head;               // ring: logical i (0 = oldest) lives in slot (head + i) % M1, i < count
+    int new_slot;                  // slot of the pair accepted in this iteration, -1 if none
+    int stop_gtd;                  // g.d > -tolerance_change: no update this iteration
+    int pad;
+    double H_diag, t, gtd, cg;     // cg = -H_diag: coefficient of g in d
+    double loss, prev_loss;
+    double g_absmax, g_abssum, gg, d_absmax, ys, yy;
+    double flags;                  // bit 0 opt_cond, 1 small step, 2 small loss change, 3 gtd break  (check_kernel)
+};
+
+struct LbfgsArrays {               // device pointers, by value to kernels
+    LbfgsState *st;
+    double *ro, *al, *cy, *cs;     // [M1] per slot
+    double *dots;                  // [M1][5]: Y.g, S.g, Y.s_new, Y.y_new, S.y_new
+    double *SY, *YY;               // [M1][M1] by slot: SY[i][j] = s_i.y_j, YY[i][j] = y_i.y_j
+    double *part;                  // partial sums scratch
+};
+
+__device__ __forceinline__ double block_sum_all(double v, double *scratch) {   // result in every thread
+    const double r = block_sum(v, scratch);
+    __shared__ double bc;
+    if (threadIdx.x == 0) bc = r;
+    __syncthreads();
+    const double out = bc;
+    __syncthreads();
+    return out;
+}
+
+// ---- statistics of a gradient: max|g|, sum|g|, g.g  (partials per block: [nb][3])
+template <typename T>
+__global__ __launch_bounds__(kLb) void gstats_kernel(const T *__restrict__ g, int64_t n, double *__restrict__ part) {
+    __shared__ double red[kLb / 64];
+    double mx = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kLb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLb) {
+        const double v = (double)g[i], a = fabs(v);
+        mx = a > mx || a != a ? a : mx;          // NaN propagates
+        s1 += a;
+        s2 += v * v;
+    }
+    // max via sum trick is not possible: dedicated shuffle max
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    __shared__ double mred[kLb / 64];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    const double t1 = block_sum(s1, red);
+    __syncthreads();
+    const double t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        double m = mred[0];
+        for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        part[3 * blockIdx.x] = m;
+        part[3 * blockIdx.x + 1] = t1;
+        part[3 * blockIdx.x + 2] = t2;
+    }
+}
+
+// finalize the statistics and the break tests that follow a closure evaluation (torch lbfgs.py: opt_cond,
+// "lack of progress" tests); `loss` is a device scalar (may be null at the first evaluation of a step)
+__global__ __launch_bounds__(kLb) void check_kernel(LbfgsArrays A, int nb, const double *__restrict__ loss, int have_prev,
+                                                    double tol_grad, double tol_change, double *__restrict__ status) {
+    __shared__ double red[kLb / 64];
+    double mx = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kLb) {
+        const double m = A.part[3 * b];
+        mx = (m > mx || m != m) ? m : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    __shared__ double mred[kLb / 64];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    for (int b = threadIdx.x; b < nb; b += kLb) { s1 += A.part[3 * b + 1]; s2 += A.part[3 * b + 2]; }
+    const double t1 = block_sum(s1, red);
+    __syncthreads();
+    const double t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        double m = mred[0];
+        for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        LbfgsState &S = *A.st;
+        S.g_absmax = m; S.g_abssum = t1; S.gg = t2;
+        if (loss) S.loss = loss[0];
+        int f = 0;
+        if (m <= tol_grad) f |= 1;
+        if (have_prev) {
+            if (S.d_absmax * fabs(S.t) <= tol_change) f |= 2;
+            if (fabs(S.loss - S.prev_loss) < tol_change) f |= 4;
+            if (S.stop_gtd) f |= 8;
+        }
+        S.flags = (double)f;
+        status[0] = S.loss; status[1] = (double)f; status[2] = m; status[3] = S.gtd; status[4] = S.t;
+        status[5] = (double)S.count; status[6] = (double)S.n_iter; status[7] = S.H_diag;
+    }
+}
+
+// ---- y = g - g_prev, s = t d into the spare slot; g_prev = g; partials of y.s and y.y: [nb][2]
+template <typename T>
+__global__ __launch_bounds__(kLb) void pair_kernel(LbfgsArrays A, const T *__restrict__ g, T *__restrict__ g_prev,
+                                                   const T *__restrict__ d, T *__restrict__ Sring, T *__restrict__ Yring,
+                                                   int64_t n, int M1, int first) {
+    __shared__ double red[kLb / 64];
+    const LbfgsState &S = *A.st;
+    const int spare = (S.head + S.count) % M1;
+    const double t = S.t;
+    T *ys_ = Yring + (int64_t)spare * n, *ss_ = Sring + (int64_t)spare * n;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kLb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLb) {
+        const T gi = g[i];
+        if (!first) {
+            const T y = gi - g_prev[i];                     // flat_grad.sub(prev_flat_grad)
+            const T s = (T)((double)d[i] * t);              // d.mul(t)
+            ys_[i] = y; ss_[i] = s;
+            a += (double)y * (double)s;
+            b += (double)y * (double)y;
+        }
+        g_prev[i] = gi;
+    }
+    const double ta = block_sum(a, red);
+    __syncthreads();
+    const double tb = block_sum(b, red);
+    if (threadIdx.x == 0) { A.part[2 * blockIdx.x] = ta; A.part[2 * blockIdx.x + 1] = tb; }
+}
+
+// accept / reject the pair, advance the ring, n_iter, prev_loss (one block)
+__global__ __launch_bounds__(kLb) void pair_reduce_kernel(LbfgsArrays A, int nb, int M1, int first) {
+    __shared__ double red[kLb / 64];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nb; k += kLb) { a += A.part[2 * k]; b += A.part[2 * k + 1]; }
+    const double ys = block_sum(a, red);
+    __syncthreads();
+    const double yy = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        LbfgsState &S = *A.st;
+        S.n_iter += 1;
+        S.new_slot = -1;
+        if (first) { S.count = 0; S.head = 0; S.H_diag = 1.0; }
+        else {
+            S.ys = ys; S.yy = yy;
+            if (ys > 1e-10) {
+                const int m = M1 - 1, slot = (S.head + S.count) % M1;
+                if (S.count == m) S.head = (S.head + 1) % M1;    // drop the oldest: its slot becomes the spare
+                else S.count += 1;
+                A.ro[slot] = 1.0 / ys;
+                S.H_diag = ys / yy;
+                S.new_slot = slot;
+            }
+        }
+        S.prev_loss = S.loss;
+    }
+}
+
+// ---- one pass over the history: block b owns chunk b (kLbChunk elements); per active slot five dots
+template <typename T>
+__global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
+                                                       const T *__restrict__ Yring, int64_t n, int M1) {
+    __shared__ double red[5][kLb / 64];
+    const LbfgsState &S = *A.st;
+    const int count = S.count, head = S.head, ns = S.new_slot;
+    const int64_t base = (int64_t)blockIdx.x * kLbChunk + threadIdx.x;
+    double gv[kLbPer], sv[kLbPer], yv[kLbPer];
+#pragma unroll
+    for (int k = 0; k < kLbPer; ++k) {
+        const int64_t i = base + (int64_t)k * kLb;
+        gv[k] = i < n ? (double)g[i] : 0.0;
+        sv[k] = (ns >= 0 && i < n) ? (double)Sring[(int64_t)ns * n + i] : 0.0;
+        yv[k] = (ns >= 0 && i < n) ? (double)Yring[(int64_t)ns * n + i] : 0.0;
+    }
+    for (int l = 0; l < count; ++l) {
+        const int slot = (head + l) % M1;
+        const T *Yj = Yring + (int64_t)slot * n, *Sj = Sring + (int64_t)slot * n;
+        double acc[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < kLbPer; ++k) {
+            const int64_t i = base + (int64_t)k * kLb;
+            if (i < n) {
+                const double y = (double)Yj[i], s = (double)Sj[i];
+                acc[0] += y * gv[k]; acc[1] += s * gv[k];
+                acc[2] += y * sv[k]; acc[3] += y * yv[k]; acc[4] += s * yv[k];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const double w = wave_sum(acc[q]);
+            if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            double r = 0.0;
+            for (int w = 0; w < kLb / 64; ++w) r += red[threadIdx.x][w];
+            A.part[((int64_t)blockIdx.x * M1 + slot) * 5 + threadIdx.x] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// sum the per-chunk partials: grid = count blocks (logical slot l each)
+__global__ __launch_bounds__(kLb) void multidot_reduce_kernel(LbfgsArrays A, int nb, int M1) {
+    __shared__ double red[kLb / 64];
+    const LbfgsState &S = *A.st;
+    if ((int)blockIdx.x >= S.count) return;
+    const int slot = (S.head + blockIdx.x) % M1;
+    for (int q = 0; q < 5; ++q) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nb; b += kLb) v += A.part[((int64_t)b * M1 + slot) * 5 + q];
+        const double r = block_sum(v, red);
+        if (threadIdx.x == 0) A.dots[slot * 5 + q] = r;
+        __syncthreads();
+    }
+}
+
+// ---- the two loops in coefficient space (one block); writes cy, cs, cg, t, gtd, stop
+__global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, double lr, double tol_change) {
+    __shared__ double red[kLb / 64];
+    LbfgsState &S = *A.st;
+    const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x;
+    // Gram row / column of the new pair
+    if (ns >= 0) {
+        for (int l = tid; l < count; l += kLb) {
+            const int j = (head + l) % M1;
+            A.SY[ns * M1 + j] = A.dots[j * 5 + 2];        // s_new . y_j
+            A.SY[j * M1 + ns] = A.dots[j * 5 + 4];        // s_j . y_new
+            A.YY[ns * M1 + j] = A.dots[j * 5 + 3];        // y_new . y_j
+            A.YY[j * M1 + ns] = A.dots[j * 5 + 3];
+        }
+    }
+    __syncthreads();
+    const double H = S.H_diag;
+    // first loop, newest to oldest: al_i = ro_i ( -s_i.g - sum_{j newer} al_j s_i.y_j )
+    for (int l = count - 1; l >= 0; --l) {
+        const int i = (head + l) % M1;
+        double v = 0.0;
+        for (int l2 = l + 1 + tid; l2 < count; l2 += kLb) {
+            const int j = (head + l2) % M1;
+            v += A.al[j] * A.SY[i * M1 + j];
+        }
+        const double sum = block_sum_all(v, red);
+        if (tid == 0) A.al[i] = A.ro[i] * (-A.dots[i * 5 + 1] - sum);
+        __syncthreads();
+    }
+    // second loop, oldest to newest: be_i = ro_i ( H(-y_i.g - sum_j al_j y_i.y_j) + sum_{j older} c_j s_j.y_i )
+    for (int l = 0; l < count; ++l) {
+        const int i = (head + l) % M1;
+        double v = 0.0, w = 0.0;
+        for (int l2 = tid; l2 < count; l2 += kLb) {
+            const int j = (head + l2) % M1;
+            v += A.al[j] * A.YY[i * M1 + j];
+            if (l2 < l) w += A.cs[j] * A.SY[j * M1 + i];
+        }
+        const double sv = block_sum_all(v, red);
+        const double sw = block_sum_all(w, red);
+        if (tid == 0) {
+            const double be = A.ro[i] * (H * (-A.dots[i * 5] - sv) + sw);
+            A.cs[i] = A.al[i] - be;
+        }
+        __syncthreads();
+    }
+    // g.d = -H g.g + sum_j (-H al_j) y_j.g + sum_j c_j s_j.g
+    double v = 0.0;
+    for (int l = tid; l < count; l += kLb) {
+        const int j = (head + l) % M1;
+        const double cyj = -H * A.al[j];
+        A.cy[j] = cyj;
+        v += cyj * A.dots[j * 5] + A.cs[j] * A.dots[j * 5 + 1];
+    }
+    const double sum = block_sum_all(v, red);
+    if (tid == 0) {
+        S.cg = -H;
+        S.gtd = -H * S.gg + sum;
+        S.t = S.n_iter == 1 ? fmin(1.0, 1.0 / S.g_abssum) * lr : lr;
+        S.stop_gtd = S.gtd > -tol_change ? 1 : 0;
+    }
+}
+
+// ---- d = cg g + sum_j cy_j Y_j + cs_j S_j (one pass over the history), max|d| partials [nb]
+template <typename T>
+__global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
+                                                        const T *__restrict__ Yring, T *__restrict__ d, int64_t n, int M1) {
+    const LbfgsState &S = *A.st;
+    const int count = S.count, head = S.head;
+    const int64_t base = (int64_t)blockIdx.x * kLbChunk + threadIdx.x;
+    const double cg = S.cg;
+    double acc[kLbPer];
+#pragma unroll
+    for (int k = 0; k < kLbPer; ++k) {
+        const int64_t i = base + (int64_t)k * kLb;
+        acc[k] = i < n ? cg * (double)g[i] : 0.0;
+    }
+    for (int l = 0; l < count; ++l) {
+        const int slot = (head + l) % M1;
+        const double cy = A.cy[slot], cs = A.cs[slot];
+        const T *Yj = Yring + (int64_t)slot * n, *Sj = Sring + (int64_t)slot * n;
+#pragma unroll
+        for (int k = 0; k < kLbPer; ++k) {
+            const int64_t i = base + (int64_t)k * kLb;
+            if (i < n) acc[k] += cy * (double)Yj[i] + cs * (double)Sj[i];
+        }
+    }
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < kLbPer; ++k) {
+        const int64_t i = base + (int64_t)k * kLb;
+        if (i < n) {
+            const T v = (T)acc[k];
+            d[i] = v;
+            const double a = fabs((double)v);
+            mx = (a > mx || a != a) ? a : mx;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    __shared__ double mred[kLb / 64];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = mred[0];
+        for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        A.part[blockIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(kLb) void dmax_reduce_kernel(LbfgsArrays A, int nb) {
+    double mx = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kLb) {
+        const double m = A.part[b];
+        mx = (m > mx || m != m) ? m : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    __shared__ double mred[kLb / 64];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = mred[0];
+        for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        A.st->d_absmax = m;
+    }
+}
+
+// ---- p += t d on one parameter segment, unless the iteration stopped on g.d
+template <typename T>
+__global__ __launch_bounds__(kLb) void apply_kernel(LbfgsArrays A, T *__restrict__ p, const T *__restrict__ d, int64_t n) {
+    const LbfgsState &S = *A.st;
+    if (S.stop_gtd) return;
+    const double t = S.t;
+    for (int64_t i = (int64_t)blockIdx.x * kLb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLb)
+        p[i] = (T)((double)p[i] + t * (double)d[i]);
+}
+
+}  // namespace hfem
+
+using namespace hfem;
+
+struct hfem_lbfgs {
+    int device = -1, M1 = 0, dtype = 0, nb_stream = 0, nb_chunk = 0;
+    int64_t n = 0;
+    bool first = true;              // no pair yet (torch state["n_iter"] == 0)
+    void *Sring = nullptr, *Yring = nullptr, *g_prev = nullptr, *d = nullptr;
+    double *scal = nullptr, *status = nullptr;
+    LbfgsArrays A{};
+};
+
+template <typename T>
+static int lb_malloc(T **p, size_t count) {
+    HFEM_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    HFEM_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    return 0;
+}
+
+extern "C" int hfem_lbfgs_destroy(hfem_lbfgs *o) {
+    if (!o) return 0;
+    if (o->device >= 0) {
+        (void)hipSetDevice(o->device);
+        (void)hipFree(o->Sring); (void)hipFree(o->Yring); (void)hipFree(o->g_prev); (void)hipFree(o->d);
+        (void)hipFree(o->scal); (void)hipFree(o->status); (void)hipFree(o->A.part); (void)hipFree(o->A.st);
+    }
+    delete o;
+    return 0;
+}
+
+extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t dtype, hfem_lbfgs **out) {
+    HFEM_ARG_CHECK(out, "null out pointer");
+    *out = nullptr;
+    HFEM_ARG_CHECK(n >= 1 && history >= 1 && history <= 1024, "need n >= 1 and 1 <= history <= 1024");
+    HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64, 1 = fp32");
+    if (int rc = use_device(device)) return rc;
+    hfem_lbfgs *o = new (std::nothrow) hfem_lbfgs();
+    HFEM_ARG_CHECK(o, "out of host memory");
+    o->device = device; o->n = n; o->M1 = history + 1; o->dtype = dtype;
+    const size_t esz = dtype == 0 ? 8 : 4, M1 = (size_t)o->M1;
+    o->nb_chunk = (int)((n + kLbChunk - 1) / kLbChunk);
+    o->nb_stream = (int)std::min<int64_t>((n + kLb - 1) / kLb, 2048);
+    int rc = 0;
+    char *ring = nullptr;
+    if (!rc) rc = lb_malloc(&ring, M1 * (size_t)n * esz); o->Sring = ring; ring = nullptr;
+    if (!rc) rc = lb_malloc(&ring, M1 * (size_t)n * esz); o->Yring = ring; ring = nullptr;
+    if (!rc) rc = lb_malloc(&ring, (size_t)n * esz); o->g_prev = ring; ring = nullptr;
+    if (!rc) rc = lb_malloc(&ring, (size_t)n * esz); o->d = ring;
+    const size_t nscal = 4 * M1 + 5 * M1 + 2 * M1 * M1;
+    if (!rc) rc = lb_malloc(&o->scal, nscal);
+    if (!rc) rc = lb_malloc(&o->status, 8);
+    const size_t npart = std::max<size_t>({(size_t)o->nb_chunk * M1 * 5, (size_t)o->nb_stream * 3, (size_t)o->nb_chunk});
+    if (!rc) rc = lb_malloc(&o->A.part, npart);
+    if (!rc) rc = lb_malloc(&o->A.st, 1);
+    if (rc) { hfem_lbfgs_destroy(o); return rc; }
+    double *s = o->scal;
+    o->A.ro = s; s += M1; o->A.al = s; s += M1; o->A.cy = s; s += M1; o->A.cs = s; s += M1;
+    o->A.dots = s; s += 5 * M1; o->A.SY = s; s += M1 * M1; o->A.YY = s;
+    *out = o;
+    return 0;
+}
+
+// Statistics of the gradient just evaluated + torch's break tests (opt_cond; after an update also the
+// "lack of progress" tests and the g.d break).  loss: device scalar (fp64) of that evaluation.
+// status (host, 8 doubles): loss, flags (bit0 opt_cond, 1 small step, 2 small loss change, 3 g.d break),
+// max|g|, g.d, t, history count, n_iter, H_diag.  Synchronises the stream.
+extern "C" int hfem_lbfgs_check(hfem_lbfgs *o, const void *g, const double *loss, int32_t after_update, double tol_grad,
+                                double tol_change, double *status_host, void *stream) {
+    HFEM_ARG_CHECK(o && g && status_host, "null pointer");
+    if (int rc = use_device(o->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (o->dtype == 0) hipLaunchKernelGGL(gstats_kernel<double>, dim3(o->nb_stream), dim3(kLb), 0, s, (const double *)g, o->n, o->A.part);
+    else hipLaunchKernelGGL(gstats_kernel<float>, dim3(o->nb_stream), dim3(kLb), 0, s, (const float *)g, o->n, o->A.part);
+    hipLaunchKernelGGL(check_kernel, dim3(1), dim3(kLb), 0, s, o->A, o->nb_stream, loss, (int)after_update, tol_grad, tol_change,
+                       o->status);
+    if (int rc = launch_status("hfem_lbfgs_check")) return rc;
+    HFEM_HIP_CHECK(hipMemcpyAsync(status_host, o->status, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HFEM_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// Memory update + direction for the gradient `g` (the one hfem_lbfgs_check saw last): d, t, g.d and the g.d break
+// flag stay on the device.
+extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, double tol_change, void *stream) {
+    HFEM_ARG_CHECK(o && g, "null pointer");
+    if (int rc = use_device(o->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int first = o->first ? 1 : 0, M1 = o->M1;
+    if (o->dtype == 0) hipLaunchKernelGGL(pair_kernel<double>, dim3(o->nb_stream), dim3(kLb), 0, s, o->A, (const double *)g, (double *)o->g_prev, (const double *)o->d, (double *)o->Sring, (double *)o->Yring, o->n, M1, first);
+    else hipLaunchKernelGGL(pair_kernel<float>, dim3(o->nb_stream), dim3(kLb), 0, s, o->A, (const float *)g, (float *)o->g_prev, (const float *)o->d, (float *)o->Sring, (float *)o->Yring, o->n, M1, first);
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, o->nb_stream, M1, first);
+    if (!first) {
+        if (o->dtype == 0) hipLaunchKernelGGL(multidot_kernel<double>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, o->n, M1);
+        else hipLaunchKernelGGL(multidot_kernel<float>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, o->n, M1);
+        hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_chunk, M1);
+    }
+    hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(kLb), 0, s, o->A, M1, lr, tol_change);
+    if (o->dtype == 0) hipLaunchKernelGGL(direction_kernel<double>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, (double *)o->d, o->n, M1);
+    else hipLaunchKernelGGL(direction_kernel<float>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, (float *)o->d, o->n, M1);
+    hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, o->nb_chunk);
+    o->first = false;
+    return launch_status("hfem_lbfgs_direction");
+}
+
+// p[0..numel) += t * d[offset .. offset+numel) for one parameter tensor (nothing if the iteration stopped on g.d)
+extern "C" int hfem_lbfgs_apply(hfem_lbfgs *o, void *p, int64_t offset, int64_t numel, void *stream) {
+    HFEM_ARG_CHECK(o && (p || numel == 0), "null pointer");
+    HFEM_ARG_CHECK(offset >= 0 && numel >= 0 && offset + numel <= o->n, "segment outside the flat vector");
+    if (numel == 0) return 0;
+    if (int rc = use_device(o->device)) return rc;
+    const int grid = (int)std::min<int64_t>((numel + kLb - 1) / kLb, 4096);
+    if (o->dtype == 0) hipLaunchKernelGGL(apply_kernel<double>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, o->A, (double *)p, (const double *)o->d + offset, numel);
+    else hipLaunchKernelGGL(apply_kernel<float>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, o->A, (float *)p, (const float *)o->d + offset, numel);
+    return launch_status("hfem_lbfgs_apply");
+}
+
+// device pointer of the direction d (flat, n elements of the optimiser's dtype): for tests / callers that
+// want to inspect it
+extern "C" void *hfem_lbfgs_direction_ptr(hfem_lbfgs *o) { return o ? o->d : nullptr; }

@@ -48,3 +48,113 @@ class FusedAdam(torch.optim.Optimizer):
                                        float(b2), float(group["eps"]), int(st["step"]), stream_ptr(p.device)),
                       "hfem_adam_step")
         return loss
+
+
+class FusedLBFGS(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.LBFGS(model.parameters())`` as ``/root/reference/examples/example4.py:68-78``
+    uses it (same defaults: lr 1, max_iter 20, max_eval 25, tolerance_grad 1e-7, tolerance_change 1e-9,
+    history_size 100; fixed step -- ``line_search_fn`` must stay ``None``).  Same algorithm and break tests as
+    ``torch/optim/lbfgs.py``; the history, the two-loop recursion (run in coefficient space, csrc/lbfgs.hip), the
+    step and every scalar live on the device, and the host reads ONE status record per inner iteration
+    (torch: ~4 * history small kernels and ~6 syncs).  One deviation: when an iteration stops on
+    ``g.d > -tolerance_change`` the host learns it after one extra closure call at the unchanged parameters
+    (``func_evals`` is then one higher than torch's).  ROCm tensors only; state is not serialisable."""
+
+    def __init__(self, params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9,
+                 history_size=100, line_search_fn=None):
+        if line_search_fn is not None:
+            raise NotImplementedError("FusedLBFGS implements the fixed-step variant (line_search_fn=None), which is "
+                                      "what the reference's example 4 runs")
+        if max_eval is None:
+            max_eval = max_iter * 5 // 4
+        super().__init__(params, dict(lr=lr, max_iter=max_iter, max_eval=max_eval, tolerance_grad=tolerance_grad,
+                                      tolerance_change=tolerance_change, history_size=history_size,
+                                      line_search_fn=line_search_fn))
+        if len(self.param_groups) != 1:
+            raise ValueError("LBFGS doesn't support per-parameter options (parameter groups)")
+        self._params = self.param_groups[0]["params"]
+        p0 = self._params[0]
+        for p in self._params:
+            require_gpu_tensor(p.data, "parameter", dtype=None)
+            if p.dtype != p0.dtype or p.dtype not in (torch.float64, torch.float32) or p.device != p0.device:
+                raise RuntimeError("FusedLBFGS: parameters must share one device and one dtype (fp64 or fp32)")
+        self._n = sum(p.numel() for p in self._params)
+        self._flat_g = torch.zeros(self._n, dtype=p0.dtype, device=p0.device)
+        self._h = None
+        import ctypes as C
+        self._status = (C.c_double * 8)()
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.lib().hfem_lbfgs_destroy(self._h)
+            self._h = None
+
+    def _handle(self):
+        if self._h is None:
+            import ctypes as C
+            h = C.c_void_p()
+            p0 = self._params[0]
+            check(_lib.lib().hfem_lbfgs_create(dev_index(p0.device), self._n, int(self.param_groups[0]["history_size"]),
+                                               0 if p0.dtype == torch.float64 else 1, C.byref(h)), "hfem_lbfgs_create")
+            self._h = h
+        return self._h
+
+    def _gather_flat_grad(self):
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is None:
+                self._flat_g[off:off + n].zero_()
+            else:
+                self._flat_g[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+
+    def _check(self, loss, after_update):
+        g = self.param_groups[0]
+        dev = self._flat_g.device
+        l64 = loss.detach().to(torch.float64).reshape(1)
+        check(_lib.lib().hfem_lbfgs_check(self._handle(), ptr(self._flat_g), ptr(l64), int(after_update),
+                                          float(g["tolerance_grad"]), float(g["tolerance_change"]), self._status,
+                                          stream_ptr(dev)), "hfem_lbfgs_check")
+        return int(self._status[1])
+
+    @torch.no_grad()
+    def step(self, closure):
+        group = self.param_groups[0]
+        closure = torch.enable_grad()(closure)
+        L, h, dev = _lib.lib(), self._handle(), self._flat_g.device
+        state = self.state[self._params[0]]
+        state.setdefault("func_evals", 0)
+        state.setdefault("n_iter", 0)
+        orig_loss = closure()
+        current_evals = 1
+        state["func_evals"] += 1
+        self._gather_flat_grad()
+        if self._check(orig_loss, 0) & 1:                      # optimal condition
+            return orig_loss
+        n_iter, max_iter, max_eval = 0, group["max_iter"], group["max_eval"]
+        while n_iter < max_iter:
+            n_iter += 1
+            state["n_iter"] += 1
+            check(L.hfem_lbfgs_direction(h, ptr(self._flat_g), float(group["lr"]), float(group["tolerance_change"]),
+                                         stream_ptr(dev)), "hfem_lbfgs_direction")
+            off = 0
+            for p in self._params:                               # p += t d (skipped on the device if g.d stopped)
+                check(L.hfem_lbfgs_apply(h, ptr(p.data), off, p.numel(), stream_ptr(dev)), "hfem_lbfgs_apply")
+                off += p.numel()
+            if n_iter == max_iter:
+                break
+            loss = closure()
+            self._gather_flat_grad()
+            flags = self._check(loss, 1)
+            if flags & 8:                                        # g.d > -tolerance_change: nothing was applied
+                break
+            current_evals += 1
+            state["func_evals"] += 1
+            if current_evals >= max_eval or flags & 7:
+                break
+        return orig_loss
+
+    def status(self):
+        """Last status record: loss, flags, max|g|, g.d, t, history count, n_iter, H_diag."""
+        return list(self._status)

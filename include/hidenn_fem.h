@@ -200,6 +200,25 @@ int hfem_scatter_rows(int device, const double *src, const int32_t *idx, int64_t
 int hfem_gather_rows(int device, const double *src, const int32_t *idx, int64_t rows,
                      int32_t width, double *dst, void *stream);
 
+/* ------------------------------------------------------------------ L-BFGS on the flat parameter vector
+ * (torch.optim.LBFGS as examples/example4.py:68-78 uses it: fixed step, no line search).
+ * State (history ring of `history` (s, y) pairs, Gram blocks, direction d, step t) lives on the device.
+ * One inner iteration of torch's loop is:
+ *     hfem_lbfgs_direction(g)  ->  hfem_lbfgs_apply(param, offset, numel) per parameter tensor
+ *     ->  closure (energy kernel) -> hfem_lbfgs_check(g_new, loss_new, after_update = 1) -> host reads status.
+ * dtype: 0 fp64, 1 fp32 (vectors); dots and the recursion are fp64 either way.
+ * status[8] (host): loss, flags (bit0 max|g| <= tol_grad, bit1 max|t d| <= tol_change,
+ * bit2 |loss - prev_loss| < tol_change, bit3 g.d > -tol_change: nothing was applied), max|g|, g.d, t,
+ * history count, n_iter, H_diag.  hfem_lbfgs_check synchronises the stream; the others only enqueue.      */
+typedef struct hfem_lbfgs hfem_lbfgs;
+int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t dtype, hfem_lbfgs **out);
+int hfem_lbfgs_destroy(hfem_lbfgs *opt);
+int hfem_lbfgs_check(hfem_lbfgs *opt, const void *g, const double *loss, int32_t after_update, double tol_grad,
+                     double tol_change, double *status_host, void *stream);
+int hfem_lbfgs_direction(hfem_lbfgs *opt, const void *g, double lr, double tol_change, void *stream);
+int hfem_lbfgs_apply(hfem_lbfgs *opt, void *p, int64_t offset, int64_t numel, void *stream);
+void *hfem_lbfgs_direction_ptr(hfem_lbfgs *opt);
+
 /* ------------------------------------------------------------------ post-processing
  * hfem_tri3_von_mises: per element, grad_u at the centroid (constant on a P1 triangle; reference
  * convention, src/models.py:351-355) -> strain -> plane-stress stress -> von Mises, exactly the chain of

@@ -8,7 +8,8 @@
 //   G0 = sum_k U_k D0k, G1 = sum_k U_k D1k
 // and from there H = G Jinv^T, eps, sigma, psi and the whole backward are the TRI3 closed forms
 // (hfem_device.h) with (a,b,c,d,G0,G1); the chain rule back to the nodes multiplies by D0k / D1k.
-// Planless this round (one thread per element, fp64 global atomics); the tiled plan is TRI3-only.
+// Two energy kernels: quad4_energy_fast_kernel on the owner-computes tile plan (production) and the planless
+// quad4_energy_atomic_kernel (one thread per element, fp64 global atomics; independent algebra, cross-check).
 #include <hip/hip_runtime.h>
 
 #include "hfem_device.h"

@@ -51,6 +51,9 @@ PROTOTYPES = {
     "hfem_edge2_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "hfem_edge2_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hfem_quad4_energy_atomic": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "hfem_adam_step_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i32, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, _vp, _vp]),
+    "hfem_counter_add": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "hfem_lbfgs_create": (C.c_int, [C.c_int, _i64, _i32, _i32, C.POINTER(_vp)]),
     "hfem_lbfgs_destroy": (C.c_int, [_vp]),
     "hfem_lbfgs_check": (C.c_int, [_vp, _vp, _vp, _i32, C.c_double, C.c_double, _vp, _vp]),

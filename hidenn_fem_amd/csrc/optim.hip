@@ -5,7 +5,7 @@
 // One launch here reads p,g,m,v and writes p,m,v (56 B/param fp64) -- bandwidth-bound, no reuse.
 // Arithmetic follows torch.optim.Adam (betas, eps, bias corrections, no weight decay / amsgrad)
 // operation for operation:  m += (g-m)(1-b1);  v = v b2 + (1-b2) g g;
-//                           p -= (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps).
+//                           p -= (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)   (same association as torch's foreach kernels).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -18,18 +18,42 @@ template <typename T>
 __global__ __launch_bounds__(256) void adam_step_kernel(T *__restrict__ p, const T *__restrict__ g,
                                                         T *__restrict__ m, T *__restrict__ v, int64_t n,
                                                         double w1, double b2, double w2, double step_size,
-                                                        double inv_sqrt_bc2, double eps) {
+                                                        double sqrt_bc2, double eps) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const T gi = g[i];
         const T mi = m[i] + (T)w1 * (gi - m[i]);                 // lerp_(grad, 1 - beta1)
-        const T vi = v[i] * (T)b2 + (T)w2 * gi * gi;             // mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const T denom = (T)sqrt((double)vi) * (T)inv_sqrt_bc2 + (T)eps;
+        const T vi = v[i] * (T)b2 + (T)w2 * (gi * gi);           // mul_(beta2).addcmul_(g, g, 1 - beta2): a + alpha (b c)
+        const T denom = (T)sqrt((double)vi) / (T)sqrt_bc2 + (T)eps;   // (sqrt(v) / sqrt(bc2)).add_(eps): a true division
         m[i] = mi;
         v[i] = vi;
         p[i] = p[i] - (T)step_size * (mi / denom);
     }
 }
+
+// hipGraph-capturable variant: the step count lives on the device (kernel arguments are frozen inside a graph),
+// the bias corrections are computed per thread from it (two pow() on uniform values: noise next to 56 B/param).
+template <typename T>
+__global__ __launch_bounds__(256) void adam_step_dev_kernel(T *__restrict__ p, const T *__restrict__ g,
+                                                            T *__restrict__ m, T *__restrict__ v, int64_t n,
+                                                            double b1, double b2, double lr, double eps,
+                                                            const int64_t *__restrict__ step_dev) {
+    const double step = (double)step_dev[0];
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const double step_size = lr / bc1, sqrt_bc2 = sqrt(bc2), w1 = 1.0 - b1, w2 = 1.0 - b2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const T gi = g[i];
+        const T mi = m[i] + (T)w1 * (gi - m[i]);
+        const T vi = v[i] * (T)b2 + (T)w2 * (gi * gi);
+        const T denom = (T)sqrt((double)vi) / (T)sqrt_bc2 + (T)eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (T)step_size * (mi / denom);
+    }
+}
+
+__global__ void counter_add_kernel(int64_t *c, int64_t inc) { c[0] += inc; }
 
 }  // namespace hfem
 
@@ -43,16 +67,44 @@ extern "C" int hfem_adam_step(int device, void *p, const void *g, void *m, void 
     HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64, 1 = fp32");
     if (int rc = use_device(device)) return rc;
     const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
-    const double step_size = lr / bc1, inv_sqrt_bc2 = 1.0 / std::sqrt(bc2);
+    const double step_size = lr / bc1, sqrt_bc2 = std::sqrt(bc2);
     int64_t grid = (n + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (dtype == 0)
         hipLaunchKernelGGL(adam_step_kernel<double>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (double *)p,
                            (const double *)g, (double *)m, (double *)v, n, 1.0 - beta1, beta2, 1.0 - beta2, step_size,
-                           inv_sqrt_bc2, eps);
+                           sqrt_bc2, eps);
     else
         hipLaunchKernelGGL(adam_step_kernel<float>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float *)p,
                            (const float *)g, (float *)m, (float *)v, n, 1.0 - beta1, beta2, 1.0 - beta2, step_size,
-                           inv_sqrt_bc2, eps);
+                           sqrt_bc2, eps);
     return launch_status("hfem_adam_step");
+}
+
+// Same update with the step count read from device memory (1-based: the value the counter holds when the kernel
+// runs), for optimiser steps captured in a hipGraph.  hfem_counter_add bumps such a counter in stream order.
+extern "C" int hfem_adam_step_dev(int device, void *p, const void *g, void *m, void *v, int64_t n, int32_t dtype,
+                                  double lr, double beta1, double beta2, double eps, const int64_t *step_dev,
+                                  void *stream) {
+    HFEM_ARG_CHECK(n >= 0, "need n >= 0");
+    if (n == 0) return 0;
+    HFEM_ARG_CHECK(p && g && m && v && step_dev, "null pointer");
+    HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64, 1 = fp32");
+    if (int rc = use_device(device)) return rc;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (dtype == 0)
+        hipLaunchKernelGGL(adam_step_dev_kernel<double>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (double *)p,
+                           (const double *)g, (double *)m, (double *)v, n, beta1, beta2, lr, eps, step_dev);
+    else
+        hipLaunchKernelGGL(adam_step_dev_kernel<float>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float *)p,
+                           (const float *)g, (float *)m, (float *)v, n, beta1, beta2, lr, eps, step_dev);
+    return launch_status("hfem_adam_step_dev");
+}
+
+extern "C" int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream) {
+    HFEM_ARG_CHECK(counter, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+    return launch_status("hfem_counter_add");
 }

@@ -1,0 +1,58 @@
+"""Whole training iterations in one hipGraph.
+
+At the reference's example sizes (10^2..10^5 elements) an iteration -- ``zero_grad``, loss, ``backward``,
+optimiser step -- is a dozen kernels of a few microseconds each, so the wall time is launch overhead and
+Python.  ``GraphedTraining`` captures ``steps_per_replay`` complete iterations once and replays them: the GPU
+then runs the kernels back to back (the CDNA playbook's "capture launch-bound inner loops in hipGraphs").
+
+Requirements (the usual ones for stream capture): static shapes and addresses -- parameters, their ``.grad``
+tensors (kept allocated: ``zero_grad(set_to_none=False)``) and every tensor the closure reads stay where they
+are; no host synchronisation inside the closure (``.item()``, ``print`` of a loss, Python branches on tensor
+values); an optimiser whose step count lives on the device (``FusedAdam(..., capturable=True)`` or
+``torch.optim.Adam(..., capturable=True)``).  L-BFGS has host control flow and cannot be captured.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+
+class GraphedTraining:
+    """``closure()`` must compute and return the loss (no ``backward``): one captured iteration is
+    ``optimizer.zero_grad(set_to_none=False); loss = closure(); loss.backward(); optimizer.step()``."""
+
+    def __init__(self, closure: Callable[[], torch.Tensor], optimizer: torch.optim.Optimizer, steps_per_replay: int = 1,
+                 warmup: int = 3):
+        self.closure, self.optimizer, self.steps_per_replay = closure, optimizer, int(steps_per_replay)
+        if self.steps_per_replay < 1:
+            raise ValueError("steps_per_replay must be >= 1")
+        self.steps_done = 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up off the default stream (allocations,
+            for _ in range(warmup):                        # optimiser state, autograd buffers) -- these count
+                self._one()                                # as real training iterations
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.steps_done += warmup
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            for _ in range(self.steps_per_replay):
+                self.loss = self._one()
+        # capture does not execute: nothing to add to steps_done
+
+    def _one(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        loss = self.closure()
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def replay(self, n: int = 1) -> torch.Tensor:
+        """Run ``n * steps_per_replay`` iterations; returns the (static) loss tensor of the last one --
+        the loss evaluated BEFORE that iteration's optimiser step, as in the eager loop."""
+        for _ in range(n):
+            self.graph.replay()
+        self.steps_done += n * self.steps_per_replay
+        return self.loss

@@ -14,10 +14,15 @@ from ._lib import check, ptr, require_gpu_tensor, stream_ptr, dev_index
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """``capturable=True``: the step count lives on the device (one counter for the optimiser), so ``step()``
+    can be captured in a hipGraph (``hidenn_fem_amd.graphed.GraphedTraining``); the arithmetic is the same."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = capturable
+        self._step_dev = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -26,6 +31,12 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        if self.capturable:
+            p0 = self.param_groups[0]["params"][0]
+            if self._step_dev is None:
+                self._step_dev = torch.zeros(1, dtype=torch.int64, device=p0.device)
+            check(L.hfem_counter_add(dev_index(p0.device), ptr(self._step_dev), 1, stream_ptr(p0.device)),
+                  "hfem_counter_add")
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -43,6 +54,12 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                if self.capturable:
+                    check(L.hfem_adam_step_dev(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]),
+                                               ptr(st["exp_avg_sq"]), p.numel(), 0 if p.dtype == torch.float64 else 1,
+                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                               ptr(self._step_dev), stream_ptr(p.device)), "hfem_adam_step_dev")
+                    continue
                 check(L.hfem_adam_step(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
                                        p.numel(), 0 if p.dtype == torch.float64 else 1, float(group["lr"]), float(b1),
                                        float(b2), float(group["eps"]), int(st["step"]), stream_ptr(p.device)),

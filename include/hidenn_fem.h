@@ -191,6 +191,12 @@ int hfem_quad4_eval_bwd(int device, const double *X, const double *U, const int3
  * dtype: 0 = fp64, 1 = fp32 (p, g, m, v all of that type).  step counts from 1.            */
 int hfem_adam_step(int device, void *p, const void *g, void *m, void *v, int64_t n, int32_t dtype,
                    double lr, double beta1, double beta2, double eps, int64_t step, void *stream);
+/* hipGraph-capturable form: the (1-based) step count is read from device memory when the kernel runs;
+ * hfem_counter_add bumps such a counter in stream order (call it once before the step's kernels).   */
+int hfem_adam_step_dev(int device, void *p, const void *g, void *m, void *v, int64_t n, int32_t dtype,
+                       double lr, double beta1, double beta2, double eps, const int64_t *step_dev,
+                       void *stream);
+int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream);
 
 /* ------------------------------------------------------------------ row gather/scatter
  * src/models.py:292-305 as index lists instead of bool-mask index_put (which

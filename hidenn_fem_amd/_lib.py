@@ -73,6 +73,9 @@ PROTOTYPES = {
     "hfem_gather_rows": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hfem_grid_param_fwd": (C.c_int, [C.c_int, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "hfem_grid_param_bwd": (C.c_int, [C.c_int, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "hfem_grid_param_ws_elems": (_i64, [_i64]),
+    "hfem_grid_param_fwd_ws": (C.c_int, [C.c_int, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hfem_grid_param_bwd_ws": (C.c_int, [C.c_int, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hfem_line2_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "hfem_line2_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hfem_bar_energy": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp]),

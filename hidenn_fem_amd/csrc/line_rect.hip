@@ -110,6 +110,137 @@ __global__ __launch_bounds__(kScan) void grid_param_bwd_kernel(const double *__r
     }
 }
 
+// ---- multi-workgroup form for long grids (the single-workgroup kernels above put every softplus -- an fp64
+// exp + log1p -- on ONE CU: 31 us forward / 53 us backward at n = 10^4, most of an example-3 iteration).
+// Three small launches each way: per-block local scan (+ block sums), one-block scan of the block sums,
+// finalize.  Blocks own kGpChunk = 1024 consecutive increments (256 threads x 4, coalesced).
+constexpr int kGpThreads = 256, kGpPer = 4, kGpChunk = kGpThreads * kGpPer;
+
+// inclusive scan (prefix or suffix) of one value per thread over the block's kGpThreads threads
+__device__ __forceinline__ double gp_block_scan(double v, double *buf, bool suffix) {
+    const int tid = threadIdx.x;
+    buf[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < kGpThreads; off <<= 1) {
+        const int o = suffix ? tid + off : tid - off;
+        const double add = (o >= 0 && o < kGpThreads) ? buf[o] : 0.0;
+        __syncthreads();
+        buf[tid] += add;
+        __syncthreads();
+    }
+    return buf[tid];
+}
+
+// F1: cumloc[k] = inclusive prefix of softplus within the block; bsum[b] = block total
+__global__ __launch_bounds__(kGpThreads) void gp_fwd_local_kernel(const double *__restrict__ p, int64_t n,
+                                                                  double *__restrict__ cum, double *__restrict__ bsum) {
+    __shared__ double buf[kGpThreads];
+    const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
+    double v[kGpPer], run = 0.0;
+#pragma unroll
+    for (int j = 0; j < kGpPer; ++j) {
+        v[j] = (k0 + j < n) ? softplus_clamped(p[k0 + j]) : 0.0;
+        run += v[j];
+        v[j] = run;
+    }
+    const double incl = gp_block_scan(run, buf, false);
+    const double before = incl - run;
+#pragma unroll
+    for (int j = 0; j < kGpPer; ++j)
+        if (k0 + j < n) cum[k0 + j] = before + v[j];
+    if (threadIdx.x == kGpThreads - 1) bsum[blockIdx.x] = incl;
+}
+
+// F2 / B2: one block; exclusive scan (prefix or suffix) of the nb block sums in place; totals to scal
+__global__ __launch_bounds__(kScan) void gp_block_offsets_kernel(double *__restrict__ bsum, int64_t nb, bool suffix,
+                                                                 const double *__restrict__ dsum, double *__restrict__ scal) {
+    __shared__ double buf[kScan];
+    __shared__ double red[kScan / 64];
+    const int tid = threadIdx.x;
+    const int64_t chunk = (nb + kScan - 1) / kScan;
+    const int64_t b0 = tid * chunk, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
+    double s = 0.0, d = 0.0;
+    for (int64_t b = b0; b < b1; ++b) { s += bsum[b]; if (dsum) d += dsum[b]; }
+    const double incl = block_scan(s, buf, suffix);
+    const double total = suffix ? buf[0] : buf[kScan - 1];
+    __syncthreads();
+    double run = incl - s;                                  // blocks strictly before (after) this thread's chunk
+    if (!suffix) for (int64_t b = b0; b < b1; ++b) { const double t = bsum[b]; bsum[b] = run; run += t; }
+    else for (int64_t b = b1 - 1; b >= b0; --b) { const double t = bsum[b]; bsum[b] = run; run += t; }
+    const double dtot = block_sum(d, red);
+    if (tid == 0) { scal[0] = total; scal[1] = dtot; }
+}
+
+// F3: cum += block offset (last entry := S exactly), grid
+__global__ __launch_bounds__(kGpThreads) void gp_fwd_final_kernel(int64_t n, double x0, double xN,
+                                                                  const uint8_t *__restrict__ mask,
+                                                                  const double *__restrict__ initial,
+                                                                  const double *__restrict__ boff,
+                                                                  const double *__restrict__ scal, double *__restrict__ cum,
+                                                                  double *__restrict__ grid) {
+    const double S = scal[0], off = boff[blockIdx.x];
+    const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
+#pragma unroll
+    for (int j = 0; j < kGpPer; ++j) {
+        const int64_t k = k0 + j;
+        if (k < n) {
+            const double c = (k == n - 1) ? S : off + cum[k];       // cum[-1]/cum[-1] == 1 exactly
+            cum[k] = c;
+            double g = x0 + (xN - x0) * c / S;                      // models.py:52
+            if (mask && mask[k + 1]) g = initial[k + 1];            // models.py:165-166
+            grid[k + 1] = g;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) grid[0] = (mask && mask[0]) ? initial[0] : x0;
+}
+
+// B1: a_k = L g_k / S; sufloc[k] = inclusive suffix of a within the block; asum[b]; dsum[b] = sum g_k cum_k
+__global__ __launch_bounds__(kGpThreads) void gp_bwd_local_kernel(int64_t n, double L, const uint8_t *__restrict__ mask,
+                                                                  const double *__restrict__ ggrid,
+                                                                  const double *__restrict__ cum, double *__restrict__ suf,
+                                                                  double *__restrict__ asum, double *__restrict__ dsum) {
+    __shared__ double buf[kGpThreads];
+    __shared__ double red[kGpThreads / 64];
+    const double S = cum[n - 1];
+    const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
+    double a[kGpPer], run = 0.0, dot = 0.0;
+#pragma unroll
+    for (int j = kGpPer - 1; j >= 0; --j) {
+        const int64_t k = k0 + j;
+        double g = 0.0;
+        if (k < n) {
+            g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+            dot += g * cum[k];
+        }
+        run += L * g / S;
+        a[j] = run;                                          // suffix within the thread
+    }
+    const double incl = gp_block_scan(run, buf, true);
+    const double after = incl - run;
+#pragma unroll
+    for (int j = 0; j < kGpPer; ++j)
+        if (k0 + j < n) suf[k0 + j] = after + a[j];
+    if (threadIdx.x == 0) asum[blockIdx.x] = incl;
+    __syncthreads();
+    const double dt = block_sum(dot, red);
+    if (threadIdx.x == 0) dsum[blockIdx.x] = dt;
+}
+
+// B3: gp[k] = (suffix over later blocks + local suffix - corr) * softplus'(p[k])
+__global__ __launch_bounds__(kGpThreads) void gp_bwd_final_kernel(const double *__restrict__ p, int64_t n, double L,
+                                                                  const double *__restrict__ cum,
+                                                                  const double *__restrict__ suf,
+                                                                  const double *__restrict__ aoff,
+                                                                  const double *__restrict__ scal, double *__restrict__ gp) {
+    const double S = cum[n - 1], corr = L * scal[1] / (S * S), off = aoff[blockIdx.x];
+    const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
+#pragma unroll
+    for (int j = 0; j < kGpPer; ++j) {
+        const int64_t k = k0 + j;
+        if (k < n) gp[k] = (off + suf[k] - corr) * softplus_clamped_grad(p[k]);
+    }
+}
+
 // searchsorted(grid, x, right=False) - 1, clamp(0, n-2)      models.py:73-74
 __device__ __forceinline__ int find_elem(const double *__restrict__ grid, int n, double x) {
     int lo = 0, hi = n;
@@ -336,6 +467,47 @@ extern "C" int hfem_grid_param_bwd(int device, const double *p, int64_t n, doubl
     hipLaunchKernelGGL(grid_param_bwd_kernel, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask,
                        ggrid, gp);
     return launch_status("hfem_grid_param_bwd");
+}
+
+// Workspace forms for long grids (three launches each way over all CUs; the forms above are one workgroup):
+// ws holds hfem_grid_param_ws_elems(n) doubles of scratch; cum[n] is an OUTPUT of the forward (the clamped-softplus
+// running sums, cum[n-1] = their total) that the backward reads back.
+extern "C" int64_t hfem_grid_param_ws_elems(int64_t n) {
+    if (n < 1) return 8;
+    const int64_t nb = (n + kGpChunk - 1) / kGpChunk;
+    return n + 2 * nb + 8;
+}
+
+extern "C" int hfem_grid_param_fwd_ws(int device, const double *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                                      const double *initial, double *grid, double *cum, double *ws, void *stream) {
+    HFEM_ARG_CHECK(p && grid && cum && ws && n >= 1, "null pointer / empty increments");
+    HFEM_ARG_CHECK(!mask || initial, "mask given without initial grid");
+    if (int rc = use_device(device)) return rc;
+    const int64_t nb = (n + kGpChunk - 1) / kGpChunk;
+    HFEM_ARG_CHECK(nb <= 2147483647, "grid too long");
+    double *bsum = ws, *scal = ws + nb;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gp_fwd_local_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, p, n, cum, bsum);
+    hipLaunchKernelGGL(gp_block_offsets_kernel, dim3(1), dim3(kScan), 0, s, bsum, nb, false, (const double *)nullptr, scal);
+    hipLaunchKernelGGL(gp_fwd_final_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, n, x0, xN, mask, initial,
+                       (const double *)bsum, (const double *)scal, cum, grid);
+    return launch_status("hfem_grid_param_fwd_ws");
+}
+
+extern "C" int hfem_grid_param_bwd_ws(int device, const double *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                                      const double *ggrid, const double *cum, double *gp, double *ws, void *stream) {
+    HFEM_ARG_CHECK(p && ggrid && cum && gp && ws && n >= 1, "null pointer / empty increments");
+    if (int rc = use_device(device)) return rc;
+    const int64_t nb = (n + kGpChunk - 1) / kGpChunk;
+    HFEM_ARG_CHECK(nb <= 2147483647, "grid too long");
+    double *suf = ws, *asum = ws + n, *dsum = asum + nb, *scal = dsum + nb;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gp_bwd_local_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, n, xN - x0, mask, ggrid, cum, suf, asum,
+                       dsum);
+    hipLaunchKernelGGL(gp_block_offsets_kernel, dim3(1), dim3(kScan), 0, s, asum, nb, true, (const double *)dsum, scal);
+    hipLaunchKernelGGL(gp_bwd_final_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, p, n, xN - x0, cum, (const double *)suf,
+                       (const double *)asum, (const double *)scal, gp);
+    return launch_status("hfem_grid_param_bwd_ws");
 }
 
 extern "C" int hfem_line2_eval_fwd(int device, const double *grid, const double *u, int64_t n,

@@ -172,6 +172,9 @@ class Edge2EvalFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------- 1D / structured grids
+GRID_PARAM_ONE_BLOCK = 2048      # increments up to here use the single-workgroup kernels (one launch each way)
+
+
 class GridParamFn(torch.autograd.Function):
     """increments p[n] -> grid[n+1] = {x0, x0 + (xN-x0) cumsum(clamp(softplus p))/S}, optionally
     ``where(mask, initial, grid)``; reference src/models.py:45-56, 146-168."""
@@ -183,18 +186,33 @@ class GridParamFn(torch.autograd.Function):
         n = pd.shape[0]
         grid = torch.empty((n + 1,), dtype=F64, device=dev)
         init = _f64(initial, "initial grid")
-        check(_lib.lib().hfem_grid_param_fwd(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8),
-                                             ptr(init), ptr(grid), stream_ptr(dev)), "hfem_grid_param_fwd")
-        ctx.save_for_backward(pd)
+        L = _lib.lib()
+        if n > GRID_PARAM_ONE_BLOCK:                  # long grids: three small launches over all CUs
+            cum = torch.empty(n, dtype=F64, device=dev)
+            ws = torch.empty(L.hfem_grid_param_ws_elems(n), dtype=F64, device=dev)
+            check(L.hfem_grid_param_fwd_ws(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8), ptr(init),
+                                           ptr(grid), ptr(cum), ptr(ws), stream_ptr(dev)), "hfem_grid_param_fwd_ws")
+            ctx.save_for_backward(pd, cum)
+        else:
+            check(L.hfem_grid_param_fwd(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8), ptr(init),
+                                        ptr(grid), stream_ptr(dev)), "hfem_grid_param_fwd")
+            ctx.save_for_backward(pd)
         ctx.mask, ctx.x0, ctx.xN, ctx.dt = mask_u8, float(x0), float(xN), p.dtype
         return grid.to(p.dtype) if p.dtype != F64 else grid
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gg):
-        (pd,) = ctx.saved_tensors
+        pd = ctx.saved_tensors[0]
         dev = pd.device
         gp = torch.empty_like(pd)
+        if len(ctx.saved_tensors) == 2:
+            L, n = _lib.lib(), pd.shape[0]
+            ws = torch.empty(L.hfem_grid_param_ws_elems(n), dtype=F64, device=dev)
+            check(L.hfem_grid_param_bwd_ws(dev_index(dev), ptr(pd), n, ctx.x0, ctx.xN, ptr(ctx.mask), ptr(_f64(gg, "ggrid")),
+                                           ptr(ctx.saved_tensors[1]), ptr(gp), ptr(ws), stream_ptr(dev)),
+                  "hfem_grid_param_bwd_ws")
+            return gp.to(ctx.dt), None, None, None, None
         check(_lib.lib().hfem_grid_param_bwd(dev_index(dev), ptr(pd), pd.shape[0], ctx.x0, ctx.xN, ptr(ctx.mask),
                                              ptr(_f64(gg, "ggrid")), ptr(gp), stream_ptr(dev)), "hfem_grid_param_bwd")
         return gp.to(ctx.dt), None, None, None, None

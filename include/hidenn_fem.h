@@ -259,6 +259,14 @@ int hfem_grid_param_fwd(int device, const double *p, int64_t n, double x0, doubl
                         void *stream);
 int hfem_grid_param_bwd(int device, const double *p, int64_t n, double x0, double xN,
                         const uint8_t *mask, const double *ggrid, double *gp, void *stream);
+/* Same for long grids, over all CUs (three small launches each way): ws = hfem_grid_param_ws_elems(n) doubles
+ * of scratch; cum[n] is written by the forward (running sums of the clamped softplus, cum[n-1] = total) and
+ * read by the backward.                                                                              */
+int64_t hfem_grid_param_ws_elems(int64_t n);
+int hfem_grid_param_fwd_ws(int device, const double *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                           const double *initial, double *grid, double *cum, double *ws, void *stream);
+int hfem_grid_param_bwd_ws(int device, const double *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                           const double *ggrid, const double *cum, double *gp, double *ws, void *stream);
 
 /* LINE2 hat-function interpolation, src/models.py:70-90: grid[n], u[n] full
  * arrays, x_eval[m] physical points -> pred[m] and dudx[m] = (u_{e+1}-u_e)/h of the

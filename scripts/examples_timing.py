@@ -53,6 +53,10 @@ def graphed(make, n=600, per=50):
     return (time.perf_counter() - t0) / n * 1e6, loss.item()
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "--graphed-only":      # for rocprofv3: kernel mix of the captured iteration
+    which = ex1 if sys.argv[2] == "1" else ex3
+    print(graphed(which, n=200, per=50))
+    sys.exit(0)
 for name, make in (("example1 (100 nodes, 1000 samples)", ex1), ("example3 (10 001 nodes, r-adapt)", ex3)):
     a, _ = eager(make, torch.optim.Adam)
     b, _ = eager(make, FusedAdam)

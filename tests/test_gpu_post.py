@@ -57,3 +57,36 @@ def test_du_dx_per_element_matches_autograd_at_midpoints():
     ref = torch.autograd.grad(uh.sum(), xm)[0]
     assert got.device.type == "cpu" and got.shape == ref.shape
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2049, 10000, 300001])
+def test_long_grid_parametrisation_matches_the_reference_chain(n):
+    """Grids longer than one workgroup's worth take the three-launch workspace kernels: same chain as
+    src/models.py:45-56 (softplus -> clamp -> cumsum -> renormalise, optional mask), forward and backward."""
+    from oracle import ref_chain as R
+    from hidenn_fem_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    p = (torch.rand(n, generator=g, dtype=F64) * 3e-3 - 1e-3)            # some negative increments (softplus regime)
+    p[::97] = -30.0                                                       # clamp(1e-6) rows: zero gradient
+    p[5::211] = 25.0                                                      # softplus threshold rows
+    mask = torch.zeros(n + 1, dtype=torch.bool)
+    mask[0] = mask[-1] = True
+    mask[torch.randint(1, n, (n // 50,), generator=g)] = True
+    initial = torch.linspace(0.0, 10.0, n + 1, dtype=F64)
+    cot = torch.randn(n + 1, generator=g, dtype=F64)
+    assert n > ops.GRID_PARAM_ONE_BLOCK
+    for use_mask in (False, True):
+        pr = p.clone().requires_grad_(True)
+        ref = R.grid_param(pr, torch.tensor([0.0], dtype=F64), torch.tensor([10.0], dtype=F64))
+        if use_mask:
+            ref = R.masked_grid(ref, mask, initial)
+        (ref * cot).sum().backward()
+        pg = p.clone().to(d).requires_grad_(True)
+        m8 = mask.to(torch.uint8).to(d) if use_mask else None
+        got = ops.GridParamFn.apply(pg, 0.0, 10.0, m8, initial.to(d) if use_mask else None)
+        (got * cot.to(d)).sum().backward()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-12, atol=1e-13)
+        gr = pr.grad.numpy()
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), gr, rtol=1e-9, atol=1e-12 * np.abs(gr).max())

@@ -26,6 +26,10 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
 
 }  // namespace hfem
 
+namespace hfem {
+constexpr int kPipeMaxTiles = 16;   // tiles one persistent workgroup may walk (descriptors cached in LDS)
+}
+
 struct hfem_plan {
     hfem::HostPlan host;
     int device = -1;
@@ -55,7 +59,7 @@ inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6])
     return k;
 }
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
-extern int g_quad4_ablate;   // quad4.hip (lab option "quad4_ablate")
+extern int g_quad4_ablate, g_quad4_pipe;   // quad4.hip (lab option "quad4_ablate")
 
 }  // namespace hfem
 

@@ -24,6 +24,7 @@ int g_quad4_stagger_groups = 2;
 // -1 = 2 us when the launch has at least 1.5 rounds of tiles.  On a warm chip it changes nothing on Q1M (27.8 us
 // with and without; the gain first read on a cold chip was clock ramp), so the default is off.
 int g_quad4_stagger = 0, g_quad4_stagger_shift = 8;
+int g_quad4_pipe = 0;     // 0: one workgroup per tile; k > 0: persistent pipelined kernel, k workgroups per CU
 int g_quad4_ablate = 0;   // lab only: bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
 
 struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1
@@ -427,6 +428,207 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
 #undef HFEM_QSTAMP
 }
 
+// ------------------------------------------------------------------ persistent, pipelined (QUAD4)
+// The one-workgroup-per-tile kernel above spends its memory phases (gather, write-out: ~16 us on Q1M) with the
+// fp64 VALU idle and its element stage (~11 us) with the memory system idle -- the two add up.  QUAD4's element
+// stage is as long as a tile's gather latency, so a register-staged software pipeline pays here (it does not for
+// TRI3, whose element stage is a third of it: tri3_energy_pipe_kernel): a persistent workgroup walks a contiguous
+// run of tiles; the gather of tile t+1 is issued right after the barrier that starts tile t's element loop and
+// lands in VGPRs while the loop runs; tile t+2's row maps are requested at the same time; tile t's gradient stores
+// are issued last and drain under tile t+1's loop.  The element loop touches no VMEM-loaded register (its records
+// and the tile descriptors are staged through LDS), and every prefetch load is straight-line code (idle lanes clamp
+// to row 0, "no next tile" is a zero-sized tile), so the compiler emits counted vmcnt(N) waits, none inside the loop.
+// LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] | red[16] | desc[16][8] | pk[cap_elems] | pk3[cap_elems]
+template <int BLOCK, int NPT, int EPT>
+__global__ __launch_bounds__(BLOCK) void quad4_energy_pipe_kernel(
+    PlanDev pd, int tile_begin, int n_tiles, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
+    const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
+    const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
+    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int cap_elems, int skip_edges) {
+    extern __shared__ double2 lds[];
+    double2 *nd_xy = lds;
+    double2 *nd_uv = lds + cap_nodes;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
+    int *ldesc = reinterpret_cast<int *>(red + 16);                      // [kPipeMaxTiles][8]
+    uint32_t *lpk = reinterpret_cast<uint32_t *>(ldesc + 8 * kPipeMaxTiles);
+    uint32_t *lpk3 = lpk + cap_elems;
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const int w = xcd_tile(blockIdx.x, G);           // consecutive w share an XCD (L2 reuse of halos)
+    const int t0 = (int)(((long long)w * n_tiles) / G), t1 = (int)(((long long)(w + 1) * n_tiles) / G);
+    double e_loc = 0.0;
+
+    if (tid < 8 * (t1 - t0)) ldesc[tid] = reinterpret_cast<const int *>(pd.tiles + tile_begin + t0)[tid];
+    __syncthreads();
+#define HFEM_DESC(T, F) __builtin_amdgcn_readfirstlane(ldesc[8 * ((T) - t0) + (F)])
+    // TileDesc fields: 0 elem_off 1 n_elem 2 node_off 3 n_node 4 n_owned 5 edge_off 6 n_edge
+    if (t0 < t1) {
+        int d_n_node, d_n_owned, d_n_elem, d_edge_off, d_n_edge;
+        int q_n_node, q_n_owned, q_elem_off, q_n_elem, q_edge_off, q_n_edge;
+        int2 s[NPT], s1[NPT], s2[NPT];
+        static_assert(NPT == 3, "the prefetch registers are named scalars (arrays of double2 end up in scratch)");
+        double2 xy0, xy1, xy2, uv0, uv1, uv2;
+        uint32_t pkr[EPT], pkr3[EPT];
+        const int2 *nsrc = pd.node_src;
+        const uint32_t *epk = pd.elem_pack, *epk3 = pd.elem_pack_hi;
+#define HFEM_GATHER1(J, XY, UV, SRC, NN)                                                           \
+    {                                                                                              \
+        const bool ok = tid + J * BLOCK < (NN);                                                    \
+        const int ix = ok ? SRC[J].x : 0, iu = ok ? SRC[J].y : 0;                                  \
+        XY = *(ix >= 0 ? x_free + ix : x_fixed + ~ix);                                             \
+        UV = *(iu >= 0 ? u_free + iu : u_fixed + ~iu);                                             \
+    }
+#define HFEM_GATHER(SRC, NN)                                                                       \
+    HFEM_GATHER1(0, xy0, uv0, SRC, NN) HFEM_GATHER1(1, xy1, uv1, SRC, NN) HFEM_GATHER1(2, xy2, uv2, SRC, NN)
+#define HFEM_LOAD_SRC(DST, OFF, NN)                                                                \
+    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
+        const int l = tid + j * BLOCK;                                                             \
+        DST[j] = nsrc[(OFF) + (l < (NN) ? l : 0)];                                                 \
+    }
+#define HFEM_LOAD_PK(OFF, NN)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
+        const int i = tid + j * BLOCK;                                                             \
+        pkr[j] = epk[(OFF) + (i < (NN) ? i : 0)];                                                  \
+        pkr3[j] = epk3[(OFF) + (i < (NN) ? i : 0)];                                                \
+    }
+#define HFEM_STAGE1(J, XY, UV)                                                                     \
+    {                                                                                              \
+        const int l = tid + J * BLOCK;                                                             \
+        if (l < d_n_node) { nd_xy[l] = XY; nd_uv[l] = UV; }                                        \
+        if (l < d_n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }         \
+    }
+#define HFEM_STAGE()                                                                               \
+    HFEM_STAGE1(0, xy0, uv0) HFEM_STAGE1(1, xy1, uv1) HFEM_STAGE1(2, xy2, uv2)                     \
+    _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
+        const int i = tid + j * BLOCK;                                                             \
+        if (i < d_n_elem) { lpk[i] = pkr[j]; lpk3[i] = pkr3[j]; }                                  \
+    }
+        {
+            const int c_elem_off = HFEM_DESC(t0, 0), c_node_off = HFEM_DESC(t0, 2);
+            d_n_elem = HFEM_DESC(t0, 1); d_n_node = HFEM_DESC(t0, 3); d_n_owned = HFEM_DESC(t0, 4);
+            d_edge_off = HFEM_DESC(t0, 5); d_n_edge = HFEM_DESC(t0, 6);
+            const bool hn = t0 + 1 < t1;
+            const int tq = hn ? t0 + 1 : t0;
+            const int q_node_off = hn ? HFEM_DESC(tq, 2) : 0;
+            q_elem_off = hn ? HFEM_DESC(tq, 0) : 0; q_n_elem = hn ? HFEM_DESC(tq, 1) : 0;
+            q_n_node = hn ? HFEM_DESC(tq, 3) : 0; q_n_owned = hn ? HFEM_DESC(tq, 4) : 0;
+            q_edge_off = hn ? HFEM_DESC(tq, 5) : 0; q_n_edge = hn ? HFEM_DESC(tq, 6) : 0;
+            HFEM_LOAD_SRC(s, c_node_off, d_n_node)
+            HFEM_LOAD_SRC(s1, q_node_off, q_n_node)
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) s2[j] = make_int2(0, 0);
+            HFEM_LOAD_PK(c_elem_off, d_n_elem)
+            HFEM_GATHER(s, d_n_node)
+            HFEM_STAGE()
+        }
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();                       // tile t is staged
+            {
+                const bool hn2 = t + 2 < t1;
+                const int tr = hn2 ? t + 2 : t;
+                const int r_node_off = hn2 ? HFEM_DESC(tr, 2) : 0, r_n_node = hn2 ? HFEM_DESC(tr, 3) : 0;
+                HFEM_GATHER(s1, q_n_node)
+                HFEM_LOAD_PK(q_elem_off, q_n_elem)
+                HFEM_LOAD_SRC(s2, r_node_off, r_n_node)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- elements of tile t: LDS in, LDS out -- no VMEM dependence
+            const int n_owned = d_n_owned;
+#pragma unroll
+            for (int jj = 0; jj < EPT; ++jj) {
+                const int i = tid + jj * BLOCK;
+                if (i < d_n_elem && !(lpk[i] & kSkipBit)) {
+                    const uint32_t p = lpk[i];
+                    const int l[4] = {(int)(p & kLocalMask), (int)((p >> kLocalBits) & kLocalMask),
+                                      (int)((p >> (2 * kLocalBits)) & kLocalMask), (int)(lpk3[i] & kLocalMask)};
+                    double2 Xn[4], Un[4], gx[4], gu[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { Xn[j] = nd_xy[l[j]]; Un[j] = nd_uv[l[j]]; }
+                    const double e = quad4_element<true>(Xn, Un, k, gx, gu);
+                    if (p & kHomeBit) e_loc += e;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (l[j] < n_owned) {
+                            unsafeAtomicAdd(&acc0[l[j]], gx[j].x); unsafeAtomicAdd(&acc1[l[j]], gx[j].y);
+                            unsafeAtomicAdd(&acc2[l[j]], gu[j].x); unsafeAtomicAdd(&acc3[l[j]], gu[j].y);
+                        }
+                }
+            }
+            const int n_edge = skip_edges ? 0 : d_n_edge;
+            for (int i = tid; i < n_edge; i += BLOCK) {      // boundary tiles only
+                const uint32_t p = pd.edge_pack[d_edge_off + i];
+                const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
+                const double4 tt = T_edge ? T_edge[pd.edge_gid[d_edge_off + i]] : Tconst;
+                double2 gx[2], gu[2];
+                const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
+                if (p & kHomeBit) e_loc -= wk;
+                if (l0 < n_owned) {
+                    unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
+                    unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
+                }
+                if (l1 < n_owned) {
+                    unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
+                    unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
+                }
+            }
+            __syncthreads();                       // all accumulation of tile t done
+            // ---- tail: A store addresses  B accumulators -> registers  C stage tile t+1 (waits for the prefetch)
+            //      D rotate row maps  E issue the stores LAST, so they drain under the next tile's element loop
+            double2 ogx[NPT], ogu[NPT];
+            int rx[NPT], ru[NPT];                  // destination rows (-1: nothing to store); no pointer arrays (scratch)
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const int l = tid + j * BLOCK;
+                rx[j] = (l < n_owned && gx_free && s[j].x >= 0) ? s[j].x : -1;                        // A
+                ru[j] = (l < n_owned && gu_free && s[j].y >= 0) ? s[j].y : -1;
+                ogx[j] = ogu[j] = make_double2(0.0, 0.0);
+                if (l < n_owned) {                                                                   // B
+                    ogx[j] = make_double2(acc0[l], acc1[l]);
+                    ogu[j] = make_double2(acc2[l], acc3[l]);
+                }
+            }
+            d_n_node = q_n_node; d_n_owned = q_n_owned; d_n_elem = q_n_elem; d_edge_off = q_edge_off;    // C
+            d_n_edge = q_n_edge;
+            HFEM_STAGE()
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) { s[j] = s1[j]; s1[j] = s2[j]; }                          // D
+            {
+                const bool hn2 = t + 2 < t1;
+                const int tr = hn2 ? t + 2 : t;
+                q_elem_off = hn2 ? HFEM_DESC(tr, 0) : 0; q_n_elem = hn2 ? HFEM_DESC(tr, 1) : 0;
+                q_n_node = hn2 ? HFEM_DESC(tr, 3) : 0; q_n_owned = hn2 ? HFEM_DESC(tr, 4) : 0;
+                q_edge_off = hn2 ? HFEM_DESC(tr, 5) : 0; q_n_edge = hn2 ? HFEM_DESC(tr, 6) : 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {                                                          // E (sc1: write-through)
+                // branch-free: a lane with nothing to store passes an offset beyond the descriptor's range and the
+                // hardware drops it -- the compiler can then count the stores (vmcnt(N), not vmcnt(0), at the loop top)
+                const double2 vx = ogx[j], vu = ogu[j];           // scalars: taking an array element's address pins it in scratch
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&vx), rsx,
+                                                       rx[j] >= 0 ? rx[j] * 16 : (int)0x80000000, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&vu), rsu,
+                                                       ru[j] >= 0 ? ru[j] * 16 : (int)0x80000000, 0, 16);
+            }
+        }
+#undef HFEM_GATHER
+#undef HFEM_GATHER1
+#undef HFEM_STAGE1
+#undef HFEM_LOAD_SRC
+#undef HFEM_LOAD_PK
+#undef HFEM_STAGE
+    }
+#undef HFEM_DESC
+    const double tot = block_sum(e_loc, red);
+    if (tid == 0) partials[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(256) void quad4_sum_partials_kernel(const double *__restrict__ partials, int n,
                                                                  double *__restrict__ out) {
     __shared__ double red[4];
@@ -518,6 +720,23 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
                        (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger, g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps)
         const int abl = g_quad4_ablate;
+        if (g_quad4_pipe > 0 && abl == 0 && h.max_nodes <= 3 * 256 && h.max_elems <= 4 * 256 &&
+            plan->lds_bytes_pipe <= 64 * 1024) {
+            int G = g_quad4_pipe * 256;
+            if (G > n) G = n;
+            if ((n + G - 1) / G > kPipeMaxTiles) G = (n + kPipeMaxTiles - 1) / kPipeMaxTiles;
+            const int cap_elems = (h.max_elems + 3) & ~3;
+            hipLaunchKernelGGL((quad4_energy_pipe_kernel<256, 3, 4>), dim3(G), dim3(256), (size_t)plan->lds_bytes_pipe, s,
+                               plan_dev(plan), (int)tile_begin, n, (const double2 *)x_free, (const double2 *)x_fixed,
+                               (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
+                               plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
+                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned, cap_elems,
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0);
+            if (int rc = launch_status("hfem_quad4_energy_plan(pipe)")) return rc;
+            if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
+            hipLaunchKernelGGL(quad4_sum_partials_kernel, dim3(1), dim3(256), 0, s, plan->d_partials + tile_begin, G, loss_out);
+            return launch_status("hfem_quad4_energy_plan(sum)");
+        }
         const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
         if (abl == 1) HFEM_LAUNCH_Q4(4, 4, 1);                       // lab instances (hfem_set_option("quad4_ablate"))
         else if (abl == 2) HFEM_LAUNCH_Q4(4, 4, 2);

@@ -393,7 +393,6 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
 // One partial energy per workgroup.
 //   NPT >= ceil(max nodes per tile / BLOCK), EPT >= ceil(max elements per tile / BLOCK).
 // LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] double | red[16] | pk[cap_elems] u32
-constexpr int kPipeMaxTiles = 16;   // tiles one persistent workgroup may walk (descriptors cached in LDS)
 
 template <int BLOCK, int NPT, int EPT>
 __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
@@ -710,7 +709,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, p->host)) return -1;
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
-    p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + 4 * ((h.max_elems + 3) & ~3);
+    p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
     if (device >= 0) {
         if (int rc = use_device(device)) return rc;
         p->device = device;
@@ -971,6 +970,9 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "quad4_stagger_shift") {
         HFEM_ARG_CHECK(value >= 0 && value <= 20, "quad4_stagger_shift: bit of the workgroup index, 0..20");
         g_quad4_stagger_shift = value;
+    } else if (n == "quad4_pipe") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 8, "quad4_pipe: 0 (one workgroup per tile) or 1..8 persistent workgroups per CU");
+        g_quad4_pipe = value;
     } else if (n == "quad4_ablate") {
         HFEM_ARG_CHECK(value >= 0 && value <= 4, "quad4_ablate: lab variants 0..4");
         g_quad4_ablate = value;
@@ -1026,6 +1028,7 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "tiled_stagger") return g_tiled_stagger;
     if (n == "fast_stagger") return g_fast_stagger;
     if (n == "quad4_stagger") return g_quad4_stagger;
+    if (n == "quad4_pipe") return g_quad4_pipe;
     if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
     return -1;
 }

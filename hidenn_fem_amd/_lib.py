@@ -44,6 +44,7 @@ PROTOTYPES = {
     "hfem_plan_get_stats": (C.c_int, [_vp, C.POINTER(PlanStats)]),
     "hfem_plan_export": (_i64, [_vp, C.c_int, _vp, _i64]),
     "hfem_tri3_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "hfem_tri3_energy_plan_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "hfem_get_option": (C.c_int, [C.c_char_p]),
     "hfem_tri3_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

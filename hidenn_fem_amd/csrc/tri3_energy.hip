@@ -227,13 +227,15 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
 // residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
 // (forcing 64 VGPRs on them spills).
-template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0>
+// V2 = storage type of the parameter / gradient rows: double2, or float2 for fp32 models (the reference's default
+// dtype) -- rows are widened on load and rounded once on store, all arithmetic stays fp64.
+template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
-    PlanDev pd, int tile_begin, const double2 *__restrict__ x_free,
-    const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
-    const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
-    double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
-    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges, int stagger_ticks, int stagger_cfg,
+    PlanDev pd, int tile_begin, const V2 *__restrict__ x_free,
+    const V2 *__restrict__ x_fixed, const V2 *__restrict__ u_free,
+    const V2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
+    double4 Tconst, double *__restrict__ partials, V2 *__restrict__ gx_free,
+    V2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges, int stagger_ticks, int stagger_cfg,
     unsigned long long *__restrict__ stamps) {
 #define HFEM_FSTAMP(I)                                                                             \
     if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
@@ -281,8 +283,10 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
         if (l < d.n_node) {
-            nd_xy[l] = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
-            nd_uv[l] = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
+            const V2 vx = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
+            const V2 vu = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
+            nd_xy[l] = make_double2((double)vx.x, (double)vx.y);
+            nd_uv[l] = make_double2((double)vu.x, (double)vu.y);
         }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
@@ -347,6 +351,8 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     // from the XCD's L2, so the once-written gradients do not evict the re-read inputs / plan arrays);
     // 2 = nt.  (aux bits of the buffer store: sc0 = 1, nt = 2, sc1 = 16.)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr bool kWide = sizeof(V2) == 16;
     __amdgpu_buffer_rsrc_t rx, ru;
     if (SP != 0) {
         rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
@@ -355,19 +361,20 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
-        if (l < n_owned) {
-            if (SP == 0) {
-                if (gx_free && s[j].x >= 0) gx_free[s[j].x] = make_double2(acc0[l], acc1[l]);
-                if (gu_free && s[j].y >= 0) gu_free[s[j].y] = make_double2(acc2[l], acc3[l]);
-            } else {
-                if (gx_free && s[j].x >= 0) {
-                    const double2 v = make_double2(acc0[l], acc1[l]);
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, SP);
-                }
-                if (gu_free && s[j].y >= 0) {
-                    const double2 v = make_double2(acc2[l], acc3[l]);
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, SP);
-                }
+        if (l < n_owned) {                          // (accumulators are read inside each branch: 64-VGPR budget)
+            if (gx_free && s[j].x >= 0) {
+                V2 v;
+                v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
+                if (SP == 0) gx_free[s[j].x] = v;
+                else if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, SP);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, SP);
+            }
+            if (gu_free && s[j].y >= 0) {
+                V2 v;
+                v.x = acc2[l]; v.y = acc3[l];
+                if (SP == 0) gu_free[s[j].y] = v;
+                else if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, SP);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, SP);
             }
         }
     }
@@ -935,6 +942,52 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
     return launch_status("hfem_tri3_energy_plan(sum)");
+}
+
+// fp32-storage form: x/u rows and the gradient rows are float2 (an fp32 model -- the reference's default dtype --
+// without widening copies); arithmetic, LDS staging and the loss are fp64 exactly as above.  Only the
+// register-prefetched kernel at 512 threads per tile implements it; other plan shapes return an error and the
+// caller widens (hidenn_fem_amd/ops.py does).
+extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, const float *x_fixed,
+                                         const float *u_free, const float *u_fixed, const double mat[4], double W,
+                                         const double Bk[6], const double *T_edge, const double Tconst[4],
+                                         int32_t tile_begin, int32_t tile_end, double *loss_out, float *gx_free,
+                                         float *gu_free, int32_t flags, void *stream) {
+    HFEM_ARG_CHECK(plan && mat && loss_out, "null pointer");
+    HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4");
+    HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
+    const HostPlan &h = plan->host;
+    const int32_t nt = (int32_t)h.tiles.size();
+    if (tile_end < 0) tile_end = nt;
+    HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
+    HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
+    bool hasb = false;
+    for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
+    HFEM_ARG_CHECK(!hasb && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
+                   "fp32-storage path: needs a zero body force and tiles of <= 1024 nodes / 2048 element slots");
+    if (int rc = use_device(plan->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = tile_end - tile_begin;
+    if (n > 0) {
+        PlanDev pd = plan_dev(plan);
+        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+#define HFEM_LAUNCH_F32(NPT, EPT)                                                                          \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, float2>), dim3(n), dim3(512),   \
+                       (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const float2 *)x_free,             \
+                       (const float2 *)x_fixed, (const float2 *)u_free, (const float2 *)u_fixed,            \
+                       make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin, \
+                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (float2 *)gx_free,                             \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (float2 *)gu_free, h.max_nodes, h.max_owned,   \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps)
+        if (h.max_elems <= 3 * 512) HFEM_LAUNCH_F32(2, 3);
+        else HFEM_LAUNCH_F32(2, 4);
+#undef HFEM_LAUNCH_F32
+        if (int rc = launch_status("hfem_tri3_energy_plan_f32")) return rc;
+    }
+    if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
+    return launch_status("hfem_tri3_energy_plan_f32(sum)");
 }
 
 // Sum, in tile order, of the per-tile partial energies a launch with HFEM_FLAG_NO_LOSS_SUM left in the plan

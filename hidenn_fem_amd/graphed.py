@@ -23,8 +23,11 @@ class GraphedTraining:
     ``optimizer.zero_grad(set_to_none=False); loss = closure(); loss.backward(); optimizer.step()``."""
 
     def __init__(self, closure: Callable[[], torch.Tensor], optimizer: torch.optim.Optimizer, steps_per_replay: int = 1,
-                 warmup: int = 3):
+                 warmup: int = 3, direct: bool = False):
+        """``direct=True``: ``closure`` itself leaves the gradients in ``.grad`` (``EnergyLoss2D.value_and_grad_``):
+        an iteration is ``loss = closure(); optimizer.step()`` -- no ``zero_grad``, no autograd."""
         self.closure, self.optimizer, self.steps_per_replay = closure, optimizer, int(steps_per_replay)
+        self.direct = direct
         if self.steps_per_replay < 1:
             raise ValueError("steps_per_replay must be >= 1")
         self.steps_done = 0
@@ -43,6 +46,10 @@ class GraphedTraining:
         # capture does not execute: nothing to add to steps_done
 
     def _one(self):
+        if self.direct:
+            loss = self.closure()
+            self.optimizer.step()
+            return loss
         self.optimizer.zero_grad(set_to_none=False)
         loss = self.closure()
         loss.backward()

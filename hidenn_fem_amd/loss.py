@@ -124,6 +124,41 @@ class EnergyLoss2D:
         return ops.Quad4PlanEnergyFn.apply(model.node_coords_free, model.u_free, model.node_coords_fixed.to(model.dtype),
                                            model.u_fixed_rows(), plan, self._mat, Tconst)
 
+    def value_and_grad_(self, model) -> torch.Tensor:
+        """Autograd-free fast path: ONE launch writes the total potential's gradients straight into
+        ``model.node_coords_free.grad`` and ``model.u_free.grad`` (overwritten -- every free row is owned by exactly
+        one tile, so no ``zero_grad`` is needed) and returns the loss (0-d, fp64).  Default forces only (zero body
+        force, constant traction); TRI3 models.  An optimiser can step right after it; under
+        ``GraphedTraining(..., direct=True)`` a whole iteration is this launch plus the optimiser's."""
+        import ctypes as C
+        from . import _lib
+        if getattr(model, "nodes_per_element", 3) != 3:
+            raise NotImplementedError("value_and_grad_: TRI3 models")
+        xf, uf = model.node_coords_free, model.u_free
+        if xf.dtype != uf.dtype or xf.dtype not in (torch.float64, torch.float32):
+            raise RuntimeError("value_and_grad_: parameters must both be fp64 or both fp32")
+        for p in (xf, uf):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        plan = model.tile_plan(self.tile_elems)
+        f32 = xf.dtype == torch.float32
+        if f32 and (plan.stats["max_tile_nodes"] > 1024 or plan.stats["max_tile_elems"] > 2048):
+            raise RuntimeError("value_and_grad_: this tile plan has no fp32-storage kernel; use model.double()")
+        cache = getattr(self, "_direct_cache", None)
+        if cache is None or cache[0] is not model or cache[1] != xf.dtype:
+            _, Tconst = self._traction(model, None)
+            dv = lambda v: (C.c_double * len(v))(*v)
+            xfix, ufix = model.node_coords_fixed.to(xf.dtype).contiguous(), model.u_fixed_rows().to(xf.dtype).contiguous()
+            cache = self._direct_cache = (model, xf.dtype, dv(self._mat), dv([0.0] * 6), dv(Tconst), xfix, ufix,
+                                          torch.zeros((), dtype=torch.float64, device=xf.device))
+        _, _, mat, Bk, Tc, xfix, ufix, loss = cache
+        fn = _lib.lib().hfem_tri3_energy_plan_f32 if f32 else _lib.lib().hfem_tri3_energy_plan
+        flags = 0 if model.N_edges else HFEM_FLAG_NO_EDGES
+        _lib.check(fn(plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),
+                      ufix.data_ptr() if ufix.numel() else None, mat, self._W, Bk, None, Tc, 0, -1, loss.data_ptr(),
+                      xf.grad.data_ptr(), uf.grad.data_ptr(), flags, _lib.stream_ptr(xf.device)), "hfem_tri3_energy_plan")
+        return loss
+
     def __call__(self, model, b_force=None, t_force=None) -> torch.Tensor:
         """Total potential = domain - edge (loss.py:113-116), one fused launch."""
         if getattr(model, "nodes_per_element", 3) == 4:

@@ -44,8 +44,6 @@ class Tri3EnergyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_free, u_free, x_fixed, u_fixed, plan, mat, W, Bk, T_edge, Tconst, tile_range, flags):
         dev = x_free.device
-        xf, uf = _f64(x_free, "node_coords_free"), _f64(u_free, "u_free")
-        xfix, ufix = _f64(x_fixed, "node_coords_fixed"), _f64(u_fixed, "u_fixed")
         need_gx = ctx.needs_input_grad[0] and not (flags & 1)
         need_gu = ctx.needs_input_grad[1] and not (flags & 2)
         loss = torch.empty((), dtype=F64, device=dev)
@@ -53,26 +51,42 @@ class Tri3EnergyFn(torch.autograd.Function):
         lo, hi = tile_range
         full = (lo == 0 and hi in (-1, plan.n_tiles))
         alloc = torch.empty_like if full else torch.zeros_like
-        gx = alloc(xf) if need_gx else None
-        gu = alloc(uf) if need_gu else None
         fl = (flags & ~3) | (0 if need_gx else 1) | (0 if need_gu else 2)
         te = _f64(T_edge, "T_edge")
+        tcv = None if Tconst is None else _dvec(Tconst)
+        ctx.dtypes = (x_free.dtype, u_free.dtype)
+        F32 = torch.float32
+        if (x_free.dtype == F32 and u_free.dtype == F32 and not any(float(b) != 0.0 for b in Bk)
+                and plan.stats["max_tile_nodes"] <= 1024 and plan.stats["max_tile_elems"] <= 2048):
+            # fp32 model (the reference's default dtype): float rows in and out, fp64 arithmetic inside -- no widening copies
+            xf, uf = require_gpu_tensor(x_free.detach(), "node_coords_free", F32), require_gpu_tensor(u_free.detach(), "u_free", F32)
+            xfix = None if x_fixed is None else x_fixed.to(F32).contiguous()
+            ufix = None if u_fixed is None else u_fixed.to(F32).contiguous()
+            gx = alloc(xf) if need_gx else None
+            gu = alloc(uf) if need_gu else None
+            check(_lib.lib().hfem_tri3_energy_plan_f32(plan.handle, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix), _dvec(mat), float(W),
+                                                       _dvec(Bk), ptr(te), tcv, int(lo), int(hi), ptr(loss), ptr(gx), ptr(gu),
+                                                       int(fl), stream_ptr(dev)), "hfem_tri3_energy_plan_f32")
+            ctx.unit = (gx, gu)
+            return loss.to(F32)
+        xf, uf = _f64(x_free, "node_coords_free"), _f64(u_free, "u_free")
+        xfix, ufix = _f64(x_fixed, "node_coords_fixed"), _f64(u_fixed, "u_fixed")
+        gx = alloc(xf) if need_gx else None
+        gu = alloc(uf) if need_gu else None
         rc = _lib.lib().hfem_tri3_energy_plan(
             plan.handle, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix), _dvec(mat), float(W), _dvec(Bk),
-            ptr(te), None if Tconst is None else _dvec(Tconst), int(lo), int(hi), ptr(loss), ptr(gx), ptr(gu),
-            int(fl), stream_ptr(dev))
+            ptr(te), tcv, int(lo), int(hi), ptr(loss), ptr(gx), ptr(gu), int(fl), stream_ptr(dev))
         check(rc, "hfem_tri3_energy_plan")
         ctx.unit = (gx, gu)
-        ctx.dtypes = (x_free.dtype, u_free.dtype)
         return loss.to(x_free.dtype) if x_free.dtype != F64 else loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         gx, gu = ctx.unit
-        g64 = g.to(F64)
-        out_x = None if gx is None else (gx * g64).to(ctx.dtypes[0])
-        out_u = None if gu is None else (gu * g64).to(ctx.dtypes[1])
+        gs = g.to(F64) if (gx if gx is not None else gu).dtype == F64 else g.to(torch.float32)
+        out_x = None if gx is None else (gx * gs).to(ctx.dtypes[0])
+        out_u = None if gu is None else (gu * gs).to(ctx.dtypes[1])
         return (out_x, out_u) + (None,) * 10
 
 

@@ -126,6 +126,16 @@ int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, const double *x
                           const double *T_edge, const double Tconst[4],
                           int32_t tile_begin, int32_t tile_end, double *loss_out,
                           double *gx_free, double *gu_free, int32_t flags, void *stream);
+/* Same pass for an fp32 model (the reference's default dtype): x / u rows and the gradient rows are float
+ * [rows][2]; they are widened on load and rounded once on store, arithmetic and loss_out stay fp64.
+ * Needs a zero body force (Bk NULL or all zero) and the default tile shape; any other plan returns an
+ * argument error (the caller then widens to the fp64 entry point).                                   */
+int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, const float *x_fixed,
+                              const float *u_free, const float *u_fixed,
+                              const double mat[4], double W, const double Bk[6],
+                              const double *T_edge, const double Tconst[4],
+                              int32_t tile_begin, int32_t tile_end, double *loss_out,
+                              float *gx_free, float *gu_free, int32_t flags, void *stream);
 /* loss_out[0] = sum, in tile order, of the per-tile partial energies that a launch with
  * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
 int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, double *loss_out, void *stream);

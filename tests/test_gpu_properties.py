@@ -143,3 +143,41 @@ def test_cfg5_like_unstructured_4m_elements_vs_oracle():
     assert abs(acc - e_ref) <= 1e-12 * abs(e_ref)
     assert int(cover.min()) == 1 and int(cover.max()) == 1
     plan.close()
+
+
+@pytest.mark.gpu
+def test_fp32_model_takes_the_float_storage_kernel_and_matches_fp64_arithmetic():
+    """An fp32 model (the reference's default dtype) runs the float-row instance of the tiled kernel: rows are widened on
+    load, all arithmetic is fp64, gradients are rounded once on store -- so it must equal the fp64 path evaluated on the
+    same float values, rounded to fp32."""
+    import copy
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 151, jitter=0.25, seed=8, flip_fraction=0.2, dtype=torch.float32)
+    torch.manual_seed(4)
+    m32 = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.3, neumann_edges=edges).to(d)
+    with torch.no_grad():
+        m32.u_free.mul_(50.0)
+    assert m32.node_coords_free.dtype == torch.float32
+    m64 = copy.deepcopy(m32).double()
+    lf32, lf64 = EnergyLoss2D(device=d, dtype=torch.float32), EnergyLoss2D(device=d, dtype=torch.float64)
+    # an fp32 loss object carries the reference's fp32-rounded constants (C, quadrature sums); same numbers for both
+    lf64._mat, lf64._W, lf64._ci, lf64._cj = lf32._mat, lf32._W, lf32._ci, lf32._cj
+    l32 = lf32(m32)
+    l64 = lf64(m64)
+    l32.backward()
+    l64.backward()
+    assert l32.dtype == torch.float32 and m32.u_free.grad.dtype == torch.float32
+    assert l32.item() == l64.float().item()
+    for a, b in ((m32.node_coords_free.grad, m64.node_coords_free.grad), (m32.u_free.grad, m64.u_free.grad)):
+        want = b.float()
+        ulp = torch.finfo(torch.float32).eps * want.abs().clamp_min(1e-30)
+        assert ((a - want).abs() <= 1.01 * ulp).all()
+        assert (a == want).float().mean().item() > 0.99          # differences only where fp64 atomics order flips a rounding
+    # scaled upstream gradient and a tile sub-range go through the same entry point
+    m32.zero_grad()
+    (3.0 * lf32(m32)).backward()
+    want = 3.0 * m64.u_free.grad.float()
+    assert ((m32.u_free.grad - want).abs() <= 4 * torch.finfo(torch.float32).eps * want.abs().clamp_min(1e-30)).all()

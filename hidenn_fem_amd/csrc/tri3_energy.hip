@@ -417,6 +417,9 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
     int *ldesc = reinterpret_cast<int *>(red + 16);                      // [kPipeMaxTiles][8]
     uint32_t *lpk = reinterpret_cast<uint32_t *>(ldesc + 8 * kPipeMaxTiles);
 
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
     const int tid = threadIdx.x;
     const int G = gridDim.x;
     const int w = xcd_tile(blockIdx.x, G);           // consecutive w share an XCD (L2 reuse of halos)
@@ -440,17 +443,22 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
         int d_n_node, d_n_owned, d_n_elem, d_edge_off, d_n_edge;
         int q_n_node, q_n_owned, q_elem_off, q_n_elem, q_edge_off, q_n_edge;
         int2 s[NPT], s1[NPT], s2[NPT];
-        double2 xy[NPT], uv[NPT];
+        static_assert(NPT <= 4, "prefetch registers are named scalars (double2 arrays end up in scratch)");
+        double2 xy0, xy1, xy2, xy3, uv0, uv1, uv2, uv3;
+        xy0 = xy1 = xy2 = xy3 = uv0 = uv1 = uv2 = uv3 = make_double2(0.0, 0.0);
         uint32_t pkr[EPT];
         const int2 *nsrc = pd.node_src;
         const uint32_t *epk = pd.elem_pack;
-#define HFEM_GATHER(SRC, NN)                                                                       \
-    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
-        const bool ok = tid + j * BLOCK < (NN);                                                    \
-        const int ix = ok ? SRC[j].x : 0, iu = ok ? SRC[j].y : 0;                                  \
-        xy[j] = *(ix >= 0 ? x_free + ix : x_fixed + ~ix);                                          \
-        uv[j] = *(iu >= 0 ? u_free + iu : u_fixed + ~iu);                                          \
+#define HFEM_GATHER1(J, XY, UV, SRC, NN)                                                           \
+    if (J < NPT) {                                                                                 \
+        const bool ok = tid + J * BLOCK < (NN);                                                    \
+        const int ix = ok ? SRC[J < NPT ? J : 0].x : 0, iu = ok ? SRC[J < NPT ? J : 0].y : 0;      \
+        XY = *(ix >= 0 ? x_free + ix : x_fixed + ~ix);                                             \
+        UV = *(iu >= 0 ? u_free + iu : u_fixed + ~iu);                                             \
     }
+#define HFEM_GATHER(SRC, NN)                                                                       \
+    HFEM_GATHER1(0, xy0, uv0, SRC, NN) HFEM_GATHER1(1, xy1, uv1, SRC, NN)                          \
+    HFEM_GATHER1(2, xy2, uv2, SRC, NN) HFEM_GATHER1(3, xy3, uv3, SRC, NN)
 #define HFEM_LOAD_SRC(DST, OFF, NN)                                                                \
     _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
         const int l = tid + j * BLOCK;                                                             \
@@ -461,12 +469,14 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
         const int i = tid + j * BLOCK;                                                             \
         pkr[j] = epk[(OFF) + (i < (NN) ? i : 0)];                                                  \
     }
-#define HFEM_STAGE()                                                                               \
-    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
-        const int l = tid + j * BLOCK;                                                             \
-        if (l < d_n_node) { nd_xy[l] = xy[j]; nd_uv[l] = uv[j]; }                                  \
+#define HFEM_STAGE1(J, XY, UV)                                                                     \
+    if (J < NPT) {                                                                                 \
+        const int l = tid + J * BLOCK;                                                             \
+        if (l < d_n_node) { nd_xy[l] = XY; nd_uv[l] = UV; }                                        \
         if (l < d_n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }         \
-    }                                                                                              \
+    }
+#define HFEM_STAGE()                                                                               \
+    HFEM_STAGE1(0, xy0, uv0) HFEM_STAGE1(1, xy1, uv1) HFEM_STAGE1(2, xy2, uv2) HFEM_STAGE1(3, xy3, uv3) \
     _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
         const int i = tid + j * BLOCK;                                                             \
         if (i < d_n_elem) lpk[i] = pkr[j];                                                         \
@@ -553,12 +563,12 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
             //      prefetch; no store is pending yet)  D rotate row maps  E issue the stores LAST, so
             //      they drain under the next tile's element loop.
             double2 ogx[NPT], ogu[NPT];
-            double2 *dgx[NPT], *dgu[NPT];
+            int rx[NPT], ru[NPT];                  // destination rows (-1: nothing to store); no pointer arrays (scratch)
 #pragma unroll
             for (int j = 0; j < NPT; ++j) {
                 const int l = tid + j * BLOCK;
-                dgx[j] = (l < n_owned && gx_free && s[j].x >= 0) ? gx_free + s[j].x : nullptr;      // A
-                dgu[j] = (l < n_owned && gu_free && s[j].y >= 0) ? gu_free + s[j].y : nullptr;
+                rx[j] = (l < n_owned && gx_free && s[j].x >= 0) ? s[j].x : -1;                        // A
+                ru[j] = (l < n_owned && gu_free && s[j].y >= 0) ? s[j].y : -1;
                 ogx[j] = ogu[j] = make_double2(0.0, 0.0);
                 if (l < n_owned) {                                                                   // B
                     ogx[j] = make_double2(acc0[l], acc1[l]);
@@ -579,12 +589,17 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NPT; ++j) {                                                          // E
-                if (dgx[j]) *dgx[j] = ogx[j];
-                if (dgu[j]) *dgu[j] = ogu[j];
+            for (int j = 0; j < NPT; ++j) {                                                          // E (sc1, branch-free:
+                const double2 vx = ogx[j], vu = ogu[j];            // idle lanes pass an out-of-range offset, dropped by the hardware)
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&vx), rsx,
+                                                       rx[j] >= 0 ? rx[j] * 16 : (int)0x80000000, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&vu), rsu,
+                                                       ru[j] >= 0 ? ru[j] * 16 : (int)0x80000000, 0, 16);
             }
         }
 #undef HFEM_GATHER
+#undef HFEM_GATHER1
+#undef HFEM_STAGE1
 #undef HFEM_LOAD_SRC
 #undef HFEM_LOAD_PK
 #undef HFEM_STAGE

@@ -102,9 +102,12 @@ class FusedLBFGS(torch.optim.Optimizer):
         self._status = (C.c_double * 8)()
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None:
-            _lib.lib().hfem_lbfgs_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None) is not None:
+                _lib.lib().hfem_lbfgs_destroy(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: the library may already be gone
+            pass
 
     def _handle(self):
         if self._h is None:

@@ -229,17 +229,21 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // (forcing 64 VGPRs on them spills).
 // V2 = storage type of the parameter / gradient rows: double2, or float2 for fp32 models (the reference's default
 // dtype) -- rows are widened on load and rounded once on store, all arithmetic stays fp64.
-template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2>
+// CAPN / CAPO > 0: compile-time LDS array strides (nodes / owned nodes per tile, >= the plan's maxima): every LDS
+// address is then ONE scaled local id plus an immediate offset instead of a runtime base add per array.
+template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2, int CAPN = 0,
+          int CAPO = 0>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free,
     const V2 *__restrict__ x_fixed, const V2 *__restrict__ u_free,
     const V2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, V2 *__restrict__ gx_free,
-    V2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges, int stagger_ticks, int stagger_cfg,
+    V2 *__restrict__ gu_free, int cap_nodes_rt, int cap_owned_rt, int skip_edges, int stagger_ticks, int stagger_cfg,
     unsigned long long *__restrict__ stamps) {
 #define HFEM_FSTAMP(I)                                                                             \
     if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_FSTAMP(0)
+    const int cap_nodes = CAPN > 0 ? CAPN : cap_nodes_rt, cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
     double2 *nd_uv = lds + cap_nodes;
@@ -642,6 +646,7 @@ static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back
 // launch fills the chip.  Measured on a warm chip (bench.py A/B, T1M): 11.25 us without, 11.3 us with -- no gain
 // for TRI3 (its element stage is short), so the default is off.  (The tiled QUAD4 kernel does gain, quad4.hip.)
 static int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
+static int g_fast_const_caps = 1; // default tile shape: instance with compile-time LDS strides
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
 static int grid_for(int64_t n, int cap = 256 * 8) {
@@ -898,6 +903,15 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
                        (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
+#define HFEM_LAUNCH_FAST_CC(NPT, EPT, CN, CO)                                                               \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, CN, CO>), dim3(n), dim3(512), \
+                       (size_t)((CN > 0 ? CN : h.max_nodes) * 32 + CO * 32 + 128), s,                       \
+                       pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
+                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
+                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
+                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, CO,           \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
 #define HFEM_FAST_HB(BLK, NPT, EPT)                                                   \
     {                                                                                 \
         if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true);                              \
@@ -906,13 +920,21 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         fast = true;                                                                  \
     }
             const int blk = g_tiled_block;
-            if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_FAST_HB(512, 1, 2)
+            // default shape (auto tile policy: <= 557 owned nodes): compile-time stride of the four accumulator arrays
+            // (12 of an element's 18 LDS addresses); a constant node stride as well costs spills in the 64-VGPR budget.
+            // The footprint must stay <= 38 912 B (four workgroups per CU).
+            if (g_fast_const_caps && blk == 512 && !hasb && g_store_policy == 16 && h.max_nodes > 512 && h.max_owned <= 560 &&
+                h.max_nodes * 32 + 560 * 32 + 128 <= 38912 && h.max_elems <= 3 * 512) {
+                HFEM_LAUNCH_FAST_CC(2, 3, 0, 560);
+                fast = true;
+            } else if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_FAST_HB(512, 1, 2)
             else if (blk == 256 && h.max_nodes <= 2 * 256 && h.max_elems <= 4 * 256) HFEM_FAST_HB(256, 2, 4)
             else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
             else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) HFEM_FAST_HB(512, 2, 4)
             else if (blk == 256 && h.max_nodes <= 4 * 256 && h.max_elems <= 6 * 256) HFEM_FAST_HB(256, 4, 6)
             else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_FAST_HB(1024, 1, 2)
 #undef HFEM_FAST_HB
+#undef HFEM_LAUNCH_FAST_CC
 #undef HFEM_LAUNCH_FAST
 #undef HFEM_LAUNCH_FAST_SP
         }
@@ -1067,6 +1089,8 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "store_policy") {
         HFEM_ARG_CHECK(value == 0 || value == 16, "store_policy: 0 (plain) or 16 (sc1 write-through)");
         g_store_policy = value;
+    } else if (n == "fast_const_caps") {
+        g_fast_const_caps = value ? 1 : 0;
     } else if (n == "tiled_fast") {
         g_tiled_fast = value ? 1 : 0;
     } else if (n == "tiled_pipe") {

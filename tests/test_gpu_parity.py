@@ -418,7 +418,8 @@ def test_kernel_variants_agree(g_tri):
     coords, conn, geom, bc, mn, edges = structured_tri_mesh(181, 95, jitter=0.25, seed=9, dtype=F64)
     results = {}
     settings = {
-        "fast_sc1": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0),
+        "fast_sc1": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0, fast_const_caps=1),
+        "fast_runtime_strides": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0, fast_const_caps=0),
         "fast_plain": dict(tiled_fast=1, store_policy=0, tiled_block=512, tiled_pipe=0),
         "loop_256": dict(tiled_fast=0, store_policy=16, tiled_block=256, tiled_pipe=0),
         "loop_1024": dict(tiled_fast=0, store_policy=16, tiled_block=1024, tiled_pipe=0),
@@ -446,7 +447,7 @@ def test_kernel_variants_agree(g_tri):
                 assert np.abs(got[1] - ref[1]).max() <= 1e-12 * np.abs(ref[1]).max(), name
                 assert np.abs(got[2] - ref[2]).max() <= 1e-12 * np.abs(ref[2]).max(), name
     finally:
-        for k, v in dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0).items():
+        for k, v in dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0, fast_const_caps=1).items():
             L.hfem_set_option(k.encode(), v)
 
 

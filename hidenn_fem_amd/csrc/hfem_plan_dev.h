@@ -59,7 +59,7 @@ inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6])
     return k;
 }
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
-extern int g_quad4_ablate, g_quad4_pipe;   // quad4.hip (lab option "quad4_ablate")
+extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 
 }  // namespace hfem
 

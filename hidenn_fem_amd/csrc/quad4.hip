@@ -24,6 +24,7 @@ int g_quad4_stagger_groups = 2;
 // -1 = 2 us when the launch has at least 1.5 rounds of tiles.  On a warm chip it changes nothing on Q1M (27.8 us
 // with and without; the gain first read on a cold chip was clock ramp), so the default is off.
 int g_quad4_stagger = 0, g_quad4_stagger_shift = 8;
+int g_quad4_const_caps = 1;   // default tile shape: instance with a compile-time accumulator stride
 int g_quad4_pipe = 0;     // 0: one workgroup per tile; k > 0: persistent pipelined kernel, k workgroups per CU
 int g_quad4_ablate = 0;   // lab only: bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
 
@@ -276,16 +277,18 @@ __global__ __launch_bounds__(kBlockQ) void quad4_eval_bwd_kernel(
 // (8 x ds_read_b128, 4 Gauss points in registers, 16 conflict-free ds_add_f64 on owned corners),
 // every owned gradient row written once with an sc1 (write-through) store.  Element records are two
 // words per slot: {l0 | l1<<10 | l2<<20 | home<<30 | skip<<31} and {l3}.
-template <int BLOCK, int NPT, int EPT, int ABL>
+// CAPO > 0: compile-time stride of the four accumulator arrays (their LDS addresses become one scaled id + immediate).
+template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0>
 __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
     const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
-    double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges,
+    double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
     int stagger_ticks, int stagger_shift, unsigned long long *__restrict__ stamps) {
 #define HFEM_QSTAMP(I)                                                                              \
     if ((ABL & 4) && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_QSTAMP(0)
+    const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
     double2 *nd_uv = lds + cap_nodes;
@@ -743,7 +746,17 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
         else if (abl == 3) HFEM_LAUNCH_Q4(4, 4, 3);
         else if (abl == 4) HFEM_LAUNCH_Q4(4, 4, 4);                  // s_memrealtime phase stamps (scripts/stamps.py)
         else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
-        else HFEM_LAUNCH_Q4(4, 4, 0);
+        else if (g_quad4_const_caps && h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 40960) {
+            // default tile shape: compile-time accumulator stride (launched with the matching LDS size)
+            hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 4, 4, 0, 560>), dim3(n), dim3(256),
+                               (size_t)(h.max_nodes * 32 + 560 * 32 + 128), s, plan_dev(plan), (int)tile_begin,
+                               (const double2 *)x_free, (const double2 *)x_fixed, (const double2 *)u_free,
+                               (const double2 *)u_fixed, k, (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
+                               (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
+                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, 560,
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger,
+                               g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps);
+        } else HFEM_LAUNCH_Q4(4, 4, 0);
 #undef HFEM_LAUNCH_Q4
         if (int rc = launch_status("hfem_quad4_energy_plan")) return rc;
     }

@@ -1060,6 +1060,8 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "quad4_stagger_shift") {
         HFEM_ARG_CHECK(value >= 0 && value <= 20, "quad4_stagger_shift: bit of the workgroup index, 0..20");
         g_quad4_stagger_shift = value;
+    } else if (n == "quad4_const_caps") {
+        g_quad4_const_caps = value ? 1 : 0;
     } else if (n == "quad4_pipe") {
         HFEM_ARG_CHECK(value >= 0 && value <= 8, "quad4_pipe: 0 (one workgroup per tile) or 1..8 persistent workgroups per CU");
         g_quad4_pipe = value;

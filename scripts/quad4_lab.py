@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--staggers", default="0", help="phase offset in 10 ns ticks")
     ap.add_argument("--shifts", default="8", help="workgroup-index bit that selects the delayed half")
     ap.add_argument("--groups", default="2")
+    ap.add_argument("--ccaps", default="1", help="compile-time accumulator stride instance (1) or runtime strides (0)")
     ap.add_argument("--pipes", default="0", help="persistent pipelined kernel: workgroups per CU (0 = off)")
     ap.add_argument("--ablate", default="0", help="lab bits: 1 no element math, 2 no LDS atomics")
     a = ap.parse_args()
@@ -102,29 +103,31 @@ def main():
         for abl, stg, sh, grp, pipe in [(int(x), int(y), int(z), int(w), int(q)) for x in a.ablate.split(",")
                                         for y in a.staggers.split(",") for z in (a.shifts.split(",") if int(y) else ["8"])
                                         for w in (a.groups.split(",") if int(y) else ["2"]) for q in a.pipes.split(",")]:
-            _lib.check(L.hfem_set_option(b"quad4_pipe", pipe))
-            if abl == 0:                                   # correctness of the variant vs the first one
-                tiled(torch.cuda.current_stream().cuda_stream, 0)
-                torch.cuda.synchronize()
-                cur = (loss.item(), gx.clone(), gu.clone())
-                if ref is None:
-                    ref = cur
-                chk = "dl=%.1e dgx=%.1e dgu=%.1e" % (abs(cur[0] - ref[0]) / abs(ref[0]),
-                                                     (cur[1] - ref[1]).abs().max().item() / ref[1].abs().max().item(),
-                                                     (cur[2] - ref[2]).abs().max().item() / ref[2].abs().max().item())
-            _lib.check(L.hfem_set_option(b"quad4_stagger_groups", grp))
-            _lib.check(L.hfem_set_option(b"quad4_ablate", abl))
-            _lib.check(L.hfem_set_option(b"quad4_stagger", stg))
-            _lib.check(L.hfem_set_option(b"quad4_stagger_shift", sh))
-            us = time_graph(tiled, a.reps)
-            _lib.check(L.hfem_set_option(b"quad4_ablate", 0))
-            _lib.check(L.hfem_set_option(b"quad4_stagger", 0))
-            _lib.check(L.hfem_set_option(b"quad4_pipe", 0))
-            st = plan.stats
-            print(json.dumps(dict(kernel="quad4_tiled", ablate=abl, stagger=stg, shift=sh, groups=grp, pipe=pipe, check=chk if abl == 0 else "", tile_elems=T, cap=cap, us=round(us, 2),
-                                  alg_TBps=round(alg / us * 1e-6, 3), frac=round(alg / us * 1e-6 / 8.0, 3),
-                                  n_tiles=st["n_tiles"], lds=st["lds_bytes"], slots=st["tile_elem_total"],
-                                  max_nodes=st["max_tile_nodes"], max_elems=st["max_tile_elems"])), flush=True)
+          for cc in [int(c_) for c_ in a.ccaps.split(",")]:
+              _lib.check(L.hfem_set_option(b"quad4_const_caps", cc))
+              _lib.check(L.hfem_set_option(b"quad4_pipe", pipe))
+              if abl == 0:                                   # correctness of the variant vs the first one
+                  tiled(torch.cuda.current_stream().cuda_stream, 0)
+                  torch.cuda.synchronize()
+                  cur = (loss.item(), gx.clone(), gu.clone())
+                  if ref is None:
+                      ref = cur
+                  chk = "dl=%.1e dgx=%.1e dgu=%.1e" % (abs(cur[0] - ref[0]) / abs(ref[0]),
+                                                       (cur[1] - ref[1]).abs().max().item() / ref[1].abs().max().item(),
+                                                       (cur[2] - ref[2]).abs().max().item() / ref[2].abs().max().item())
+              _lib.check(L.hfem_set_option(b"quad4_stagger_groups", grp))
+              _lib.check(L.hfem_set_option(b"quad4_ablate", abl))
+              _lib.check(L.hfem_set_option(b"quad4_stagger", stg))
+              _lib.check(L.hfem_set_option(b"quad4_stagger_shift", sh))
+              us = time_graph(tiled, a.reps)
+              _lib.check(L.hfem_set_option(b"quad4_ablate", 0))
+              _lib.check(L.hfem_set_option(b"quad4_stagger", 0))
+              _lib.check(L.hfem_set_option(b"quad4_pipe", 0))
+              st = plan.stats
+              print(json.dumps(dict(kernel="quad4_tiled", ablate=abl, stagger=stg, shift=sh, groups=grp, pipe=pipe, ccaps=cc, check=chk if abl == 0 else "", tile_elems=T, cap=cap, us=round(us, 2),
+                                    alg_TBps=round(alg / us * 1e-6, 3), frac=round(alg / us * 1e-6 / 8.0, 3),
+                                    n_tiles=st["n_tiles"], lds=st["lds_bytes"], slots=st["tile_elem_total"],
+                                    max_nodes=st["max_tile_nodes"], max_elems=st["max_tile_elems"])), flush=True)
 
 
 if __name__ == "__main__":

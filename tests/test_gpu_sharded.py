@@ -113,3 +113,51 @@ def test_loss_is_bit_reproducible_and_deferred_sum_matches():
         _lib.check(L.hfem_plan_loss_sum(plan.handle, 5, nt - 9, out[6:7].data_ptr(), st))
         o = out.tolist()
         assert o[0] == o[1] == o[3] and o[2] == 0.0 and o[4] == o[6] and o[5] == 0.0 and o[4] != o[0]
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_rank_collectives():
+    """The N > 1 bench path uses torch.distributed's `nccl` backend (= RCCL on ROCm).  One GPU is all a test box has,
+    so: a 1-rank process group on the real backend, the two collectives the exchange modes issue on the very buffers
+    they issue them on (fp64 sum all-reduce of [gX|gU|loss]; all_gather_into_tensor of the interface payload), and the
+    sharded evaluator end to end."""
+    import socket
+    import torch.distributed as dist
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    assert dist.is_nccl_available()
+    d = torch.device("cuda:0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=d)
+    try:
+        coords, conn, geom, bc, mn, edges = structured_tri_mesh(101, 61, jitter=0.2, seed=1, dtype=F64)
+        torch.manual_seed(0)
+        m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                     neumann_edges=edges).to(d)
+        lf = EnergyLoss2D(device=d, dtype=F64)
+        sh = ShardedTri3Energy(m, lf).setup_interfaces()
+        assert (sh.rank, sh.world) == (0, 1)
+        loss, gx, gu = sh.value_and_grad()
+        ref = lf(m)
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 1e-13 * abs(ref.item())
+        assert (gx - m.node_coords_free.grad).abs().max().item() <= 1e-12 * gx.abs().max().item()
+        # the collectives themselves, on the exchange buffers
+        before = sh.send.clone()
+        dist.all_reduce(sh.send, op=dist.ReduceOp.SUM)
+        assert torch.equal(sh.send, before)
+        sh.evaluate_owner()
+        sh._pack()
+        dist.all_gather_into_tensor(sh.gathered, sh.payload)
+        sh._unpack()
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert abs(sh.loss_global.item() - ref.item()) <= 1e-13 * abs(ref.item())
+        assert torch.equal(sh.gathered, sh.payload)
+    finally:
+        dist.destroy_process_group()

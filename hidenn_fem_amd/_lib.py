@@ -63,6 +63,9 @@ PROTOTYPES = {
     "hfem_lbfgs_direction_ptr": (_vp, [_vp]),
     "hfem_tri3_von_mises": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),
     "hfem_line2_slopes": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "hfem_tri3_energy_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i32, _vp]),
+    "hfem_adam_prep": (C.c_int, [C.c_int, _vp, _f64, _f64, _vp, _vp]),
     "hfem_plan_loss_sum": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "hfem_iface_pack": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "hfem_iface_unpack": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _vp, _vp]),

@@ -55,6 +55,14 @@ __global__ __launch_bounds__(256) void adam_step_dev_kernel(T *__restrict__ p, c
 
 __global__ void counter_add_kernel(int64_t *c, int64_t inc) { c[0] += inc; }
 
+// step += 1; bc = {1 - b1^step, sqrt(1 - b2^step)}: the scalars of one Adam step, for kernels that fuse the update
+__global__ void adam_prep_kernel(int64_t *step, double b1, double b2, double *bc) {
+    const int64_t st = step[0] + 1;
+    step[0] = st;
+    bc[0] = 1.0 - pow(b1, (double)st);
+    bc[1] = sqrt(1.0 - pow(b2, (double)st));
+}
+
 }  // namespace hfem
 
 using namespace hfem;
@@ -107,4 +115,11 @@ extern "C" int hfem_counter_add(int device, int64_t *counter, int64_t inc, void 
     if (int rc = use_device(device)) return rc;
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
     return launch_status("hfem_counter_add");
+}
+
+extern "C" int hfem_adam_prep(int device, int64_t *step_dev, double beta1, double beta2, double *bc_dev, void *stream) {
+    HFEM_ARG_CHECK(step_dev && bc_dev, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, beta1, beta2, bc_dev);
+    return launch_status("hfem_adam_prep");
 }

@@ -227,19 +227,27 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
 // residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
 // (forcing 64 VGPRs on them spills).
+struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
+    double2 *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows); must not alias the inputs
+    double2 *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows, updated in place
+    const double *bc = nullptr;                  // device {1 - b1^step, sqrt(1 - b2^step)} of this step (hfem_adam_prep)
+    double lr_x = 0, lr_u = 0, b1 = 0.9, b2 = 0.999, eps = 1e-8;
+};
+
 // V2 = storage type of the parameter / gradient rows: double2, or float2 for fp32 models (the reference's default
 // dtype) -- rows are widened on load and rounded once on store, all arithmetic stays fp64.
 // CAPN / CAPO > 0: compile-time LDS array strides (nodes / owned nodes per tile, >= the plan's maxima): every LDS
 // address is then ONE scaled local id plus an immediate offset instead of a runtime base add per array.
+// ADAM: the write-out applies the Adam update instead of storing the gradient (struct AdamFuse below).
 template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2, int CAPN = 0,
-          int CAPO = 0>
+          int CAPO = 0, bool ADAM = false>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free,
     const V2 *__restrict__ x_fixed, const V2 *__restrict__ u_free,
     const V2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, V2 *__restrict__ gx_free,
     V2 *__restrict__ gu_free, int cap_nodes_rt, int cap_owned_rt, int skip_edges, int stagger_ticks, int stagger_cfg,
-    unsigned long long *__restrict__ stamps) {
+    unsigned long long *__restrict__ stamps, AdamFuse af) {
 #define HFEM_FSTAMP(I)                                                                             \
     if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_FSTAMP(0)
@@ -354,6 +362,39 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     // SP: cache policy of the gradient stores.  0 plain; 16 = sc1 (write-through, the line is dropped
     // from the XCD's L2, so the once-written gradients do not evict the re-read inputs / plan arrays);
     // 2 = nt.  (aux bits of the buffer store: sc0 = 1, nt = 2, sc1 = 16.)
+    if (ADAM) {
+        // Fused optimiser step (hfem_tri3_energy_adam_step): every free row is owned by exactly one tile, which holds
+        // the row's complete gradient (acc*) and its current value (nd_xy / nd_uv) in LDS -- so the tile applies
+        // torch.optim.Adam's update right here: m, v read and written in place, the NEW parameter row written to the
+        // OTHER parameter buffer (tiles still gathering this launch must keep seeing the old one: ping-pong), and the
+        // gradient never goes to memory.  Arithmetic = optim.hip's adam_step_dev_kernel, operation for operation.
+        const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];   // 1 - b1^step, sqrt(1 - b2^step): hfem_adam_prep (no pow() in here)
+        const double w1 = 1.0 - af.b1, w2 = 1.0 - af.b2;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int l = tid + j * BLOCK;
+            if (l < n_owned) {
+                const int2 rows = src[l];                  // re-read (L2 hit) rather than kept: the element stage has no VGPR to spare
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {              // c = 0: coordinates, 1: displacements
+                    const int row = c ? rows.y : rows.x;
+                    if (row < 0) continue;
+                    const double2 g = c ? make_double2(acc2[l], acc3[l]) : make_double2(acc0[l], acc1[l]);
+                    const double2 p = c ? nd_uv[l] : nd_xy[l];
+                    double2 *mp = (c ? af.mu : af.mx) + row, *vp = (c ? af.vu : af.vx) + row;
+                    const double2 m = *mp, v = *vp;
+                    const double ss = (c ? af.lr_u : af.lr_x) / bc1;
+                    double2 mn, vn, pn;
+                    mn.x = m.x + w1 * (g.x - m.x); mn.y = m.y + w1 * (g.y - m.y);
+                    vn.x = v.x * af.b2 + w2 * (g.x * g.x); vn.y = v.y * af.b2 + w2 * (g.y * g.y);
+                    pn.x = p.x - ss * (mn.x / (sqrt(vn.x) / sqrt_bc2 + af.eps));
+                    pn.y = p.y - ss * (mn.y / (sqrt(vn.y) / sqrt_bc2 + af.eps));
+                    *mp = mn; *vp = vn;
+                    (c ? af.u_out : af.x_out)[row] = pn;
+                }
+            }
+        }
+    } else {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     constexpr bool kWide = sizeof(V2) == 16;
@@ -382,6 +423,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
             }
         }
     }
+    }   // !ADAM
     HFEM_FSTAMP(6)
     if (tid == 0) {                                     // fixed order: the tile energy is bit-reproducible
         double tile_e = 0.0;
@@ -880,7 +922,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                                (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
                                make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
                                (double2 *)gx_free, (double2 *)gu_free, h.max_nodes, h.max_owned,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps);
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{});
             fast = true;
         }
         if (abl == 0 && g_tiled_fast) {
@@ -894,7 +936,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{})
 #define HFEM_LAUNCH_FAST(BLK, NPT, EPT, HB)                                                                 \
     hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
@@ -902,7 +944,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{})
 #define HFEM_LAUNCH_FAST_CC(NPT, EPT, CN, CO)                                                               \
     hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, CN, CO>), dim3(n), dim3(512), \
                        (size_t)((CN > 0 ? CN : h.max_nodes) * 32 + CO * 32 + 128), s,                       \
@@ -911,7 +953,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                        (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, CO,           \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{})
 #define HFEM_FAST_HB(BLK, NPT, EPT)                                                   \
     {                                                                                 \
         if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true);                              \
@@ -1016,7 +1058,7 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
                        make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin, \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (float2 *)gx_free,                             \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (float2 *)gu_free, h.max_nodes, h.max_owned,   \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, AdamFuse{})
         if (h.max_elems <= 3 * 512) HFEM_LAUNCH_F32(2, 3);
         else HFEM_LAUNCH_F32(2, 4);
 #undef HFEM_LAUNCH_F32
@@ -1025,6 +1067,58 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
     return launch_status("hfem_tri3_energy_plan_f32(sum)");
+}
+
+// One training step in one launch: energy + gradients as hfem_tri3_energy_plan, but the write-out applies
+// torch.optim.Adam's update (betas, eps, bias correction; no weight decay / amsgrad; one learning rate per parameter
+// tensor, as the reference's commented example-4 variant sets them) instead of storing the gradient:
+//   m, v   [rows][2] moments of node_coords_free / u_free, updated in place
+//   x_out, u_out   the NEW parameter rows -- buffers different from x_free / u_free (tiles that are still gathering
+//                  must see the old values), to be swapped with them by the caller after the launch (ping-pong)
+//   bc_dev         device {1 - beta1^step, sqrt(1 - beta2^step)} of this step: hfem_adam_prep(step counter, betas) writes it
+// loss_out = the energy at the OLD parameters, as `loss = closure(); optimizer.step()` reports it.  Whole-plan launches
+// only (every free row must be owned by a tile of the launch); default tile shape; zero body force.
+extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                                          const double *u_free, const double *u_fixed, const double mat[4], double W,
+                                          const double *T_edge, const double Tconst[4], double *x_out, double *u_out,
+                                          double *m_x, double *v_x, double *m_u, double *v_u, double lr_x, double lr_u,
+                                          double beta1, double beta2, double eps, const double *bc_dev,
+                                          double *loss_out, int32_t flags, void *stream) {
+    HFEM_ARG_CHECK(plan && mat && loss_out && x_free && u_free, "null pointer");
+    HFEM_ARG_CHECK(x_out && u_out && m_x && v_x && m_u && v_u && bc_dev, "null optimiser buffer");
+    HFEM_ARG_CHECK(x_out != x_free && u_out != u_free, "x_out / u_out must not alias the input parameters (ping-pong)");
+    HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4");
+    const HostPlan &h = plan->host;
+    HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
+    HFEM_ARG_CHECK(h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
+                   "fused Adam step: needs tiles of <= 1024 nodes / 2048 element slots");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_GX | HFEM_FLAG_NO_GU)), "fused Adam step updates both parameter tensors");
+    if (int rc = use_device(plan->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = (int)h.tiles.size();
+    if (n > 0) {
+        PlanDev pd = plan_dev(plan);
+        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+        AdamFuse af;
+        af.x_out = (double2 *)x_out; af.u_out = (double2 *)u_out;
+        af.mx = (double2 *)m_x; af.vx = (double2 *)v_x; af.mu = (double2 *)m_u; af.vu = (double2 *)v_u;
+        af.bc = bc_dev; af.lr_x = lr_x; af.lr_u = lr_u; af.b1 = beta1; af.b2 = beta2; af.eps = eps;
+#define HFEM_LAUNCH_ADAM(NPT, EPT)                                                                          \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, 0, 0, true>), dim3(n),   \
+                       dim3(512), (size_t)plan->lds_bytes, s, pd, 0, (const double2 *)x_free,               \
+                       (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,         \
+                       make_consts(mat, W, nullptr), (const double4 *)T_edge, tc, plan->d_partials,         \
+                       (double2 *)nullptr, (double2 *)nullptr, h.max_nodes, h.max_owned,                    \
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, af)
+        if (h.max_elems <= 3 * 512) HFEM_LAUNCH_ADAM(2, 3);
+        else HFEM_LAUNCH_ADAM(2, 4);
+#undef HFEM_LAUNCH_ADAM
+        if (int rc = launch_status("hfem_tri3_energy_adam_step")) return rc;
+    }
+    if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials, n, loss_out);
+    return launch_status("hfem_tri3_energy_adam_step(sum)");
 }
 
 // Sum, in tile order, of the per-tile partial energies a launch with HFEM_FLAG_NO_LOSS_SUM left in the plan

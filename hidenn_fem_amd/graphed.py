@@ -28,6 +28,8 @@ class GraphedTraining:
         an iteration is ``loss = closure(); optimizer.step()`` -- no ``zero_grad``, no autograd."""
         self.closure, self.optimizer, self.steps_per_replay = closure, optimizer, int(steps_per_replay)
         self.direct = direct
+        if optimizer is None and not direct:
+            raise ValueError("optimizer=None needs direct=True (a closure that also updates the parameters)")
         if self.steps_per_replay < 1:
             raise ValueError("steps_per_replay must be >= 1")
         self.steps_done = 0
@@ -48,7 +50,8 @@ class GraphedTraining:
     def _one(self):
         if self.direct:
             loss = self.closure()
-            self.optimizer.step()
+            if self.optimizer is not None:       # None: the closure updates the parameters itself (EnergyAdamStep.step)
+                self.optimizer.step()
             return loss
         self.optimizer.zero_grad(set_to_none=False)
         loss = self.closure()

@@ -136,6 +136,20 @@ int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, const float 
                               const double *T_edge, const double Tconst[4],
                               int32_t tile_begin, int32_t tile_end, double *loss_out,
                               float *gx_free, float *gu_free, int32_t flags, void *stream);
+/* One training step in one launch (no reference counterpart; the reference runs `loss.backward(); optimizer.step()`
+ * with torch.optim.Adam, examples/example4.py:53-64 commented variant, example1-3): the pass above, but every tile
+ * applies Adam's update to the rows it owns instead of storing their gradient.  m_*, v_* [rows][2]: moments, updated
+ * in place.  x_out / u_out: the NEW parameter rows, buffers different from x_free / u_free (swap after the launch).
+ * bc_dev: device {1 - beta1^step, sqrt(1 - beta2^step)} of this step, written by hfem_adam_prep (which also bumps the
+ * device step counter) in stream order just before.  loss_out: energy
+ * at the old parameters.  Whole plan, default tile shape, zero body force; flags: HFEM_FLAG_NO_EDGES, _NO_LOSS_SUM. */
+int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                               const double *u_free, const double *u_fixed, const double mat[4], double W,
+                               const double *T_edge, const double Tconst[4], double *x_out, double *u_out,
+                               double *m_x, double *v_x, double *m_u, double *v_u, double lr_x, double lr_u,
+                               double beta1, double beta2, double eps, const double *bc_dev,
+                               double *loss_out, int32_t flags, void *stream);
+int hfem_adam_prep(int device, int64_t *step_dev, double beta1, double beta2, double *bc_dev, void *stream);
 /* loss_out[0] = sum, in tile order, of the per-tile partial energies that a launch with
  * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
 int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, double *loss_out, void *stream);

@@ -39,3 +39,24 @@ for dt in (torch.float64, torch.float32):
     torch.cuda.synchronize()
     print(f"{dt}: autograd loss+backward {t_auto:.1f} us | value_and_grad_ {(time.perf_counter() - t0) / 500 * 1e6:.1f} us "
           f"(hipGraphs of 50)", flush=True)
+
+# full Adam training iteration at T1M, fp64: two-launch loop vs the fused step
+from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
+from hidenn_fem_amd.graphed import GraphedTraining
+coords, conn, geom, bc, mn, edges = structured_tri_mesh(1001, 501, jitter=0.2, seed=0, dtype=torch.float64)
+for mode in ("value_and_grad_ + FusedAdam", "EnergyAdamStep"):
+    torch.manual_seed(0)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    lf = EnergyLoss2D(device=d, dtype=torch.float64)
+    if mode == "EnergyAdamStep":
+        gt = GraphedTraining(EnergyAdamStep(m, lf, lr_x=1e-9, lr_u=1e-8).step, None, steps_per_replay=50, warmup=2, direct=True)
+    else:
+        opt = FusedAdam([dict(params=[m.node_coords_free], lr=1e-9), dict(params=[m.u_free], lr=1e-8)], capturable=True)
+        gt = GraphedTraining(lambda: lf.value_and_grad_(m), opt, steps_per_replay=50, warmup=2, direct=True)
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < 0.3:
+        gt.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gt.replay(10)
+    torch.cuda.synchronize()
+    print(f"Adam training iteration, T1M fp64, {mode}: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us", flush=True)

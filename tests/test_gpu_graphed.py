@@ -112,3 +112,44 @@ def test_direct_value_and_grad_matches_autograd_and_trains_in_a_graph(dtype):
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert (pa - pb).abs().max().item() <= (1e-10 if dtype == F64 else 1e-5) * pa.abs().max().item()
     assert (a.u_free - base.u_free).abs().max().item() > 0
+
+
+@pytest.mark.gpu
+def test_fused_energy_adam_step_matches_the_two_launch_loop():
+    """EnergyAdamStep: the tile that owns a row applies Adam's update at write-out (one launch per iteration, ping-pong
+    parameter buffers).  Must follow value_and_grad_ + FusedAdam with the same per-tensor learning rates, eagerly and
+    inside a hipGraph."""
+    import copy
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
+    from hidenn_fem_amd.graphed import GraphedTraining
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(161, 101, jitter=0.2, seed=3, dtype=F64)
+    torch.manual_seed(2)
+    base = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    lr_x, lr_u, n_steps = 1e-8, 1e-7, 12
+    a = copy.deepcopy(base)
+    opt = FusedAdam([dict(params=[a.node_coords_free], lr=lr_x), dict(params=[a.u_free], lr=lr_u)], capturable=True)
+    ref_losses = []
+    for _ in range(n_steps):
+        ref_losses.append(lf.value_and_grad_(a).item())
+        opt.step()
+    b = copy.deepcopy(base)
+    tr = EnergyAdamStep(b, lf, lr_x=lr_x, lr_u=lr_u)
+    got = [tr.step().item() for _ in range(n_steps)]
+    np.testing.assert_allclose(got, ref_losses, rtol=1e-11)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert (pa - pb).abs().max().item() <= 1e-11 * pa.abs().max().item()
+    assert (b.u_free - base.u_free).abs().max().item() > 0 and int(tr.state["step"].item()) == n_steps
+    # graphed: 2 warm-up + 5 replays of 2 iterations == 12 iterations
+    c = copy.deepcopy(base)
+    tr2 = EnergyAdamStep(c, lf, lr_x=lr_x, lr_u=lr_u)
+    gt = GraphedTraining(tr2.step, None, steps_per_replay=2, warmup=2, direct=True)
+    last = gt.replay(5)
+    torch.cuda.synchronize()
+    assert abs(last.item() - ref_losses[-1]) <= 1e-11 * abs(ref_losses[-1])
+    for pa, pc in zip(a.parameters(), c.parameters()):
+        assert (pa - pc).abs().max().item() <= 1e-11 * pa.abs().max().item()

@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--cpu-evals", type=int, default=2)
+    ap.add_argument("--inline-loss-sum", action="store_true", help="N = 1: reduce the tile energies with a separate "
+                    "1-block launch after every energy kernel instead of inside the next launch")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed replays before each timed leg")
     ap.add_argument("--option", action="append", default=[], help="name=value for hfem_set_option (lab A/B runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
@@ -141,7 +143,11 @@ def main():
         sh.evaluate_owner()     # interface parameter rows + partial energies (what the next evaluation needs)
         sh.exchange_halo()
 
-    step = sh.evaluate_local if world == 1 else step_owner
+    # N = 1: the energy of step k is reduced by an extra workgroup of launch k+1 (HFEM_FLAG_SUM_PREVIOUS) and the last one
+    # by a trailing 1-block launch, inside the timed region: every step's loss is produced, the reduction and its kernel
+    # boundary just leave the critical path.  --inline-loss-sum restores the separate reduction after every launch.
+    lagged = world == 1 and not a.inline_loss_sum
+    step = (sh.evaluate_local_lagged if lagged else sh.evaluate_local) if world == 1 else step_owner
 
     def sync_all():
         if world > 1:
@@ -150,6 +156,8 @@ def main():
 
     # ---- correctness guard: the benchmarked path must produce the oracle's numbers
     step()
+    if lagged:
+        sh.flush_loss()
     torch.cuda.synchronize()
     if world == 1:
         loss_gpu = sh._views(sh.send)[0].item()
@@ -170,12 +178,18 @@ def main():
             with torch.cuda.stream(s):
                 for _ in range(3):
                     step()
+                if lagged:
+                    sh.flush_loss()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                if lagged:
+                    sh.begin_lagged()
                 for _ in range(a.steps):
                     step()
+                if lagged:
+                    sh.flush_loss()
         except Exception as e:  # pragma: no cover
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
@@ -193,6 +207,8 @@ def main():
             step()
     for _ in range(a.warmup):
         step()
+    if lagged:
+        sh.flush_loss()
     if graph is not None:
         graph.replay()
     sync_all()
@@ -202,12 +218,16 @@ def main():
     else:
         for _ in range(a.steps):
             step()
+        if lagged:
+            sh.flush_loss()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=f64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    if lagged:                  # the trailing flush delivered the last step's energy: same bits as the guard evaluation
+        assert sh._views(sh.send)[0].item() == loss_gpu, (sh._views(sh.send)[0].item(), loss_gpu)
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
@@ -326,6 +346,8 @@ def main():
                         elements=ne, nodes=nn, elements_per_gpu=ne // world, tiles=st["n_tiles"],
                         tile_elems=st["tile_elems"], halo_elem_factor=st["tile_elem_total"] / max(ne, 1),
                         lds_bytes=st["lds_bytes"], launch="hipgraph" if graph is not None else "eager",
+                        loss_sum=("by an extra workgroup of the next launch (HFEM_FLAG_SUM_PREVIOUS) + one trailing "
+                                  "1-block launch" if lagged else "1-block launch after every energy kernel"),
                         exchange="none" if world == 1 else
                         f"owner-sharded: gradient rows stay with the rank whose tiles own the node; one all_gather per "
                         f"step of interface parameter rows + partial energy ({sh.interface_stats['payload_bytes']} B "

@@ -40,7 +40,9 @@ struct hfem_plan {
     int2 *d_node_src = nullptr;
     uint32_t *d_edge_pack = nullptr;
     int32_t *d_edge_gid = nullptr;
-    double *d_partials = nullptr;
+    double *d_partials = nullptr;             // two banks of [n_tiles] tile energies
+    int bank = 0;                             // bank the most recent launch wrote (host state; one plan = one stream)
+    int prev_begin = 0, prev_n = 0;           // partial range of the most recent HFEM_FLAG_NO_LOSS_SUM launch
     unsigned long long *d_stamps = nullptr;   // lab only: [n_tiles][8] s_memrealtime stamps
     int64_t device_bytes = 0;
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch

@@ -227,6 +227,12 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
 // residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
 // (forcing 64 VGPRs on them spills).
+struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
+    const double *prev = nullptr;    // partials bank the previous launch wrote (offset to its first tile)
+    int prev_n = 0;
+    double *out = nullptr;           // receives their sum (same order and bits as sum_partials_kernel)
+};
+
 struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
     double2 *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows); must not alias the inputs
     double2 *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows, updated in place
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     const V2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, V2 *__restrict__ gx_free,
     V2 *__restrict__ gu_free, int cap_nodes_rt, int cap_owned_rt, int skip_edges, int stagger_ticks, int stagger_cfg,
-    unsigned long long *__restrict__ stamps, AdamFuse af) {
+    unsigned long long *__restrict__ stamps, AdamFuse af, LagSum lag) {
 #define HFEM_FSTAMP(I)                                                                             \
     if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_FSTAMP(0)
@@ -260,7 +266,19 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     double *red = acc3 + cap_owned;
 
     const int tid = threadIdx.x;
-    const int slot = xcd_tile(blockIdx.x, gridDim.x);
+    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0);
+    if (lag.prev && (int)blockIdx.x == n_launch) {
+        // The launch's one extra workgroup: sum the tile energies the PREVIOUS launch left (other partials bank) --
+        // the 1-block reduction and the kernel boundary in front of it leave the critical path.  Same order as
+        // sum_partials_kernel (256 adders, shuffle tree, wave sums in wave order): bit-identical result.
+        double v = 0.0;
+        if (tid < 256)
+            for (int i = tid; i < lag.prev_n; i += 256) v += lag.prev[i];
+        const double tot = block_sum(v, red);
+        if (tid == 0) lag.out[0] = tot;
+        return;
+    }
+    const int slot = xcd_tile(blockIdx.x, n_launch);
     // lab (hfem_set_option("fast_stagger")): phase offset between groups of co-resident workgroups, so that one
     // group gathers while another is in its element stage.  stagger_cfg = bit | (groups - 1) << 8.
     if (stagger_ticks > 0) {
@@ -790,7 +808,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         if (!rc) rc = hfem_upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
-        if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, h.tiles.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
         if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, h.tiles.size() * 8, raw->device_bytes);
         if (!rc && p->lds_bytes_pipe > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
@@ -867,6 +885,25 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     if (int rc = use_device(plan->device)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
+    // partials banks: a launch that leaves its tile energies unsummed writes the OTHER bank, so that the next launch
+    // can reduce them with its one extra workgroup (HFEM_FLAG_SUM_PREVIOUS) while it fills this one
+    const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0;
+    HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
+    HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
+    const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
+    double *pbase = plan->d_partials + (size_t)wbank * nt;
+    LagSum lag;
+    if (lag_consume) {
+        bool hasb0 = false;
+        for (int i = 0; i < 6; ++i) hasb0 = hasb0 || (Bk && Bk[i] != 0.0);
+        HFEM_ARG_CHECK(g_tiled_fast && g_tiled_pipe == 0 && g_tiled_ablate == 0 && g_tiled_block == 512 && !hasb0 &&
+                       g_store_policy == 16 && plan->host.max_nodes <= 1024 && plan->host.max_elems <= 2048,
+                       "HFEM_FLAG_SUM_PREVIOUS: only the default (register-prefetched, 512-thread) kernel path implements it");
+        lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
+        lag.prev_n = plan->prev_n;
+        lag.out = loss_out;
+    }
+    const int n_grid = n + (lag_consume ? 1 : 0);
     if (n > 0) {
         PlanDev pd = plan_dev(plan);
         const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
@@ -881,7 +918,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes_pipe, s, \
                        pd, (int)tile_begin, n, (const double2 *)x_free, (const double2 *)x_fixed,           \
                        (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
                        (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0)
@@ -905,7 +942,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     hipLaunchKernelGGL((tri3_energy_tiled_kernel<BLK, ABL>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, pd, \
                        (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,                  \
                        (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, plan->host.max_nodes,      \
                        plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, g_tiled_stagger,         \
@@ -920,9 +957,9 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, false, true, 16>), dim3(n), dim3(512),
                                (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const double2 *)x_free,
                                (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
-                               make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
+                               make_consts(mat, W, Bk), (const double4 *)T_edge, tc, pbase + tile_begin,
                                (double2 *)gx_free, (double2 *)gu_free, h.max_nodes, h.max_owned,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{});
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, LagSum{});
             fast = true;
         }
         if (abl == 0 && g_tiled_fast) {
@@ -930,30 +967,30 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             bool hasb = false;
             for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
 #define HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, HB, SPV)                                                         \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, false, SPV>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, false, SPV>), dim3(n_grid), dim3(BLK), (size_t)plan->lds_bytes, s, \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
                        (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{})
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, lag)
 #define HFEM_LAUNCH_FAST(BLK, NPT, EPT, HB)                                                                 \
     hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
                        (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{})
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, LagSum{})
 #define HFEM_LAUNCH_FAST_CC(NPT, EPT, CN, CO)                                                               \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, CN, CO>), dim3(n), dim3(512), \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, CN, CO>), dim3(n_grid), dim3(512), \
                        (size_t)((CN > 0 ? CN : h.max_nodes) * 32 + CO * 32 + 128), s,                       \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
                        (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, plan->d_partials + tile_begin,                          \
+                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, CO,           \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{})
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, lag)
 #define HFEM_FAST_HB(BLK, NPT, EPT)                                                   \
     {                                                                                 \
         if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true);                              \
@@ -1013,13 +1050,19 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
 #undef HFEM_LAUNCH_TILED
         }
         if (int rc = launch_status("hfem_tri3_energy_plan")) return rc;
-        if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin,
+        if (flags & HFEM_FLAG_NO_LOSS_SUM) {
+            plan->bank = wbank; plan->prev_begin = tile_begin; plan->prev_n = n_partials;
+            return 0;
+        }
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase + tile_begin,
                            n_partials, loss_out);
         return launch_status("hfem_tri3_energy_plan(sum)");
     }
-    if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
+    if (flags & HFEM_FLAG_NO_LOSS_SUM) {
+        plan->bank = wbank; plan->prev_begin = tile_begin; plan->prev_n = 0;
+        return 0;
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase + tile_begin, n, loss_out);
     return launch_status("hfem_tri3_energy_plan(sum)");
 }
 
@@ -1055,17 +1098,19 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, float2>), dim3(n), dim3(512),   \
                        (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const float2 *)x_free,             \
                        (const float2 *)x_fixed, (const float2 *)u_free, (const float2 *)u_fixed,            \
-                       make_consts(mat, W, Bk), (const double4 *)T_edge, tc, plan->d_partials + tile_begin, \
+                       make_consts(mat, W, Bk), (const double4 *)T_edge, tc,                                \
+                       plan->d_partials + (size_t)plan->bank * nt + tile_begin,                             \
                        (flags & HFEM_FLAG_NO_GX) ? nullptr : (float2 *)gx_free,                             \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (float2 *)gu_free, h.max_nodes, h.max_owned,   \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, AdamFuse{})
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, AdamFuse{}, LagSum{})
         if (h.max_elems <= 3 * 512) HFEM_LAUNCH_F32(2, 3);
         else HFEM_LAUNCH_F32(2, 4);
 #undef HFEM_LAUNCH_F32
         if (int rc = launch_status("hfem_tri3_energy_plan_f32")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + tile_begin, n, loss_out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + (size_t)plan->bank * nt + tile_begin,
+                       n, loss_out);
     return launch_status("hfem_tri3_energy_plan_f32(sum)");
 }
 
@@ -1096,7 +1141,18 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
     HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_GX | HFEM_FLAG_NO_GU)), "fused Adam step updates both parameter tensors");
     if (int rc = use_device(plan->device)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int n = (int)h.tiles.size();
+    const int n = (int)h.tiles.size(), nt = n;
+    const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0;
+    HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
+    HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
+    const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
+    double *pbase = plan->d_partials + (size_t)wbank * nt;
+    LagSum lag;
+    if (lag_consume) {
+        lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
+        lag.prev_n = plan->prev_n;
+        lag.out = loss_out;
+    }
     if (n > 0) {
         PlanDev pd = plan_dev(plan);
         const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
@@ -1105,19 +1161,23 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
         af.mx = (double2 *)m_x; af.vx = (double2 *)v_x; af.mu = (double2 *)m_u; af.vu = (double2 *)v_u;
         af.bc = bc_dev; af.lr_x = lr_x; af.lr_u = lr_u; af.b1 = beta1; af.b2 = beta2; af.eps = eps;
 #define HFEM_LAUNCH_ADAM(NPT, EPT)                                                                          \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, 0, 0, true>), dim3(n),   \
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, 0, 0, true>),            \
+                       dim3(n + (lag_consume ? 1 : 0)),                                                     \
                        dim3(512), (size_t)plan->lds_bytes, s, pd, 0, (const double2 *)x_free,               \
                        (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,         \
-                       make_consts(mat, W, nullptr), (const double4 *)T_edge, tc, plan->d_partials,         \
+                       make_consts(mat, W, nullptr), (const double4 *)T_edge, tc, pbase,                    \
                        (double2 *)nullptr, (double2 *)nullptr, h.max_nodes, h.max_owned,                    \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, af)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, af, lag)
         if (h.max_elems <= 3 * 512) HFEM_LAUNCH_ADAM(2, 3);
         else HFEM_LAUNCH_ADAM(2, 4);
 #undef HFEM_LAUNCH_ADAM
         if (int rc = launch_status("hfem_tri3_energy_adam_step")) return rc;
     }
-    if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials, n, loss_out);
+    if (flags & HFEM_FLAG_NO_LOSS_SUM) {
+        plan->bank = wbank; plan->prev_begin = 0; plan->prev_n = n;
+        return 0;
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase, n, loss_out);
     return launch_status("hfem_tri3_energy_adam_step(sum)");
 }
 
@@ -1133,7 +1193,7 @@ extern "C" int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t t
     HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
     if (int rc = use_device(plan->device)) return rc;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
-                       plan->d_partials + tile_begin, tile_end - tile_begin, loss_out);
+                       plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, loss_out);
     return launch_status("hfem_plan_loss_sum");
 }
 

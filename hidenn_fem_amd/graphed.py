@@ -23,11 +23,12 @@ class GraphedTraining:
     ``optimizer.zero_grad(set_to_none=False); loss = closure(); loss.backward(); optimizer.step()``."""
 
     def __init__(self, closure: Callable[[], torch.Tensor], optimizer: torch.optim.Optimizer, steps_per_replay: int = 1,
-                 warmup: int = 3, direct: bool = False):
+                 warmup: int = 3, direct: bool = False, begin: Callable[[], None] = None, end: Callable[[], None] = None):
         """``direct=True``: ``closure`` itself leaves the gradients in ``.grad`` (``EnergyLoss2D.value_and_grad_``):
         an iteration is ``loss = closure(); optimizer.step()`` -- no ``zero_grad``, no autograd."""
         self.closure, self.optimizer, self.steps_per_replay = closure, optimizer, int(steps_per_replay)
         self.direct = direct
+        self._begin, self._end = begin or (lambda: None), end or (lambda: None)   # bracket every sequence of iterations
         if optimizer is None and not direct:
             raise ValueError("optimizer=None needs direct=True (a closure that also updates the parameters)")
         if self.steps_per_replay < 1:
@@ -36,15 +37,19 @@ class GraphedTraining:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up off the default stream (allocations,
-            for _ in range(warmup):                        # optimiser state, autograd buffers) -- these count
-                self._one()                                # as real training iterations
+            self._begin()                                  # optimiser state, autograd buffers) -- these count
+            for _ in range(warmup):                        # as real training iterations
+                self._one()
+            self._end()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.steps_done += warmup
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            self._begin()
             for _ in range(self.steps_per_replay):
                 self.loss = self._one()
+            self._end()
         # capture does not execute: nothing to add to steps_done
 
     def _one(self):

@@ -218,7 +218,25 @@ class EnergyAdamStep:
         self._flags = 0 if model.N_edges else 4          # HFEM_FLAG_NO_EDGES
         self.k = 0
 
-    def step(self) -> torch.Tensor:
+    # lagged loss (HFEM_FLAG_SUM_PREVIOUS): iteration k's energy is reduced by an extra workgroup of launch k+1
+    def begin_lagged(self):
+        self._lag_on = False
+
+    def step_lagged(self) -> torch.Tensor:
+        """``step()`` whose returned tensor holds the loss of the PREVIOUS iteration of the sequence (nothing new on the
+        first); ``flush_loss()`` delivers the last one.  Use as ``GraphedTraining(tr.step_lagged, None, ...,
+        direct=True, begin=tr.begin_lagged, end=tr.flush_loss)``."""
+        flags = 8 | (32 if getattr(self, "_lag_on", False) else 0)
+        self._lag_on = True
+        return self.step(_extra_flags=flags)
+
+    def flush_loss(self) -> torch.Tensor:
+        dev = self.loss.device
+        check(_lib.lib().hfem_plan_loss_sum(self.plan.handle, 0, -1, ptr(self.loss), stream_ptr(dev)), "hfem_plan_loss_sum")
+        self._lag_on = False
+        return self.loss
+
+    def step(self, _extra_flags: int = 0) -> torch.Tensor:
         """One iteration; returns the loss (0-d fp64 tensor, reused) at the parameters BEFORE the update."""
         L, dev = _lib.lib(), self.loss.device
         st = self.state
@@ -230,7 +248,7 @@ class EnergyAdamStep:
             ptr(self._ufix) if self._ufix.numel() else None, self._mat, float(self.loss_fn._W), None, self._Tc,
             ptr(self._x[o]), ptr(self._u[o]), ptr(st["exp_avg_x"]), ptr(st["exp_avg_sq_x"]), ptr(st["exp_avg_u"]),
             ptr(st["exp_avg_sq_u"]), self.lr_x, self.lr_u, self.betas[0], self.betas[1], self.eps, ptr(self._bc),
-            ptr(self.loss), self._flags, sp), "hfem_tri3_energy_adam_step")
+            ptr(self.loss), self._flags | _extra_flags, sp), "hfem_tri3_energy_adam_step")
         self.model.node_coords_free.data = self._x[o]
         self.model.u_free.data = self._u[o]
         self.k += 1

@@ -65,7 +65,7 @@ class ShardedTri3Energy:
         nx, nu = self._nx, self._nu
         return buf[nx + nu:nx + nu + 1], buf[:nx].view(-1, 2), buf[nx:nx + nu].view(-1, 2)
 
-    def _evaluate_hip(self, lo, hi, loss_v, gx_v, gu_v):
+    def _evaluate_hip(self, lo, hi, loss_v, gx_v, gu_v, flags=0):
         m, lf = self.model, self.loss_fn
         dev = m.node_coords_free.device
         c = getattr(self, "_consts", None)
@@ -80,13 +80,35 @@ class ShardedTri3Energy:
                                 (xfix, ufix), _lib.lib().hfem_tri3_energy_plan)
         mat, W, Bk, Tc, pxfix, pufix, _, fn = c
         rc = fn(self.plan.handle, m.node_coords_free.data_ptr(), pxfix, m.u_free.data_ptr(), pufix, mat, W, Bk, None,
-                Tc, int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), 0, _lib.stream_ptr(dev))
+                Tc, int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), int(flags), _lib.stream_ptr(dev))
         _lib.check(rc, "hfem_tri3_energy_plan")
 
     def evaluate_local(self):
         """Kernel over this rank's tiles only (no communication): fills the send buffer."""
         loss_v, gx_v, gu_v = self._views(self.send)
         self._evaluate(self.lo, self.hi, loss_v, gx_v, gu_v)
+
+    # lagged loss sum (HFEM_FLAG_SUM_PREVIOUS): the energy of evaluation k is reduced by one extra workgroup of launch
+    # k+1, so the 1-block reduction and its kernel boundary are off the critical path; flush_loss() delivers the last
+    def begin_lagged(self):
+        """Start a sequence of evaluate_local_lagged() calls (call it at the top of every captured graph)."""
+        self._lag_on = False
+
+    def evaluate_local_lagged(self):
+        """evaluate_local whose loss slot receives the energy of the PREVIOUS call of the sequence (nothing on the
+        first); gradients are this call's.  HIP only."""
+        loss_v, gx_v, gu_v = self._views(self.send)
+        self._evaluate_hip(self.lo, self.hi, loss_v, gx_v, gu_v, 8 | (32 if getattr(self, "_lag_on", False) else 0))
+        self._lag_on = True
+        return loss_v
+
+    def flush_loss(self):
+        """Energy of the last evaluate_local_lagged() call into the loss slot (one 1-block launch)."""
+        loss_v, _, _ = self._views(self.send)
+        _lib.check(_lib.lib().hfem_plan_loss_sum(self.plan.handle, int(self.lo), int(self.hi), loss_v.data_ptr(),
+                                                 _lib.stream_ptr(self.send.device)), "hfem_plan_loss_sum")
+        self._lag_on = False
+        return loss_v
 
     def exchange(self):
         """The single collective: recv = sum over ranks of send."""

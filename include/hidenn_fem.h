@@ -112,6 +112,11 @@ int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t ca
 #define HFEM_FLAG_NO_EDGES 4 /* domain energy only (EnergyLoss2D.domain_energy, src/loss.py:55-88) */
 #define HFEM_FLAG_NO_LOSS_SUM 8 /* leave the per-tile partial energies unsummed, loss_out untouched
                                    (gradient-only callers; bench.py's kernel-only roofline leg) */
+#define HFEM_FLAG_SUM_PREVIOUS 32 /* with NO_LOSS_SUM: one extra workgroup of THIS launch sums the tile energies the
+                                   * PREVIOUS NO_LOSS_SUM launch on this plan left (the plan keeps two banks) into
+                                   * loss_out -- the energy of evaluation k arrives with launch k+1, and the 1-block
+                                   * reduction + kernel boundary leave the critical path.  hfem_plan_loss_sum
+                                   * delivers the last one.  TRI3 default kernel path only.                    */
 
 /* One fwd+bwd "element-eval" pass over tiles [tile_begin, tile_end):
  *   loss_out[0]  = sum_elem A (W psi - beta)  -  sum_edge ds m        (OVERWRITTEN)

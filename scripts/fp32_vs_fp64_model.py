@@ -44,11 +44,14 @@ for dt in (torch.float64, torch.float32):
 from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
 from hidenn_fem_amd.graphed import GraphedTraining
 coords, conn, geom, bc, mn, edges = structured_tri_mesh(1001, 501, jitter=0.2, seed=0, dtype=torch.float64)
-for mode in ("value_and_grad_ + FusedAdam", "EnergyAdamStep"):
+for mode in ("value_and_grad_ + FusedAdam", "EnergyAdamStep", "EnergyAdamStep, lagged loss"):
     torch.manual_seed(0)
     m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
     lf = EnergyLoss2D(device=d, dtype=torch.float64)
-    if mode == "EnergyAdamStep":
+    if mode == "EnergyAdamStep, lagged loss":
+        tr = EnergyAdamStep(m, lf, lr_x=1e-9, lr_u=1e-8)
+        gt = GraphedTraining(tr.step_lagged, None, steps_per_replay=50, warmup=2, direct=True, begin=tr.begin_lagged, end=tr.flush_loss)
+    elif mode == "EnergyAdamStep":
         gt = GraphedTraining(EnergyAdamStep(m, lf, lr_x=1e-9, lr_u=1e-8).step, None, steps_per_replay=50, warmup=2, direct=True)
     else:
         opt = FusedAdam([dict(params=[m.node_coords_free], lr=1e-9), dict(params=[m.u_free], lr=1e-8)], capturable=True)

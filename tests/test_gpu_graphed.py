@@ -153,3 +153,14 @@ def test_fused_energy_adam_step_matches_the_two_launch_loop():
     assert abs(last.item() - ref_losses[-1]) <= 1e-11 * abs(ref_losses[-1])
     for pa, pc in zip(a.parameters(), c.parameters()):
         assert (pa - pc).abs().max().item() <= 1e-11 * pa.abs().max().item()
+    # lagged loss sum inside the graph: same trajectory, last loss delivered by the trailing flush
+    e = copy.deepcopy(base)
+    tr3 = EnergyAdamStep(e, lf, lr_x=lr_x, lr_u=lr_u)
+    gt3 = GraphedTraining(tr3.step_lagged, None, steps_per_replay=4, warmup=2, direct=True, begin=tr3.begin_lagged,
+                          end=tr3.flush_loss)
+    gt3.replay(2)
+    torch.cuda.synchronize()
+    assert abs(tr3.loss.item() - ref_losses[9]) <= 1e-11 * abs(ref_losses[9])      # 2 + 8 iterations: loss of the 10th
+    tr3.step(); tr3.step()
+    for pa, pe in zip(a.parameters(), e.parameters()):
+        assert (pa - pe).abs().max().item() <= 1e-11 * pa.abs().max().item()

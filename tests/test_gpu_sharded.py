@@ -161,3 +161,77 @@ def test_rccl_backend_single_rank_collectives():
         assert torch.equal(sh.gathered, sh.payload)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_lagged_loss_sum_delivers_every_energy_bit_exactly():
+    """HFEM_FLAG_SUM_PREVIOUS: the energy of evaluation k is reduced by an extra workgroup of launch k+1 (two partials
+    banks), the last one by hfem_plan_loss_sum.  With the inputs changing before every launch, eagerly and back to back in
+    a hipGraph, on the full plan and on a tile sub-range, every delivered energy must equal the inline sum's bits."""
+    import ctypes as C
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(501, 301, jitter=0.2, seed=4, dtype=F64)
+    torch.manual_seed(1)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    plan = m.tile_plan(lf.tile_elems)
+    L = _lib.lib()
+    dv = lambda v: (C.c_double * len(v))(*v)
+    _, Tconst = lf._traction(m, None)
+    xf, uf, xfix, ufix = m.node_coords_free.detach(), m.u_free.detach(), m.node_coords_fixed, m.u_fixed_rows()
+    gx, gu = torch.empty_like(xf), torch.empty_like(uf)
+    nt, K = plan.n_tiles, 40
+    assert nt > 200
+
+    def run(out, lo, hi, flags, stream):
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr(), uf.data_ptr(), ufix.data_ptr(),
+                                           dv(lf._mat), lf._W, dv([0.0] * 6), None, dv(Tconst), lo, hi, out.data_ptr(),
+                                           gx.data_ptr(), gu.data_ptr(), flags, stream), "energy")
+
+    for lo, hi in ((0, -1), (11, nt - 7)):
+        scales = [1.0 + 1e-3 * ((i % 7) - 3) for i in range(2 * K)]
+        want = torch.zeros(2 * K, dtype=F64, device=d)
+        uf0 = uf.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        for i in range(2 * K):                                   # inline sums: the reference sequence
+            uf.mul_(scales[i])
+            run(want[i:i + 1], lo, hi, 0, st)
+        torch.cuda.synchronize()
+        uf.copy_(uf0)
+        got = torch.zeros(2 * K, dtype=F64, device=d)
+        for i in range(K):                                       # eager lagged sequence: loss k arrives with launch k+1
+            uf.mul_(scales[i])
+            run(got[max(i - 1, 0):max(i - 1, 0) + 1], lo, hi, 8 | (32 if i else 0), st)
+        _lib.check(L.hfem_plan_loss_sum(plan.handle, lo, hi, got[K - 1:K].data_ptr(), st))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()                               # the second half back to back inside one graph
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        scratch = torch.zeros(1, dtype=F64, device=d)
+        with torch.cuda.stream(s):
+            run(scratch, lo, hi, 0, s.cuda_stream)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            cs = torch.cuda.current_stream().cuda_stream
+            for i in range(K, 2 * K):
+                uf.mul_(scales[i])
+                j = max(i - 1, K)
+                run(got[j:j + 1], lo, hi, 8 | (32 if i > K else 0), cs)
+            _lib.check(L.hfem_plan_loss_sum(plan.handle, lo, hi, got[2 * K - 1:2 * K].data_ptr(), cs))
+        g.replay()
+        torch.cuda.synchronize()
+        assert want.unique().numel() > K
+        bad = (got != want).nonzero().flatten()
+        assert bad.numel() == 0, f"range {(lo, hi)}: {bad.numel()} wrong lagged energies, first {bad[:5].tolist()}"
+        uf.copy_(uf0)
+    with pytest.raises(RuntimeError):                            # nothing to consume on a fresh plan
+        m2 = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0).to(d)
+        p2 = m2.tile_plan(0)
+        _lib.check(L.hfem_tri3_energy_plan(p2.handle, m2.node_coords_free.data_ptr(), m2.node_coords_fixed.data_ptr(),
+                                           m2.u_free.data_ptr(), m2.u_fixed_rows().data_ptr(), dv(lf._mat), lf._W,
+                                           dv([0.0] * 6), None, dv(Tconst), 0, -1, scratch.data_ptr(), None, None, 8 | 32 | 3, st))

@@ -143,10 +143,10 @@ class ShardedTri3Energy:
         n_tiles = td.shape[0]
         bounds = np.array([plan.shard_range(r, world)[0] for r in range(world)] + [n_tiles], dtype=np.int64)
         tile_rank = np.searchsorted(bounds, np.arange(n_tiles), side="right") - 1
-        if not np.array_equal(td[:, 2], np.concatenate([[0], np.cumsum(td[:, 3])[:-1]])):
-            raise RuntimeError("tile plan: node slots are not laid out tile after tile")
-        slot_tile = np.repeat(np.arange(n_tiles), td[:, 3])                      # tile of every node slot
-        slot_local = np.arange(ns.shape[0]) - np.repeat(td[:, 2], td[:, 3])
+        counts = td[:, 3]
+        slot_tile = np.repeat(np.arange(n_tiles), counts)                        # tile of every (real) node slot
+        slot_local = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
+        ns = ns[np.repeat(td[:, 2], counts) + slot_local]                        # compact or fixed-stride layout alike
         slot_owned = slot_local < td[slot_tile, 4]
         slot_rank = tile_rank[slot_tile]
         publish, need = [], []                      # per array (x, u): publish[r] rows, need = (rows, owner rank)

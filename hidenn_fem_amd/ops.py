@@ -316,7 +316,8 @@ class Line2MseFn(torch.autograd.Function):
         gd, ud = _f64(grid, "grid"), _f64(u_full, "u_full")
         xd, td = _f64(x_eval.reshape(-1), "x_eval"), _f64(target.reshape(-1), "target")
         loss = torch.zeros((), dtype=F64, device=dev)
-        ggrid, gu = torch.zeros_like(gd), torch.zeros_like(ud)
+        ggrid = torch.zeros_like(gd) if ctx.needs_input_grad[0] else None       # fixed grid: no grid-gradient atomics
+        gu = torch.zeros_like(ud) if ctx.needs_input_grad[1] else None
         check(_lib.lib().hfem_line2_mse(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), ptr(td), xd.shape[0],
                                         ptr(loss), ptr(ggrid), ptr(gu), stream_ptr(dev)), "hfem_line2_mse")
         ctx.unit, ctx.dts = (ggrid, gu), (grid.dtype, u_full.dtype)
@@ -327,7 +328,8 @@ class Line2MseFn(torch.autograd.Function):
     def backward(ctx, g):
         ggrid, gu = ctx.unit
         g64 = g.to(F64)
-        return (ggrid * g64).to(ctx.dts[0]), (gu * g64).to(ctx.dts[1]), None, None
+        return (None if ggrid is None else (ggrid * g64).to(ctx.dts[0]),
+                None if gu is None else (gu * g64).to(ctx.dts[1]), None, None)
 
 
 class RectQ4EvalFn(torch.autograd.Function):
@@ -368,7 +370,11 @@ class RectQ4MseFn(torch.autograd.Function):
         gxd, gyd, ud = _f64(gx, "grid_x"), _f64(gy, "grid_y"), _f64(u_full, "u_full")
         xd, td = _f64(x_eval, "x_eval"), _f64(target.reshape(-1), "target")
         loss = torch.zeros((), dtype=F64, device=dev)
-        ggx, ggy, gu = torch.zeros_like(gxd), torch.zeros_like(gyd), torch.zeros_like(ud)
+        # only the gradients somebody asked for: with fixed nodes the grid gradients are M x 4 atomics onto a few
+        # hundred addresses (most of the kernel's time at M = 262 144) for nothing
+        ggx = torch.zeros_like(gxd) if ctx.needs_input_grad[0] else None
+        ggy = torch.zeros_like(gyd) if ctx.needs_input_grad[1] else None
+        gu = torch.zeros_like(ud) if ctx.needs_input_grad[2] else None
         check(_lib.lib().hfem_rectq4_mse(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
                                          ptr(xd), ptr(td), xd.shape[0], ptr(loss), ptr(ggx), ptr(ggy), ptr(gu),
                                          stream_ptr(dev)), "hfem_rectq4_mse")
@@ -379,7 +385,7 @@ class RectQ4MseFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         g64 = g.to(F64)
-        return tuple((t * g64).to(dt) for t, dt in zip(ctx.unit, ctx.dts)) + (None, None)
+        return tuple(None if t is None else (t * g64).to(dt) for t, dt in zip(ctx.unit, ctx.dts)) + (None, None)
 
 
 # ---------------------------------------------------------------- QUAD4-iso extension (planless)

@@ -261,7 +261,8 @@ class Line2EvalFn(torch.autograd.Function):
         dev = grid.device
         gd, ud, xd = _f64(grid, "grid"), _f64(u_full, "u_full"), _f64(x_eval.reshape(-1), "x_eval")
         m = xd.shape[0]
-        ggrid, gu = torch.zeros_like(gd), torch.zeros_like(ud)
+        ggrid = torch.zeros_like(gd) if ctx.needs_input_grad[0] else None     # only what autograd asks for
+        gu = torch.zeros_like(ud) if ctx.needs_input_grad[1] else None
         gx = torch.empty_like(xd) if ctx.needs_input_grad[2] else None
         cp = None if g_pred is None else _f64(g_pred.reshape(-1), "g_pred")
         cdd = None if g_dudx is None else _f64(g_dudx.reshape(-1), "g_dudx")
@@ -279,7 +280,7 @@ class Line2EvalFn(torch.autograd.Function):
                 gxe = g_pred * d
             else:
                 gxe = gx.reshape(x_eval.shape).to(x_eval.dtype)
-        return ggrid.to(ctx.dt), gu.to(u_full.dtype), gxe
+        return (None if ggrid is None else ggrid.to(ctx.dt), None if gu is None else gu.to(u_full.dtype), gxe)
 
 
 class BarEnergyFn(torch.autograd.Function):
@@ -352,13 +353,15 @@ class RectQ4EvalFn(torch.autograd.Function):
     def backward(ctx, g):
         gxd, gyd, ud, xd = ctx.saved_tensors
         dev = gxd.device
-        ggx, ggy, gu = torch.zeros_like(gxd), torch.zeros_like(gyd), torch.zeros_like(ud)
+        ggx = torch.zeros_like(gxd) if ctx.needs_input_grad[0] else None      # only what autograd asks for
+        ggy = torch.zeros_like(gyd) if ctx.needs_input_grad[1] else None
+        gu = torch.zeros_like(ud) if ctx.needs_input_grad[2] else None
         gxe = torch.empty_like(xd) if ctx.needs_input_grad[3] else None
         check(_lib.lib().hfem_rectq4_eval_bwd(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
                                               ptr(xd), xd.shape[0], ptr(_f64(g, "grad")), ptr(ggx), ptr(ggy), ptr(gu),
                                               ptr(gxe), stream_ptr(dev)), "hfem_rectq4_eval_bwd")
         d = ctx.dts
-        return ggx.to(d[0]), ggy.to(d[1]), gu.to(d[2]), None if gxe is None else gxe.to(d[3])
+        return tuple(None if t is None else t.to(dt) for t, dt in zip((ggx, ggy, gu, gxe), d))
 
 
 class RectQ4MseFn(torch.autograd.Function):

@@ -128,13 +128,14 @@ class EnergyLoss2D:
         """Autograd-free fast path: ONE launch writes the total potential's gradients straight into
         ``model.node_coords_free.grad`` and ``model.u_free.grad`` (overwritten -- every free row is owned by exactly
         one tile, so no ``zero_grad`` is needed) and returns the loss (0-d, fp64).  Default forces only (zero body
-        force, constant traction); TRI3 models.  An optimiser can step right after it; under
+        force, constant traction); TRI3 models (fp64 or fp32 rows) and fp64 QUAD4 models.  An optimiser can step right after it; under
         ``GraphedTraining(..., direct=True)`` a whole iteration is this launch plus the optimiser's."""
         import ctypes as C
         from . import _lib
-        if getattr(model, "nodes_per_element", 3) != 3:
-            raise NotImplementedError("value_and_grad_: TRI3 models")
+        quad = getattr(model, "nodes_per_element", 3) == 4
         xf, uf = model.node_coords_free, model.u_free
+        if quad and xf.dtype != torch.float64:
+            raise RuntimeError("value_and_grad_: QUAD4 models must be fp64 (model.double())")
         if xf.dtype != uf.dtype or xf.dtype not in (torch.float64, torch.float32):
             raise RuntimeError("value_and_grad_: parameters must both be fp64 or both fp32")
         for p in (xf, uf):
@@ -152,8 +153,14 @@ class EnergyLoss2D:
             cache = self._direct_cache = (model, xf.dtype, dv(self._mat), dv([0.0] * 6), dv(Tconst), xfix, ufix,
                                           torch.zeros((), dtype=torch.float64, device=xf.device))
         _, _, mat, Bk, Tc, xfix, ufix, loss = cache
-        fn = _lib.lib().hfem_tri3_energy_plan_f32 if f32 else _lib.lib().hfem_tri3_energy_plan
         flags = 0 if model.N_edges else HFEM_FLAG_NO_EDGES
+        if quad:                                     # QUAD4-iso extension: same contract, tiled QUAD4 kernel
+            _lib.check(_lib.lib().hfem_quad4_energy_plan(
+                plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),
+                ufix.data_ptr() if ufix.numel() else None, mat, None, Tc, 0, -1, loss.data_ptr(), xf.grad.data_ptr(),
+                uf.grad.data_ptr(), flags, _lib.stream_ptr(xf.device)), "hfem_quad4_energy_plan")
+            return loss
+        fn = _lib.lib().hfem_tri3_energy_plan_f32 if f32 else _lib.lib().hfem_tri3_energy_plan
         _lib.check(fn(plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),
                       ufix.data_ptr() if ufix.numel() else None, mat, self._W, Bk, None, Tc, 0, -1, loss.data_ptr(),
                       xf.grad.data_ptr(), uf.grad.data_ptr(), flags, _lib.stream_ptr(xf.device)), "hfem_tri3_energy_plan")

@@ -77,6 +77,14 @@ def test_quad4_kernels_match_the_autograd_oracle():
     assert abs(loss_p.item() - ref.item()) <= 1e-12 * abs(ref.item())
     assert np.abs(m.node_coords_free.grad.cpu().numpy() - gx).max() <= 1e-10 * np.abs(gx).max()
     assert np.abs(m.u_free.grad.cpu().numpy() - gu).max() <= 1e-10 * np.abs(gu).max()
+    # autograd-free form: gradients straight into .grad
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.grad.fill_(3.0)
+    loss_d = lf.value_and_grad_(m)
+    assert abs(loss_d.item() - ref.item()) <= 1e-12 * abs(ref.item())
+    assert np.abs(m.node_coords_free.grad.cpu().numpy() - gx).max() <= 1e-10 * np.abs(gx).max()
+    assert np.abs(m.u_free.grad.cpu().numpy() - gu).max() <= 1e-10 * np.abs(gu).max()
     # per-point forward / backward with the (x_ref, element_id) contract
     g = torch.Generator().manual_seed(5)
     M = 700

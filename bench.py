@@ -140,8 +140,7 @@ def main():
         sh.exchange()
 
     def step_owner():           # owner-sharded: gradient rows stay with their owner; ONE all_gather of the
-        sh.evaluate_owner()     # interface parameter rows + partial energies (what the next evaluation needs)
-        sh.exchange_halo()
+        sh.owner_step()         # interface parameter rows + partial energies (what the next evaluation needs)
 
     # N = 1: the energy of step k is reduced by an extra workgroup of launch k+1 (HFEM_FLAG_SUM_PREVIOUS) and the last one
     # by a trailing 1-block launch, inside the timed region: every step's loss is produced, the reduction and its kernel

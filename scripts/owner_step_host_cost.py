@@ -14,7 +14,8 @@ f64 = torch.float64
 coords, conn, geom, bc, mn, edges = structured_tri_mesh(1001, 501, jitter=0.2, seed=0, dtype=f64)
 m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
 sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=f64)).setup_interfaces()
-for name, fn in (("evaluate_local", sh.evaluate_local), ("evaluate_owner+exchange_halo", lambda: (sh.evaluate_owner(), sh.exchange_halo()))):
+for name, fn in (("evaluate_local", sh.evaluate_local), ("evaluate_owner+exchange_halo", lambda: (sh.evaluate_owner(), sh.exchange_halo())),
+                 ("owner_step (hoisted lookups)", sh.owner_step)):
     for _ in range(200):
         fn()
     torch.cuda.synchronize()

@@ -159,6 +159,12 @@ def test_rccl_backend_single_rank_collectives():
         torch.cuda.synchronize()
         assert abs(sh.loss_global.item() - ref.item()) <= 1e-13 * abs(ref.item())
         assert torch.equal(sh.gathered, sh.payload)
+        # the hoisted-lookup form bench.py times is the same step
+        sh.loss_global.zero_()
+        loss_s, gx_s, gu_s = sh.owner_step()
+        torch.cuda.synchronize()
+        assert loss_s.item() == ref.item() or abs(loss_s.item() - ref.item()) <= 1e-13 * abs(ref.item())
+        assert (gx_s - m.node_coords_free.grad).abs().max().item() <= 1e-12 * gx_s.abs().max().item()
     finally:
         dist.destroy_process_group()
 

@@ -1,0 +1,78 @@
+"""Edge cases of the newer entry points through the C ABI: empty and minimal inputs, argument errors that must come
+back as error codes (never a fault), tiny optimiser problems."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+F64 = torch.float64
+
+
+@pytest.mark.gpu
+def test_empty_and_minimal_inputs_are_handled_by_the_abi():
+    from hidenn_fem_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    z = torch.zeros(8, dtype=F64, device=d)
+    i32 = torch.zeros(4, dtype=torch.int32, device=d)
+    # zero elements / zero rows / a single-node grid: success, nothing written
+    assert L.hfem_tri3_von_mises(0, None, None, None, 0, 1e9, 0.3, None, None, st) == 0
+    assert L.hfem_line2_slopes(0, z.data_ptr(), z.data_ptr(), 1, 1, z.data_ptr(), st) == 0
+    assert L.hfem_iface_pack(0, None, None, None, 0, 0, None, st) == 0
+    assert L.hfem_lbfgs_apply(None, None, 0, 0, st) != 0                     # null handle: an error code, not a crash
+    assert b"null" in L.hfem_last_error()
+    # unpack with no rows still sums the partial energies of `world` payloads
+    recv = torch.tensor([[1.5, 0.0], [2.25, 0.0], [4.0, 0.0]], dtype=F64, device=d)      # stride 1: only loss slots
+    out = torch.zeros(1, dtype=F64, device=d)
+    assert L.hfem_iface_unpack(0, recv.data_ptr(), None, None, 0, 0, None, None, 3, 1, 0, out.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert out.item() == 7.75
+    # argument errors
+    assert L.hfem_iface_unpack(0, recv.data_ptr(), None, None, 0, 0, None, None, 3, 1, 1, out.data_ptr(), st) != 0   # slot >= stride
+    h = C.c_void_p()
+    assert L.hfem_lbfgs_create(0, 0, 10, 0, C.byref(h)) != 0 and not h.value
+    assert L.hfem_lbfgs_create(0, 5, 0, 0, C.byref(h)) != 0
+    assert L.hfem_lbfgs_create(0, 5, 4, 7, C.byref(h)) != 0
+    assert L.hfem_grid_param_ws_elems(0) >= 8 and L.hfem_grid_param_ws_elems(5000) >= 5000
+    assert L.hfem_adam_prep(0, None, 0.9, 0.999, None, st) != 0
+    # one-increment grid through the workspace kernels: grid = {x0, xN}, gradient 0 (renormalisation kills it)
+    p = torch.tensor([0.3], dtype=F64, device=d)
+    grid, cum = torch.zeros(2, dtype=F64, device=d), torch.zeros(1, dtype=F64, device=d)
+    ws = torch.zeros(L.hfem_grid_param_ws_elems(1), dtype=F64, device=d)
+    assert L.hfem_grid_param_fwd_ws(0, p.data_ptr(), 1, 2.0, 5.0, None, None, grid.data_ptr(), cum.data_ptr(), ws.data_ptr(), st) == 0
+    gg, gp = torch.tensor([1.0, -2.0], dtype=F64, device=d), torch.zeros(1, dtype=F64, device=d)
+    assert L.hfem_grid_param_bwd_ws(0, p.data_ptr(), 1, 2.0, 5.0, None, gg.data_ptr(), cum.data_ptr(), gp.data_ptr(), ws.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert grid.tolist() == [2.0, 5.0] and abs(gp.item()) <= 1e-15
+
+
+@pytest.mark.gpu
+def test_lbfgs_on_tiny_problems():
+    """n = 1 and n = 3 parameters (fewer than one wave, history longer than the problem is wide): same iterates as torch."""
+    from hidenn_fem_amd.optim import FusedLBFGS
+    d = torch.device("cuda:0")
+    for n in (1, 3):
+        A = torch.diag(torch.linspace(1.0, 4.0, n, dtype=F64)).to(d)
+        b = torch.arange(1, n + 1, dtype=F64, device=d)
+
+        def run(cls):
+            p = torch.nn.Parameter(torch.full((n,), 2.0, dtype=F64, device=d))
+            opt = cls([p])
+            out = []
+
+            def closure():
+                opt.zero_grad()
+                loss = 0.5 * p @ (A @ p) - b @ p + 0.1 * (p ** 4).sum()
+                loss.backward()
+                return loss
+
+            for _ in range(3):
+                out.append(opt.step(closure).item())
+            return out, p.detach().cpu().numpy()
+
+        ref_l, ref_p = run(torch.optim.LBFGS)
+        got_l, got_p = run(FusedLBFGS)
+        np.testing.assert_allclose(got_l, ref_l, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(got_p, ref_p, rtol=1e-8, atol=1e-10)

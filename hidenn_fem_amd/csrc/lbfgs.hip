@@ -202,7 +202,9 @@ __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *_
         sv[k] = (ns >= 0 && i < n) ? (double)Sring[(int64_t)ns * n + i] : 0.0;
         yv[k] = (ns >= 0 && i < n) ? (double)Yring[(int64_t)ns * n + i] : 0.0;
     }
-    for (int l = 0; l < count; ++l) {
+    // gridDim.y workgroups share a chunk and take the slots l = blockIdx.y, + gridDim.y, ...: short vectors (few
+    // chunks) still fill the chip; each (chunk, slot) partial is produced by exactly one workgroup, in the same order
+    for (int l = blockIdx.y; l < count; l += gridDim.y) {
         const int slot = (head + l) % M1;
         const T *Yj = Yring + (int64_t)slot * n, *Sj = Sring + (int64_t)slot * n;
         double acc[5] = {0, 0, 0, 0, 0};
@@ -250,9 +252,10 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
     __shared__ double red[kLb / 64];
     LbfgsState &S = *A.st;
     const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x;
+    const int nthr = blockDim.x;         // launched with ONE wave: the 2 x count sequential steps then sync at wave cost
     // Gram row / column of the new pair
     if (ns >= 0) {
-        for (int l = tid; l < count; l += kLb) {
+        for (int l = tid; l < count; l += nthr) {
             const int j = (head + l) % M1;
             A.SY[ns * M1 + j] = A.dots[j * 5 + 2];        // s_new . y_j
             A.SY[j * M1 + ns] = A.dots[j * 5 + 4];        // s_j . y_new
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
     for (int l = count - 1; l >= 0; --l) {
         const int i = (head + l) % M1;
         double v = 0.0;
-        for (int l2 = l + 1 + tid; l2 < count; l2 += kLb) {
+        for (int l2 = l + 1 + tid; l2 < count; l2 += nthr) {
             const int j = (head + l2) % M1;
             v += A.al[j] * A.SY[i * M1 + j];
         }
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
     for (int l = 0; l < count; ++l) {
         const int i = (head + l) % M1;
         double v = 0.0, w = 0.0;
-        for (int l2 = tid; l2 < count; l2 += kLb) {
+        for (int l2 = tid; l2 < count; l2 += nthr) {
             const int j = (head + l2) % M1;
             v += A.al[j] * A.YY[i * M1 + j];
             if (l2 < l) w += A.cs[j] * A.SY[j * M1 + i];
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
     }
     // g.d = -H g.g + sum_j (-H al_j) y_j.g + sum_j c_j s_j.g
     double v = 0.0;
-    for (int l = tid; l < count; l += kLb) {
+    for (int l = tid; l < count; l += nthr) {
         const int j = (head + l) % M1;
         const double cyj = -H * A.al[j];
         A.cy[j] = cyj;
@@ -309,32 +312,35 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
 }
 
 // ---- d = cg g + sum_j cy_j Y_j + cs_j S_j (one pass over the history), max|d| partials [nb]
-template <typename T>
+// PER elements per thread: 8 for long vectors (fewer, fatter workgroups), 1 for short ones (more workgroups); the slot
+// loop is unrolled so that several slots' loads are in flight (it is latency-bound otherwise).  Same sums either way.
+template <typename T, int PER>
 __global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
                                                         const T *__restrict__ Yring, T *__restrict__ d, int64_t n, int M1) {
     const LbfgsState &S = *A.st;
     const int count = S.count, head = S.head;
-    const int64_t base = (int64_t)blockIdx.x * kLbChunk + threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * (kLb * PER) + threadIdx.x;
     const double cg = S.cg;
-    double acc[kLbPer];
+    double acc[PER];
 #pragma unroll
-    for (int k = 0; k < kLbPer; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const int64_t i = base + (int64_t)k * kLb;
         acc[k] = i < n ? cg * (double)g[i] : 0.0;
     }
+#pragma unroll 4
     for (int l = 0; l < count; ++l) {
         const int slot = (head + l) % M1;
         const double cy = A.cy[slot], cs = A.cs[slot];
         const T *Yj = Yring + (int64_t)slot * n, *Sj = Sring + (int64_t)slot * n;
 #pragma unroll
-        for (int k = 0; k < kLbPer; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int64_t i = base + (int64_t)k * kLb;
             if (i < n) acc[k] += cy * (double)Yj[i] + cs * (double)Sj[i];
         }
     }
     double mx = 0.0;
 #pragma unroll
-    for (int k = 0; k < kLbPer; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const int64_t i = base + (int64_t)k * kLb;
         if (i < n) {
             const T v = (T)acc[k];
@@ -439,7 +445,8 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     const size_t nscal = 4 * M1 + 5 * M1 + 2 * M1 * M1;
     if (!rc) rc = lb_malloc(&o->scal, nscal);
     if (!rc) rc = lb_malloc(&o->status, 8);
-    const size_t npart = std::max<size_t>({(size_t)o->nb_chunk * M1 * 5, (size_t)o->nb_stream * 3, (size_t)o->nb_chunk});
+    const size_t npart = std::max<size_t>({(size_t)o->nb_chunk * M1 * 5, (size_t)o->nb_stream * 3, (size_t)o->nb_chunk,
+                                           (size_t)((n + kLb - 1) / kLb) < 8192 ? (size_t)((n + kLb - 1) / kLb) : 0});
     if (!rc) rc = lb_malloc(&o->A.part, npart);
     if (!rc) rc = lb_malloc(&o->A.st, 1);
     if (rc) { hfem_lbfgs_destroy(o); return rc; }
@@ -480,14 +487,23 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
     else hipLaunchKernelGGL(pair_kernel<float>, dim3(o->nb_stream), dim3(kLb), 0, s, o->A, (const float *)g, (float *)o->g_prev, (const float *)o->d, (float *)o->Sring, (float *)o->Yring, o->n, M1, first);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, o->nb_stream, M1, first);
     if (!first) {
-        if (o->dtype == 0) hipLaunchKernelGGL(multidot_kernel<double>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, o->n, M1);
-        else hipLaunchKernelGGL(multidot_kernel<float>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, o->n, M1);
+        int gy = 2048 / o->nb_chunk;                      // slot classes: fill the chip when the vectors are short
+        gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
+        if (o->dtype == 0) hipLaunchKernelGGL(multidot_kernel<double>, dim3(o->nb_chunk, gy), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, o->n, M1);
+        else hipLaunchKernelGGL(multidot_kernel<float>, dim3(o->nb_chunk, gy), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, o->n, M1);
         hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_chunk, M1);
     }
-    hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(kLb), 0, s, o->A, M1, lr, tol_change);
-    if (o->dtype == 0) hipLaunchKernelGGL(direction_kernel<double>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, (double *)o->d, o->n, M1);
-    else hipLaunchKernelGGL(direction_kernel<float>, dim3(o->nb_chunk), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, (float *)o->d, o->n, M1);
-    hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, o->nb_chunk);
+    hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
+    const bool fine = o->nb_chunk < 1024;                 // short vectors: one element per thread, 8x the workgroups
+    const int nb_dir = fine ? (int)((o->n + kLb - 1) / kLb) : o->nb_chunk;
+    if (o->dtype == 0) {
+        if (fine) hipLaunchKernelGGL((direction_kernel<double, 1>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, (double *)o->d, o->n, M1);
+        else hipLaunchKernelGGL((direction_kernel<double, kLbPer>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, (double *)o->d, o->n, M1);
+    } else {
+        if (fine) hipLaunchKernelGGL((direction_kernel<float, 1>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, (float *)o->d, o->n, M1);
+        else hipLaunchKernelGGL((direction_kernel<float, kLbPer>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, (float *)o->d, o->n, M1);
+    }
+    hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, nb_dir);
     o->first = false;
     return launch_status("hfem_lbfgs_direction");
 }

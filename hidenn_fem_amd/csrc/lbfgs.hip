@@ -311,6 +311,131 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
     }
 }
 
+// ---- the same two loops for histories up to 256 pairs, without a reduction on the critical path.
+// The reduction form above pays a global-load round trip plus two block reductions per sequential step (178 us at
+// 100 pairs -- more than the two passes over the history on a 35 k-element mesh).  Here every pending sum is kept as a
+// running vector in LDS: after al_i is known, every older row k takes t_k += al_i s_k.y_i; after c_i is known, every
+// newer row k takes w_k += c_i s_i.y_k (rank-1 updates); a sequential step is then one LDS read, a few flops and a
+// broadcast, and the Gram entries it needs are fetched four steps ahead (their addresses do not depend on the values).
+// Logical index l = 0 (oldest) .. count-1; thread k owns rows k and k + 128.
+constexpr int kRecT = 128, kRecMax = 256;
+__global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, int M1, double lr, double tol_change) {
+    __shared__ double t_[kRecMax], w_[kRecMax], v_[kRecMax], al_[kRecMax], c_[kRecMax], ro_[kRecMax], sg_[kRecMax], yg_[kRecMax];
+    __shared__ int slot_[kRecMax];
+    __shared__ double red[kRecT / 64];
+    LbfgsState &S = *A.st;
+    const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x;
+    if (ns >= 0) {                                        // Gram row / column of the new pair
+        for (int l = tid; l < count; l += kRecT) {
+            const int j = (head + l) % M1;
+            A.SY[ns * M1 + j] = A.dots[j * 5 + 2];
+            A.SY[j * M1 + ns] = A.dots[j * 5 + 4];
+            A.YY[ns * M1 + j] = A.dots[j * 5 + 3];
+            A.YY[j * M1 + ns] = A.dots[j * 5 + 3];
+        }
+    }
+    for (int l = tid; l < count; l += kRecT) {
+        const int j = (head + l) % M1;
+        slot_[l] = j; ro_[l] = A.ro[j]; sg_[l] = A.dots[j * 5 + 1]; yg_[l] = A.dots[j * 5];
+        t_[l] = 0.0; w_[l] = 0.0;
+    }
+    __syncthreads();
+    const double H = S.H_diag;
+    const int k0 = tid, k1 = tid + kRecT;
+    const int s0 = k0 < count ? slot_[k0] : 0, s1 = k1 < count ? slot_[k1] : 0;
+    // ---- first loop, i = count-1 .. 0, four steps per prefetch group: column i of S^T Y
+    {
+        double a0[4], a1[4], b0[4], b1[4];
+        auto fetch = [&](int i_hi, double (&x0)[4], double (&x1)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i_hi - q;
+                const int si = i >= 0 ? slot_[i] : 0;
+                x0[q] = (i >= 0 && k0 < i) ? A.SY[s0 * M1 + si] : 0.0;
+                x1[q] = (i >= 0 && k1 < i) ? A.SY[s1 * M1 + si] : 0.0;
+            }
+        };
+        fetch(count - 1, a0, a1);
+        for (int ih = count - 1; ih >= 0; ih -= 4) {
+            fetch(ih - 4, b0, b1);                        // next group's entries land under this group's steps
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = ih - q;
+                if (i >= 0) {                             // uniform
+                    if (tid == 0) al_[i] = ro_[i] * (-sg_[i] - t_[i]);
+                    __syncthreads();
+                    const double ai = al_[i];
+                    if (k0 < i) t_[k0] += ai * a0[q];
+                    if (k1 < i) t_[k1] += ai * a1[q];
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a0[q] = b0[q]; a1[q] = b1[q]; }
+        }
+    }
+    // ---- v_k = sum_j al_j y_k.y_j : every row streams its own Gram row (no dependence between rows)
+    {
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < count; ++j) {
+            const int sj = slot_[j];
+            const double aj = al_[j];
+            if (k0 < count) v0 += aj * A.YY[s0 * M1 + sj];
+            if (k1 < count) v1 += aj * A.YY[s1 * M1 + sj];
+        }
+        if (k0 < count) v_[k0] = v0;
+        if (k1 < count) v_[k1] = v1;
+    }
+    __syncthreads();
+    // ---- second loop, i = 0 .. count-1: row i of S^T Y
+    {
+        double a0[4], a1[4], b0[4], b1[4];
+        auto fetch = [&](int i_lo, double (&x0)[4], double (&x1)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i_lo + q;
+                const int si = i < count ? slot_[i] : 0;
+                x0[q] = (i < count && k0 > i && k0 < count) ? A.SY[si * M1 + s0] : 0.0;
+                x1[q] = (i < count && k1 > i && k1 < count) ? A.SY[si * M1 + s1] : 0.0;
+            }
+        };
+        fetch(0, a0, a1);
+        for (int il = 0; il < count; il += 4) {
+            fetch(il + 4, b0, b1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = il + q;
+                if (i < count) {                          // uniform
+                    if (tid == 0) c_[i] = al_[i] - ro_[i] * (H * (-yg_[i] - v_[i]) + w_[i]);
+                    __syncthreads();
+                    const double ci = c_[i];
+                    if (k0 > i && k0 < count) w_[k0] += ci * a0[q];
+                    if (k1 > i && k1 < count) w_[k1] += ci * a1[q];
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a0[q] = b0[q]; a1[q] = b1[q]; }
+        }
+    }
+    // ---- coefficients by slot, g.d, step, break flag
+    double v = 0.0;
+    for (int l = tid; l < count; l += kRecT) {
+        const int j = slot_[l];
+        const double cyj = -H * al_[l];
+        A.al[j] = al_[l]; A.cy[j] = cyj; A.cs[j] = c_[l];
+        v += cyj * yg_[l] + c_[l] * sg_[l];
+    }
+    const double sum = block_sum(v, red);
+    if (tid == 0) {
+        S.cg = -H;
+        S.gtd = -H * S.gg + sum;
+        S.t = S.n_iter == 1 ? fmin(1.0, 1.0 / S.g_abssum) * lr : lr;
+        S.stop_gtd = S.gtd > -tol_change ? 1 : 0;
+    }
+}
+
 // ---- d = cg g + sum_j cy_j Y_j + cs_j S_j (one pass over the history), max|d| partials [nb]
 // PER elements per thread: 8 for long vectors (fewer, fatter workgroups), 1 for short ones (more workgroups); the slot
 // loop is unrolled so that several slots' loads are in flight (it is latency-bound otherwise).  Same sums either way.
@@ -493,7 +618,8 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
         else hipLaunchKernelGGL(multidot_kernel<float>, dim3(o->nb_chunk, gy), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, o->n, M1);
         hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_chunk, M1);
     }
-    hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
+    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
+    else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
     const bool fine = o->nb_chunk < 1024;                 // short vectors: one element per thread, 8x the workgroups
     const int nb_dir = fine ? (int)((o->n + kLb - 1) / kLb) : o->nb_chunk;
     if (o->dtype == 0) {

@@ -30,10 +30,12 @@ def run(nx=200, ny=100, steps=30, dtype=torch.float32, log_every=5, fused_lbfgs=
     calls = [0]
 
     def closure():
+        calls[0] += 1
+        if fused_lbfgs:                   # autograd-free: one launch writes loss and .grad (no zero_grad / backward)
+            return loss_fn.value_and_grad_(model)
         opt.zero_grad()
         value = loss_fn(model)
         value.backward()
-        calls[0] += 1
         return value
 
     import time

@@ -38,11 +38,23 @@ def energy_reference_form(model, xi, wi):
     return torch.sum(wq * (0.5 * E_MOD * du ** 2 - body_force(xq) * u))
 
 
-def run(epochs=4000, nodes=89, reference_form=False, log_every=500, fused_adam=False):
+def run(epochs=4000, nodes=89, reference_form=False, log_every=500, fused_adam=False, graphed=False):
     dev = torch.device("cuda")
     grid = torch.linspace(0, LENGTH, nodes, device=dev)
     xi, wi = gauss_legendre_points_weights(2, device=dev)
     model = PiecewiseLinearShapeNN(grid, r_adapt=True, u0=0.0, uN=0.0).to(dev)
+    if graphed:         # whole iterations in one hipGraph (100 per replay), Adam's step count on the device
+        from hidenn_fem_amd.graphed import GraphedTraining
+        from hidenn_fem_amd.optim import FusedAdam
+        per = 100
+        gt = GraphedTraining(lambda: bar_energy_loss(model, xi, wi, body_force, E=E_MOD),
+                             FusedAdam(model.parameters(), lr=1e-4, capturable=True), steps_per_replay=per, warmup=0)
+        loss = gt.replay(epochs // per)
+        with torch.no_grad():
+            xs = torch.linspace(0, LENGTH, 1000, device=dev)
+            err = (model(xs) - exact_u(xs)).abs().max().item()
+        print(f"final loss {loss.item():.6f}, max |u_h - u_exact| = {err:.3e}")
+        return model, loss.item(), err
     if fused_adam:                      # one HIP launch per parameter tensor
         from hidenn_fem_amd.optim import FusedAdam
         opt = FusedAdam(model.parameters(), lr=1e-4)
@@ -68,5 +80,6 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=4000)
     ap.add_argument("--reference-form", action="store_true")
     ap.add_argument("--fused-adam", action="store_true")
+    ap.add_argument("--graphed", action="store_true", help="capture 100 iterations per hipGraph (FusedAdam, capturable)")
     a = ap.parse_args()
-    run(a.epochs, reference_form=a.reference_form, fused_adam=a.fused_adam)
+    run(a.epochs, reference_form=a.reference_form, fused_adam=a.fused_adam, graphed=a.graphed)

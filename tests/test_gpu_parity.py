@@ -460,6 +460,8 @@ def test_example3_converges_to_the_analytic_bar_solution():
     assert err < 4e-4
     _, loss_f, err_f = e3.run(epochs=4000, log_every=100000, fused_adam=True)     # fused Adam: same trajectory
     assert abs(loss_f - loss) < 2e-5 and err_f < 4e-4
+    _, loss_g, err_g = e3.run(epochs=4000, graphed=True)                          # 40 hipGraph replays of 100 iterations
+    assert abs(loss_g - loss) < 2e-5 and err_g < 4e-4
 
 
 def test_fused_adam_matches_torch_adam():

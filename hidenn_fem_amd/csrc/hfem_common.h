@@ -52,12 +52,21 @@ struct HostPlan {
     std::vector<uint32_t> edge_pack;   // li | lj<<10 | home<<30
     std::vector<int32_t> edge_gid;     // global edge id (row of the traction table)
     int32_t max_nodes = 0, max_owned = 0, max_elems = 0, max_edges = 0;
+    // Chunked element order (elem_order 4; the streamed kernel's contract, tri3_stream.hip): a tile's slots are
+    // kChunks spatial strips [0,e1) [e1,e2) [e2,n_elem), each a whole number of 16-lane groups; owned and halo
+    // local ids are each sorted by the first strip that touches them, so a strip's nodes are a prefix of both
+    // id ranges.  tile_chunks[t] = {e1, e2, po0 | po1<<8 | ph0<<16 | ph1<<24, 0}: po_k / ph_k = number of
+    // 64-id pieces of the owned / halo id range that strips 0..k need.  Empty for the other element orders.
+    std::vector<int32_t> tile_chunks;
+    int32_t max_chunk_elems = 0;       // longest strip (slots); 0 = not chunked
 };
+constexpr int kChunks = 3;
 
 // Build the owner-computes tiling.  Returns 0 or -1 (message via set_error).
 int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
-                    int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, HostPlan &out);
+                    int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, int32_t chunk_cap,
+                    HostPlan &out);
 
 void set_plan_curve(int c);   // 0 Morton, 1 Hilbert (default)
 

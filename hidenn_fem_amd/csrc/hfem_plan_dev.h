@@ -13,7 +13,15 @@ struct PlanDev {
     const uint32_t *edge_pack;
     const int32_t *edge_gid;
     const uint32_t *elem_pack_hi;   // QUAD4 plans only: 4th local node id of every slot
+    const int4 *tile_chunks;        // chunked plans only (HostPlan::tile_chunks)
 };
+
+struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
+    const double *prev = nullptr;    // partials bank the previous launch wrote (offset to its first tile)
+    int prev_n = 0;
+    double *out = nullptr;           // receives their sum (same order and bits as sum_partials_kernel)
+};
+
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
 // L2).  Map block -> tile so that each XCD walks one contiguous run of the
@@ -40,6 +48,7 @@ struct hfem_plan {
     int2 *d_node_src = nullptr;
     uint32_t *d_edge_pack = nullptr;
     int32_t *d_edge_gid = nullptr;
+    int4 *d_tile_chunks = nullptr;            // chunked element order only
     double *d_partials = nullptr;             // two banks of [n_tiles] tile energies
     int bank = 0;                             // bank the most recent launch wrote (host state; one plan = one stream)
     int prev_begin = 0, prev_n = 0;           // partial range of the most recent HFEM_FLAG_NO_LOSS_SUM launch
@@ -51,7 +60,7 @@ struct hfem_plan {
 
 namespace hfem {
 inline PlanDev plan_dev(const hfem_plan *p) {
-    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi};
+    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi, p->d_tile_chunks};
 }
 inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6]) {
     Tri3Consts k;
@@ -60,6 +69,11 @@ inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6])
     for (int i = 0; i < 6; ++i) k.Bk[i] = Bk ? Bk[i] : 0.0;
     return k;
 }
+// tri3_stream.hip: streamed (LDS-DMA, strip-pipelined) TRI3 kernel on a chunked plan; 1 = launched, 0 = shape not held
+int launch_tri3_stream(const hfem_plan *plan, int n_grid, int tile_begin, const double *x_free, const double *x_fixed,
+                       const double *u_free, const double *u_fixed, const Tri3Consts &kc, const double *T_edge,
+                       double4 tc, double *partials, double *gx_free, double *gu_free, int skip_edges, int store_policy,
+                       const LagSum &lag, hipStream_t s);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

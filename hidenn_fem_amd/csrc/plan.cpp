@@ -102,6 +102,70 @@ void morton_order(const int64_t *conn, int npe, int64_t ne, int64_t nn, const do
 
 constexpr int kOrphanTileNodes = 512;
 
+// LDS-bank-aware packing of one element list into groups of 16 (order_tile_elements mode 3, below): appends the
+// packed list to `out`; holes are -1.  pad_last: also pad the final partial group (the list then ends on a
+// 16-slot boundary).
+void pack_bank_groups(const std::vector<int32_t> &elems, const int64_t *conn, int npe, const std::vector<int32_t> &lid,
+                      int32_t n_owned, bool pad_last, bool fill_tail, std::vector<int32_t> &out) {
+    constexpr int G = 16;
+    struct Open { std::vector<int32_t> el; uint16_t used[4]; };
+    // most-constrained first: elements with 3 owned corners, then 2, 1, 0 (stable: curve order kept
+    // inside a class).  The flexible ones (halo elements, few owned corners) then fill the holes the
+    // constrained ones leave; with no window limit this brings the padding from ~8 % to ~2 %.
+    std::vector<int32_t> byc[5];
+    for (int32_t e : elems) {
+        int owned = 0;
+        for (int k = 0; k < npe; ++k) owned += lid[conn[npe * (int64_t)e + k]] < n_owned;
+        byc[npe - owned].push_back(e);
+    }
+    std::vector<Open> open;
+    size_t first_open = 0;                                   // groups before this index are full
+    for (int cls = 0; cls <= npe; ++cls)
+        for (int32_t e : byc[cls]) {
+            uint16_t bit[4] = {0, 0, 0, 0};
+            for (int k = 0; k < npe; ++k) {
+                const int32_t l = lid[conn[npe * (int64_t)e + k]];
+                bit[k] = l < n_owned ? (uint16_t)(1u << (l & 15)) : 0;
+            }
+            bool placed = false;
+            for (size_t j = first_open; j < open.size(); ++j) {
+                Open &g = open[j];
+                if ((int)g.el.size() >= G) continue;
+                if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2]) | (g.used[3] & bit[3])) continue;
+                g.el.push_back(e);
+                for (int k = 0; k < 4; ++k) g.used[k] |= bit[k];
+                placed = true;
+                break;
+            }
+            if (!placed) {
+                Open g;
+                g.el.push_back(e);
+                for (int k = 0; k < 4; ++k) g.used[k] = bit[k];
+                open.push_back(std::move(g));
+            }
+            while (first_open < open.size() && (int)open[first_open].el.size() >= G) ++first_open;
+        }
+    // emit: full groups first, then partial ones fullest-first.  fill_tail: the elements of the emptiest partial
+    // groups are moved into the holes of the fuller ones even where that costs a bank conflict (one extra LDS
+    // cycle on that group) -- cheaper than idle lanes; only the very last group can then be short.
+    std::stable_sort(open.begin(), open.end(), [](const Open &a, const Open &b) { return a.el.size() > b.el.size(); });
+    if (fill_tail) {
+        size_t lo = 0, hi = open.size();
+        while (lo < hi && (int)open[lo].el.size() >= G) ++lo;
+        while (lo + 1 < hi) {
+            Open &dst = open[lo], &srcg = open[hi - 1];
+            while ((int)dst.el.size() < G && !srcg.el.empty()) { dst.el.push_back(srcg.el.back()); srcg.el.pop_back(); }
+            if (srcg.el.empty()) --hi;
+            if ((int)dst.el.size() >= G) ++lo;
+        }
+        open.resize(hi);
+    }
+    for (size_t j = 0; j < open.size(); ++j) {
+        out.insert(out.end(), open[j].el.begin(), open[j].el.end());
+        if ((pad_last || j + 1 < open.size()) && (int)open[j].el.size() < G) out.insert(out.end(), G - open[j].el.size(), -1);
+    }
+}
+
 // Order the elements of one tile so that the 64 lanes of a wave-instruction (64 consecutive
 // positions) do not add into the same LDS accumulator: same-address ds_add_f64 lanes serialise.
 //   mode 0: keep Morton order (neighbouring lanes share nodes: worst for atomics)
@@ -117,52 +181,9 @@ void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, int 
     const int n = (int)telems.size();
     if (npe != 3 && mode != 3) mode = 3;                 // the legacy orders are TRI3-only lab variants
     if (mode == 3) {
-        constexpr int G = 16;
-        struct Open { std::vector<int32_t> el; uint16_t used[4]; };
-        // most-constrained first: elements with 3 owned corners, then 2, 1, 0 (stable: curve order kept
-        // inside a class).  The flexible ones (halo elements, few owned corners) then fill the holes the
-        // constrained ones leave; with no window limit this brings the padding from ~8 % to ~2 %.
-        std::vector<int32_t> byc[5];
-        for (int i = 0; i < n; ++i) {
-            int owned = 0;
-            for (int k = 0; k < npe; ++k) owned += lid[conn[npe * (int64_t)telems[i] + k]] < n_owned;
-            byc[npe - owned].push_back(telems[i]);
-        }
-        std::vector<Open> open;
         std::vector<int32_t> out;
-        out.reserve(n + n / 8 + G);
-        size_t first_open = 0;                                   // groups before this index are full
-        for (int cls = 0; cls <= npe; ++cls)
-            for (int32_t e : byc[cls]) {
-                uint16_t bit[4] = {0, 0, 0, 0};
-                for (int k = 0; k < npe; ++k) {
-                    const int32_t l = lid[conn[npe * (int64_t)e + k]];
-                    bit[k] = l < n_owned ? (uint16_t)(1u << (l & 15)) : 0;
-                }
-                bool placed = false;
-                for (size_t j = first_open; j < open.size(); ++j) {
-                    Open &g = open[j];
-                    if ((int)g.el.size() >= G) continue;
-                    if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2]) | (g.used[3] & bit[3])) continue;
-                    g.el.push_back(e);
-                    for (int k = 0; k < 4; ++k) g.used[k] |= bit[k];
-                    placed = true;
-                    break;
-                }
-                if (!placed) {
-                    Open g;
-                    g.el.push_back(e);
-                    for (int k = 0; k < 4; ++k) g.used[k] = bit[k];
-                    open.push_back(std::move(g));
-                }
-                while (first_open < open.size() && (int)open[first_open].el.size() >= G) ++first_open;
-            }
-        // emit: full groups first, then partial ones fullest-first (the very last needs no padding)
-        std::stable_sort(open.begin(), open.end(), [](const Open &a, const Open &b) { return a.el.size() > b.el.size(); });
-        for (size_t j = 0; j < open.size(); ++j) {
-            out.insert(out.end(), open[j].el.begin(), open[j].el.end());
-            if (j + 1 < open.size()) out.insert(out.end(), G - open[j].el.size(), -1);
-        }
+        out.reserve(n + n / 8 + 16);
+        pack_bank_groups(telems, conn, npe, lid, n_owned, false, false, out);
         telems.swap(out);
         return;
     }
@@ -251,9 +272,9 @@ void cut_tiles(const int64_t *conn, int npe, int64_t ne, int64_t nn, const std::
     bounds.push_back(ne);
 }
 
-int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const int32_t *x_src,
+int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *xy, const int32_t *x_src,
               const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T, int32_t node_cap,
-              const std::vector<int32_t> &order, int elem_order, HostPlan &P) {
+              const std::vector<int32_t> &order, int elem_order, int32_t chunk_cap, HostPlan &P) {
     std::vector<int64_t> bounds;
     cut_tiles(conn, npe, ne, nn, order, T, node_cap, bounds);
     const int32_t nt_main = ne > 0 ? (int32_t)bounds.size() - 1 : 0;
@@ -321,7 +342,8 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const int32_
     P.node_src.reserve(2 * (nn + nn / 3));
 
     std::vector<int32_t> stamp_e(ne, -1), stamp_n(nn, -1), lid(nn, 0);
-    std::vector<int32_t> telems, halo;
+    std::vector<int32_t> first_use_stamp(elem_order == 4 ? nn : 0, -1), first_use(elem_order == 4 ? nn : 0, 0);
+    std::vector<int32_t> telems, halo, own_order_buf;
     for (int32_t t = 0; t < nt; ++t) {
         TileDesc &d = P.tiles[t];
         d = TileDesc();
@@ -341,8 +363,11 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const int32_
             }
         }
         // local nodes: owned first
+        const bool chunked = elem_order == 4 && npe == 3;
+        std::vector<int32_t> &own_order = own_order_buf;       // this tile's owned nodes in local-id order
+        own_order.assign(own.begin() + o0, own.begin() + o1);
         int32_t nloc = 0;
-        for (int64_t i = o0; i < o1; ++i) { stamp_n[own[i]] = t; lid[own[i]] = nloc++; }
+        for (int32_t n : own_order) { stamp_n[n] = t; lid[n] = nloc++; }
         d.n_owned = nloc;
         for (int32_t e : telems)
             for (int k = 0; k < npe; ++k) {
@@ -355,9 +380,76 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const int32_
                 if (stamp_n[n] != t) { stamp_n[n] = t; halo.push_back(n); }
             }
         std::sort(halo.begin(), halo.end());
-        for (int32_t n : halo) lid[n] = nloc++;
-        if (nloc > kMaxLocal) return 1;
-        order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
+        if (d.n_owned + (int32_t)halo.size() > kMaxLocal) return 1;
+        int32_t chunk_rec[4] = {0, 0, 0, 0};
+        if (chunked) {
+            // ---- strips: sort the tile's elements along the longer side of their bounding box (centroids; without
+            //      coordinates: list order = curve order of the home elements, then halo) and cut into kChunks equal runs
+            const int n = (int)telems.size();
+            std::vector<int32_t> strip_of(n, 0);
+            {
+                std::vector<std::pair<double, int32_t>> key(n);
+                if (xy) {
+                    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+                    std::vector<double> cx(n), cy(n);
+                    for (int i = 0; i < n; ++i) {
+                        double c[2] = {0, 0};
+                        for (int k = 0; k < npe; ++k) {
+                            const int64_t nd = conn[npe * (int64_t)telems[i] + k];
+                            c[0] += xy[2 * nd]; c[1] += xy[2 * nd + 1];
+                        }
+                        cx[i] = c[0]; cy[i] = c[1];
+                        for (int a = 0; a < 2; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+                    }
+                    const bool along_x = (hi[0] - lo[0]) >= (hi[1] - lo[1]);
+                    for (int i = 0; i < n; ++i) key[i] = {along_x ? cx[i] : cy[i], i};
+                } else {
+                    for (int i = 0; i < n; ++i) key[i] = {(double)i, i};
+                }
+                std::stable_sort(key.begin(), key.end());
+                for (int r = 0; r < n; ++r) strip_of[key[r].second] = (int32_t)(((int64_t)r * kChunks) / std::max(n, 1));
+            }
+            // ---- first strip that touches each local node; local ids = (owned | halo) x (first strip, node id)
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < npe; ++k) {
+                    const int32_t nd = (int32_t)conn[npe * (int64_t)telems[i] + k];
+                    if (first_use_stamp[nd] != t) { first_use_stamp[nd] = t; first_use[nd] = strip_of[i]; }
+                    else first_use[nd] = std::min(first_use[nd], strip_of[i]);
+                }
+            auto fu = [&](int32_t nd) { return first_use_stamp[nd] == t ? first_use[nd] : kChunks - 1; };   // edge-only nodes: last
+            auto by_use = [&](int32_t a, int32_t b) { const int32_t fa = fu(a), fb = fu(b); return fa != fb ? fa < fb : a < b; };
+            std::sort(own_order.begin(), own_order.end(), by_use);
+            std::sort(halo.begin(), halo.end(), by_use);
+            nloc = 0;
+            for (int32_t nd : own_order) lid[nd] = nloc++;
+            int32_t cnt_o[kChunks] = {0}, cnt_h[kChunks] = {0};
+            for (int32_t nd : own_order) cnt_o[fu(nd)]++;
+            for (int32_t nd : halo) cnt_h[fu(nd)]++;
+            for (int32_t nd : halo) lid[nd] = nloc++;
+            // ---- bank-aware groups inside every strip; every strip ends on a 16-slot boundary
+            std::vector<int32_t> packed, part;
+            int32_t ends[kChunks];
+            for (int c = 0; c < kChunks; ++c) {
+                part.clear();
+                for (int i = 0; i < n; ++i)
+                    if (strip_of[i] == c) part.push_back(telems[i]);
+                pack_bank_groups(part, conn, npe, lid, d.n_owned, true, true, packed);
+                ends[c] = (int32_t)packed.size();
+                const int32_t len = ends[c] - (c ? ends[c - 1] : 0);
+                if (chunk_cap > 0 && len > chunk_cap) return 1;              // a strip must fit one pass of the workgroup
+                P.max_chunk_elems = std::max(P.max_chunk_elems, len);
+            }
+            telems.swap(packed);
+            const int32_t po0 = (cnt_o[0] + 63) / 64, po1 = (cnt_o[0] + cnt_o[1] + 63) / 64;
+            const int32_t ph0 = (cnt_h[0] + 63) / 64, ph1 = (cnt_h[0] + cnt_h[1] + 63) / 64;
+            chunk_rec[0] = ends[0]; chunk_rec[1] = ends[1];
+            chunk_rec[2] = po0 | (po1 << 8) | (ph0 << 16) | (ph1 << 24);
+        } else {
+            for (int32_t n : halo) lid[n] = nloc++;
+            order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
+        }
+        nloc = d.n_owned + (int32_t)halo.size();
+        if (elem_order == 4) P.tile_chunks.insert(P.tile_chunks.end(), chunk_rec, chunk_rec + 4);
 
         d.elem_off = (int32_t)P.elem_pack.size();
         d.n_elem = (int32_t)telems.size();
@@ -383,7 +475,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const int32_
             P.node_src.push_back(x_src ? x_src[n] : n);
             P.node_src.push_back(u_src ? u_src[n] : n);
         };
-        for (int64_t i = o0; i < o1; ++i) push_node(own[i]);
+        for (int32_t n : own_order) push_node(n);
         for (int32_t n : halo) push_node(n);
         for (int64_t i = edg_ptr[t]; i < edg_ptr[t + 1]; ++i) {
             const int32_t g = tedge[i];
@@ -411,7 +503,8 @@ void set_plan_curve(int c) { set_locality_curve(c); }
 
 int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
-                    int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, HostPlan &out) {
+                    int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, int32_t chunk_cap,
+                    HostPlan &out) {
     if (npe != 3 && npe != 4) { set_error("plan: nodes per element must be 3 (TRI3) or 4 (QUAD4)"); return -1; }
     if (ne < 0 || nn < 0 || ned < 0 || nn > std::numeric_limits<int32_t>::max() ||
         ne > std::numeric_limits<int32_t>::max() || ned > std::numeric_limits<int32_t>::max()) {
@@ -429,7 +522,7 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
     std::vector<int32_t> order;
     morton_order(conn, npe, ne, nn, coords, order);
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
-        const int rc = try_build(conn, npe, ne, nn, x_src, u_src, edges, ned, T, node_cap, order, elem_order, out);
+        const int rc = try_build(conn, npe, ne, nn, coords, x_src, u_src, edges, ned, T, node_cap, order, elem_order, chunk_cap, out);
         if (rc == 0 && npe == 4 && out.max_elems > kMaxQuadSlots) continue;   // QUAD4 kernel: <= 4 slots x 256 threads
         if (rc <= 0) return rc;
     }

@@ -227,12 +227,6 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
 // residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
 // (forcing 64 VGPRs on them spills).
-struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
-    const double *prev = nullptr;    // partials bank the previous launch wrote (offset to its first tile)
-    int prev_n = 0;
-    double *out = nullptr;           // receives their sum (same order and bits as sum_partials_kernel)
-};
-
 struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
     double2 *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows); must not alias the inputs
     double2 *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows, updated in place
@@ -691,7 +685,7 @@ using namespace hfem;
 // ---- tuning / lab options (process-wide; hfem_set_option)
 static int g_tiled_block = 512;    // threads per tile (measured best on T1M: 512 at 1024-element tiles)
 static int g_tiled_ablate = 0;
-static int g_plan_elem_order = 3;  // LDS-bank-aware 16-lane groups (plan.cpp order_tile_elements)
+static int g_plan_elem_order = 4;  // 4: three spatial strips per tile, LDS-bank-aware 16-lane groups inside each (plan.cpp); 3: one list
 static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
 static int g_tiled_stagger_mode = 0;
 static int g_plan_node_cap = -1; // max distinct nodes among a tile's own elements; 0: cut by element count only;
@@ -707,6 +701,8 @@ static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back
 // for TRI3 (its element stage is short), so the default is off.  (The tiled QUAD4 kernel does gain, quad4.hip.)
 static int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
 static int g_fast_const_caps = 1; // default tile shape: instance with compile-time LDS strides
+static int g_plan_chunk_cap = 512; // chunked plans: longest strip a tile may have (slots); the streamed kernel walks a strip per pass
+static int g_tri3_stream = 1;    // chunked plans: streamed kernel (tri3_stream.hip); 0 = the register-prefetched kernel
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
 static int grid_for(int64_t n, int cap = 256 * 8) {
@@ -767,6 +763,7 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
         (void)hipFree(plan->d_node_src);
         (void)hipFree(plan->d_edge_pack);
         (void)hipFree(plan->d_edge_gid);
+        (void)hipFree(plan->d_tile_chunks);
         (void)hipFree(plan->d_partials);
         (void)hipFree(plan->d_stamps);
     }
@@ -793,7 +790,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     int32_t node_cap = g_plan_node_cap;
     if (node_cap < 0) node_cap = tile_elems <= 0 ? 557 : 0;
     if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
-    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, p->host)) return -1;
+    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, g_plan_chunk_cap, p->host)) return -1;
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
@@ -808,6 +805,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         if (!rc) rc = hfem_upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
+        if (!rc && !h.tile_chunks.empty()) rc = hfem_upload(&raw->d_tile_chunks, h.tile_chunks.data(), h.tile_chunks.size() / 4, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
         if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, h.tiles.size() * 8, raw->device_bytes);
         if (!rc && p->lds_bytes_pipe > 64 * 1024) {
@@ -850,6 +848,7 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 4: src = h.edge_gid.data(); n = (int64_t)h.edge_gid.size(); break;
         case 5: src = h.elem_gid.data(); n = (int64_t)h.elem_gid.size(); break;
         case 7: src = h.elem_pack_hi.data(); n = (int64_t)h.elem_pack_hi.size(); break;
+        case 8: src = h.tile_chunks.data(); n = (int64_t)h.tile_chunks.size(); break;
         case 6: {   // lab: device stamps, 8 x uint64 per tile, returned as 16 x int32 per tile
             n = (int64_t)h.tiles.size() * 16;
             if (buf) {
@@ -966,6 +965,13 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             const HostPlan &h = plan->host;
             bool hasb = false;
             for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
+            if (g_tri3_stream && !hasb && g_tiled_block == 512 &&
+                launch_tri3_stream(plan, n_grid, (int)tile_begin, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk),
+                                   T_edge, tc, pbase + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free,
+                                   (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0,
+                                   g_store_policy, lag, s) == 1)
+                fast = true;
+            if (!fast) {
 #define HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, HB, SPV)                                                         \
     hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, false, SPV>), dim3(n_grid), dim3(BLK), (size_t)plan->lds_bytes, s, \
                        pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
@@ -1016,6 +1022,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
 #undef HFEM_LAUNCH_FAST_CC
 #undef HFEM_LAUNCH_FAST
 #undef HFEM_LAUNCH_FAST_SP
+            }
         }
         if (fast) {
         } else if (abl == 0) {
@@ -1247,13 +1254,18 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_store_policy = value;
     } else if (n == "fast_const_caps") {
         g_fast_const_caps = value ? 1 : 0;
+    } else if (n == "plan_chunk_cap") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 4096, "plan_chunk_cap: 0 (no limit) .. 4096 slots");
+        g_plan_chunk_cap = value;
+    } else if (n == "tri3_stream") {
+        g_tri3_stream = value ? 1 : 0;
     } else if (n == "tiled_fast") {
         g_tiled_fast = value ? 1 : 0;
     } else if (n == "tiled_pipe") {
         HFEM_ARG_CHECK(value >= 0 && value <= 8, "tiled_pipe must be 0..8 workgroups per CU");
         g_tiled_pipe = value;
     } else if (n == "plan_elem_order") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 3, "plan_elem_order must be 0..3");
+        HFEM_ARG_CHECK(value >= 0 && value <= 4, "plan_elem_order must be 0..4");
         g_plan_elem_order = value;
     } else {
         set_error("hfem_set_option: unknown option '" + n + "'");
@@ -1271,6 +1283,9 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "plan_elem_order") return g_plan_elem_order;
     if (n == "tiled_pipe") return g_tiled_pipe;
     if (n == "tiled_fast") return g_tiled_fast;
+    if (n == "tri3_stream") return g_tri3_stream;
+    if (n == "plan_chunk_cap") return g_plan_chunk_cap;
+    if (n == "fast_const_caps") return g_fast_const_caps;
     if (n == "store_policy") return g_store_policy;
     if (n == "plan_node_cap") return g_plan_node_cap;
     if (n == "tiled_stagger") return g_tiled_stagger;

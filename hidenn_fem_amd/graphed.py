@@ -34,6 +34,14 @@ class GraphedTraining:
         if self.steps_per_replay < 1:
             raise ValueError("steps_per_replay must be >= 1")
         self.steps_done = 0
+        # optimiser state must exist BEFORE the capture: created inside it, its zero fills become graph nodes and
+        # every replay resets the moments / step count
+        if optimizer is not None:
+            if hasattr(optimizer, "init_state"):
+                optimizer.init_state()
+            elif warmup < 1 and len(optimizer.state) == 0:
+                raise ValueError("GraphedTraining: warmup=0 with an optimiser whose state is still empty would create "
+                                 "that state inside the capture; use warmup >= 1")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up off the default stream (allocations,

@@ -14,8 +14,17 @@ from ._lib import check, ptr, require_gpu_tensor, stream_ptr, dev_index
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """``capturable=True``: the step count lives on the device (one counter for the optimiser), so ``step()``
-    can be captured in a hipGraph (``hidenn_fem_amd.graphed.GraphedTraining``); the arithmetic is the same."""
+    """``capturable=True``: the step count lives on the device, so ``step()`` can be captured in a hipGraph
+    (``hidenn_fem_amd.graphed.GraphedTraining``); the arithmetic is the same.  State layout: ``exp_avg``,
+    ``exp_avg_sq`` and ``step`` per parameter as in ``torch.optim.Adam``; with ``capturable=True`` ``step`` is an
+    int64 device tensor (as torch's capturable Adam keeps it) and ONE tensor is shared by all parameters -- a
+    single counter for the optimiser, bumped once per ``step()`` call, so a parameter whose gradient is ``None`` on
+    some steps still advances (torch counts per parameter; the reference's loops never skip one).  It travels with
+    ``state_dict()`` and is re-shared by ``load_state_dict``.
+
+    State is never created under stream capture (the fill kernels would become graph nodes and reset the
+    moments on every replay): ``init_state()`` allocates it eagerly, ``GraphedTraining`` calls it before
+    capturing, and ``step()`` refuses to create state while the stream is capturing."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
@@ -24,6 +33,46 @@ class FusedAdam(torch.optim.Optimizer):
         self.capturable = capturable
         self._step_dev = None
 
+    def init_state(self):
+        """Allocate moments and the step counter of every parameter now (idempotent)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.requires_grad:
+                    self._state_of(p)
+        return self
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdam: optimiser state would be created inside a hipGraph capture (its zero "
+                                   "fills would replay with the graph); call init_state() before capturing")
+            if self.capturable:
+                if self._step_dev is None:
+                    self._step_dev = torch.zeros(1, dtype=torch.int64, device=p.device)
+                st["step"] = self._step_dev
+            else:
+                st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_dev = None
+        for st in self.state.values():               # re-share one device counter (each entry was loaded as its own copy)
+            if "step" not in st:
+                continue
+            if self.capturable:
+                if not torch.is_tensor(st["step"]):
+                    dev = st["exp_avg"].device
+                    st["step"] = torch.full((1,), int(st["step"]), dtype=torch.int64, device=dev)
+                if self._step_dev is None:
+                    self._step_dev = st["step"].to(torch.int64).reshape(1).contiguous()
+                st["step"] = self._step_dev
+            elif torch.is_tensor(st["step"]):
+                st["step"] = int(st["step"].item())
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -31,39 +80,35 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        if self.capturable:
-            p0 = self.param_groups[0]["params"][0]
-            if self._step_dev is None:
-                self._step_dev = torch.zeros(1, dtype=torch.int64, device=p0.device)
-            check(L.hfem_counter_add(dev_index(p0.device), ptr(self._step_dev), 1, stream_ptr(p0.device)),
-                  "hfem_counter_add")
+        todo = []
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 require_gpu_tensor(p.data, "parameter", dtype=None)
                 if p.dtype not in (torch.float64, torch.float32):
                     raise RuntimeError("FusedAdam supports fp64 / fp32 parameters")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                if g.dtype != p.dtype:
-                    g = g.to(p.dtype)
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-                if self.capturable:
-                    check(L.hfem_adam_step_dev(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]),
-                                               ptr(st["exp_avg_sq"]), p.numel(), 0 if p.dtype == torch.float64 else 1,
-                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                               ptr(self._step_dev), stream_ptr(p.device)), "hfem_adam_step_dev")
-                    continue
-                check(L.hfem_adam_step(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
-                                       p.numel(), 0 if p.dtype == torch.float64 else 1, float(group["lr"]), float(b1),
-                                       float(b2), float(group["eps"]), int(st["step"]), stream_ptr(p.device)),
-                      "hfem_adam_step")
+                todo.append((group, p, self._state_of(p)))
+        if self.capturable and todo:
+            p0 = todo[0][1]
+            check(L.hfem_counter_add(dev_index(p0.device), ptr(self._step_dev), 1, stream_ptr(p0.device)),
+                  "hfem_counter_add")
+        for group, p, st in todo:
+            b1, b2 = group["betas"]
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if g.dtype != p.dtype:
+                g = g.to(p.dtype)
+            if self.capturable:
+                check(L.hfem_adam_step_dev(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]),
+                                           ptr(st["exp_avg_sq"]), p.numel(), 0 if p.dtype == torch.float64 else 1,
+                                           float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                           ptr(self._step_dev), stream_ptr(p.device)), "hfem_adam_step_dev")
+                continue
+            st["step"] += 1
+            check(L.hfem_adam_step(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
+                                   p.numel(), 0 if p.dtype == torch.float64 else 1, float(group["lr"]), float(b1),
+                                   float(b2), float(group["eps"]), int(st["step"]), stream_ptr(p.device)),
+                  "hfem_adam_step")
         return loss
 
 

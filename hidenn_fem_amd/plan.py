@@ -16,7 +16,7 @@ import torch
 from . import _lib
 
 EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
-              "stamps": 6, "elem_pack_hi": 7}
+              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8}
 
 
 def _np(a, dtype):
@@ -94,6 +94,8 @@ class TilePlan:
             out = out.reshape(-1, 8)
         elif name == "node_src":
             out = out.reshape(-1, 2)
+        elif name == "tile_chunks":
+            out = out.reshape(-1, 4)
         elif name == "stamps":
             out = out.view(np.uint64).reshape(-1, 8)
         return out

@@ -71,6 +71,39 @@ def test_graphed_training_follows_the_eager_loop(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("warmup", [0, 1])
+def test_graphed_training_without_warmup_keeps_the_optimiser_state(warmup):
+    """FusedAdam's moments and step counter must not be (re)created inside the capture: with warmup=0 they used to be,
+    so every replay restarted Adam.  Parameters after several replays == the eager loop, to rounding."""
+    from hidenn_fem_amd.optim import FusedAdam
+    from hidenn_fem_amd.graphed import GraphedTraining
+    d = torch.device("cuda:0")
+    per, n_replays = 4, 3
+    m_e, closure_e, lr = _example1(d)
+    opt_e = FusedAdam(m_e.parameters(), lr=lr, capturable=True)
+    for _ in range(warmup + per * n_replays):
+        opt_e.zero_grad()
+        closure_e().backward()
+        opt_e.step()
+    m, closure, lr = _example1(d)
+    opt = FusedAdam(m.parameters(), lr=lr, capturable=True)
+    gt = GraphedTraining(closure, opt, steps_per_replay=per, warmup=warmup)
+    gt.replay(n_replays)
+    torch.cuda.synchronize()
+    assert int(opt.state[next(iter(m.parameters()))]["step"].item()) == warmup + per * n_replays
+    for a, b in zip(m.parameters(), m_e.parameters()):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-9, atol=1e-13)
+    # the device step counter travels with state_dict(): a resumed optimiser continues, it does not restart
+    opt2 = FusedAdam(m.parameters(), lr=lr, capturable=True)
+    opt2.load_state_dict(opt.state_dict())
+    assert int(opt2._step_dev.item()) == warmup + per * n_replays
+    # a stock optimiser whose state does not exist yet must be refused with warmup=0
+    m3, closure3, lr3 = _example1(d)
+    with pytest.raises(ValueError):
+        GraphedTraining(closure3, torch.optim.Adam(m3.parameters(), lr=lr3, capturable=True), warmup=0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_direct_value_and_grad_matches_autograd_and_trains_in_a_graph(dtype):
     """EnergyLoss2D.value_and_grad_: one launch, gradients straight into .grad -- same numbers as loss.backward();

@@ -73,7 +73,7 @@ inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6])
 int launch_tri3_stream(const hfem_plan *plan, int n_grid, int tile_begin, const double *x_free, const double *x_fixed,
                        const double *u_free, const double *u_fixed, const Tri3Consts &kc, const double *T_edge,
                        double4 tc, double *partials, double *gx_free, double *gu_free, int skip_edges, int store_policy,
-                       const LagSum &lag, hipStream_t s);
+                       const LagSum &lag, hipStream_t s, int ablate = 0);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

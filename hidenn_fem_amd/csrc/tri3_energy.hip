@@ -685,7 +685,7 @@ using namespace hfem;
 // ---- tuning / lab options (process-wide; hfem_set_option)
 static int g_tiled_block = 512;    // threads per tile (measured best on T1M: 512 at 1024-element tiles)
 static int g_tiled_ablate = 0;
-static int g_plan_elem_order = 4;  // 4: three spatial strips per tile, LDS-bank-aware 16-lane groups inside each (plan.cpp); 3: one list
+static int g_plan_elem_order = 3;  // 3: LDS-bank-aware 16-lane groups (plan.cpp); 4: the same inside three spatial strips per tile (streamed kernel)
 static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
 static int g_tiled_stagger_mode = 0;
 static int g_plan_node_cap = -1; // max distinct nodes among a tile's own elements; 0: cut by element count only;
@@ -702,7 +702,8 @@ static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back
 static int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
 static int g_fast_const_caps = 1; // default tile shape: instance with compile-time LDS strides
 static int g_plan_chunk_cap = 512; // chunked plans: longest strip a tile may have (slots); the streamed kernel walks a strip per pass
-static int g_tri3_stream = 1;    // chunked plans: streamed kernel (tri3_stream.hip); 0 = the register-prefetched kernel
+static int g_stream_ablate = 0;   // lab
+static int g_tri3_stream = 0;    // 1: chunked plans (plan_elem_order 4) take the streamed kernel (tri3_stream.hip) -- measured slower, kept for the lab
 static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
 
 static int grid_for(int64_t n, int cap = 256 * 8) {
@@ -807,7 +808,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
         if (!rc && !h.tile_chunks.empty()) rc = hfem_upload(&raw->d_tile_chunks, h.tile_chunks.data(), h.tile_chunks.size() / 4, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
-        if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, h.tiles.size() * 8, raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, (h.tiles.size() + 1) * 16, raw->device_bytes);
         if (!rc && p->lds_bytes_pipe > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
             rc = -1;
@@ -849,8 +850,8 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 5: src = h.elem_gid.data(); n = (int64_t)h.elem_gid.size(); break;
         case 7: src = h.elem_pack_hi.data(); n = (int64_t)h.elem_pack_hi.size(); break;
         case 8: src = h.tile_chunks.data(); n = (int64_t)h.tile_chunks.size(); break;
-        case 6: {   // lab: device stamps, 8 x uint64 per tile, returned as 16 x int32 per tile
-            n = (int64_t)h.tiles.size() * 16;
+        case 6: {   // lab: device stamps, 16 x uint64 per tile, returned as 32 x int32 per tile
+            n = (int64_t)h.tiles.size() * 32;
             if (buf) {
                 if (cap_elems < n || plan->device < 0) { set_error("hfem_plan_export: stamps need a device plan + buffer"); return -1; }
                 (void)hipSetDevice(plan->device);
@@ -969,7 +970,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                 launch_tri3_stream(plan, n_grid, (int)tile_begin, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk),
                                    T_edge, tc, pbase + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free,
                                    (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0,
-                                   g_store_policy, lag, s) == 1)
+                                   g_store_policy, lag, s, g_stream_ablate) == 1)
                 fast = true;
             if (!fast) {
 #define HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, HB, SPV)                                                         \
@@ -1257,6 +1258,8 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "plan_chunk_cap") {
         HFEM_ARG_CHECK(value >= 0 && value <= 4096, "plan_chunk_cap: 0 (no limit) .. 4096 slots");
         g_plan_chunk_cap = value;
+    } else if (n == "stream_ablate") {
+        g_stream_ablate = value;
     } else if (n == "tri3_stream") {
         g_tri3_stream = value ? 1 : 0;
     } else if (n == "tiled_fast") {
@@ -1284,6 +1287,7 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "tiled_pipe") return g_tiled_pipe;
     if (n == "tiled_fast") return g_tiled_fast;
     if (n == "tri3_stream") return g_tri3_stream;
+    if (n == "stream_ablate") return g_stream_ablate;
     if (n == "plan_chunk_cap") return g_plan_chunk_cap;
     if (n == "fast_const_caps") return g_fast_const_caps;
     if (n == "store_policy") return g_store_policy;

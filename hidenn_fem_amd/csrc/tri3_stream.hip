@@ -51,13 +51,13 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
 // CAPO > 0: compile-time stride of the four accumulator arrays (>= the plan's max owned nodes per tile).
 // SP: cache policy of the gradient stores (16 = sc1 write-through, 0 = plain).
 // LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] double | red[BLOCK/64]
-template <int BLOCK, int MAXP, int CAPO, int SP>
+template <int BLOCK, int MAXP, int CAPO, int SP, int ABL = 0>
 __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_stream_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
     const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    LagSum lag) {
+    LagSum lag, unsigned long long *__restrict__ stamps) {
     static_assert(kChunks == 3, "the strip loop below is written out for three strips");
     constexpr int NW = BLOCK / 64;
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
@@ -71,6 +71,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // lab (ABL & 256): s_memrealtime stamps (100 MHz) of thread 0 -> stamps[16 * blockIdx.x + I]
+    unsigned long long st_[12];
+#define HFEM_SSTAMP(I) if (ABL & 256) st_[I] = __builtin_amdgcn_s_memrealtime();   // wave-uniform: stays in SGPRs
+    HFEM_SSTAMP(0)
     const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0);
     if (lag.prev && (int)blockIdx.x == n_launch) {
         // the launch's one extra workgroup: sum the tile energies the PREVIOUS launch left (HFEM_FLAG_SUM_PREVIOUS;
@@ -83,16 +87,21 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
         return;
     }
     const int slot = xcd_tile(blockIdx.x, n_launch);
+    if (ABL & 32) { if (tid == 0 && cap_nodes < 0) partials[slot] = 0.0; return; }      // lab: launch cost only
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int4 ck = pd.tile_chunks[tile_begin + slot];
     const int n_owned = d.n_owned, n_node = d.n_node;
+    if ((ABL & 256) && n_node >= 0) HFEM_SSTAMP(1)
+    if (ABL & 16) { if (tid == 0) partials[slot] = (double)(n_owned + ck.x); return; }  // lab: + the descriptor round trip
 
     // ---- element records of the three strips (one slot per thread and strip)
     const uint32_t *ep = pd.elem_pack + d.elem_off;
     uint32_t pk0 = kSkipBit, pk1 = kSkipBit, pk2 = kSkipBit;
-    if (tid < ck.x) pk0 = ep[tid];
-    if (ck.x + tid < ck.y) pk1 = ep[ck.x + tid];
-    if (ck.y + tid < d.n_elem) pk2 = ep[ck.y + tid];
+    if (!(ABL & 64)) {
+        if (tid < ck.x) pk0 = ep[tid];
+        if (ck.x + tid < ck.y) pk1 = ep[ck.x + tid];
+        if (ck.y + tid < d.n_elem) pk2 = ep[ck.y + tid];
+    }
 
     // ---- DMA pieces in need order: [owned: strip 0][halo: strip 0][owned: +strip 1][halo: +strip 1][owned: rest][halo: rest]
     const int po0 = ck.z & 255, po1 = (ck.z >> 8) & 255, ph0 = (ck.z >> 16) & 255, ph1 = (ck.z >> 24) & 255;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
         const bool valid = s < b5 && l < (own[i] ? n_owned : n_node);
         lid[i] = valid ? l : -1;
         m[i] = make_int2(0, 0);
-        if (valid) m[i] = src[l];
+        if (valid) m[i] = (ABL & 128) ? make_int2(l, l) : src[l];
         n_mine += s < b5;
         q0 += s < b1;
         q1 += s < b3;
@@ -126,10 +135,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
     // every index load has landed before the first DMA goes out: nothing the compiler counts is in flight while
     // the pieces are (its own waits would otherwise drain them)
     asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2));
+    if ((ABL & 256) && (pk0 | 1u)) HFEM_SSTAMP(2)
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         if (lid[i] >= 0) {
             const int l = lid[i];
+            if (ABL & 2) {       // lab: no gather (synthetic node data)
+                nd_xy[l] = make_double2(0.001 * l + 1e-4 * (l & 7), 0.002 * (l & 15) + 1e-4 * (l & 3) * (l & 5));
+                nd_uv[l] = make_double2(1e-5, 2e-5 * (l & 3));
+                if (own[i]) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
+                continue;
+            }
             const unsigned dst_xy = __builtin_amdgcn_readfirstlane(lds_addr(nd_xy + (l - lane)));
             const unsigned dst_uv = __builtin_amdgcn_readfirstlane(lds_addr(nd_uv + (l - lane)));
             glds16(m[i].x >= 0 ? x_free + m[i].x : x_fixed + ~m[i].x, dst_xy);
@@ -138,15 +154,21 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
         }
     }
 
+    HFEM_SSTAMP(3)
     double e_loc = 0.0;
     auto strip = [&](const uint32_t p) {
-        if (!(p & kSkipBit)) {
+        if ((ABL & 1) == 0 && !(p & kSkipBit)) {
             const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask),
                       l2 = (int)((p >> (2 * kLocalBits)) & kLocalMask);
             double2 gx[3], gu[3];
             const double e = tri3_element<true, false>(nd_xy[l0], nd_xy[l1], nd_xy[l2], nd_uv[l0], nd_uv[l1],
                                                        nd_uv[l2], k, gx, gu);
             if (p & kHomeBit) e_loc += e;
+            if (ABL & 8) {       // lab: math without the LDS accumulation
+                asm volatile("" ::"v"(gx[0].x), "v"(gx[0].y), "v"(gx[1].x), "v"(gx[1].y), "v"(gx[2].x), "v"(gx[2].y),
+                             "v"(gu[0].x), "v"(gu[0].y), "v"(gu[1].x), "v"(gu[1].y), "v"(gu[2].x), "v"(gu[2].y));
+                return;
+            }
             if (l0 < n_owned) {
                 unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
                 unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
@@ -162,16 +184,25 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
         }
     };
     // ---- strip c: this wave's pieces of strips 0..c have landed, then the workgroup's (barrier), then the math
-    dma_wait(2 * (n_mine - q0));
+    dma_wait((ABL & 512) ? 0 : 2 * (n_mine - q0));            // lab 512: one wait for the whole gather, no strip barriers
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the accumulator clears
+    HFEM_SSTAMP(4)
     __builtin_amdgcn_s_barrier();
+    HFEM_SSTAMP(5)
     strip(pk0);
-    dma_wait(2 * (n_mine - q1));
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 512)) {
+        dma_wait(2 * (n_mine - q1));
+        __builtin_amdgcn_s_barrier();
+    }
+    HFEM_SSTAMP(6)
     strip(pk1);
-    dma_wait(0);
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 512)) {
+        dma_wait(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    HFEM_SSTAMP(7)
     strip(pk2);
+    HFEM_SSTAMP(8)
 
     const int n_edge = skip_edges ? 0 : d.n_edge;
     for (int i = tid; i < n_edge; i += BLOCK) {          // boundary tiles only
@@ -195,6 +226,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
         if (lane == 0) red[tid >> 6] = w;
     }
     __syncthreads();
+    HFEM_SSTAMP(9)
 
     // ---- every owned gradient row is written exactly once, by the lane that fetched the node
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
     }
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        if (own[i] && lid[i] >= 0) {
+        if (!(ABL & 4) && own[i] && lid[i] >= 0) {
             const int l = lid[i];
             if (gx_free && m[i].x >= 0) {
                 double2 v;
@@ -227,6 +259,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
         for (int w = 0; w < NW; ++w) tile_e += red[w];
         partials[slot] = tile_e;
     }
+    HFEM_SSTAMP(10)
+    if ((ABL & 256) && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) stamps[16 * (size_t)blockIdx.x + i] = st_[i];
+    }
+#undef HFEM_SSTAMP
 }
 
 // Launch on a chunked plan.  Returns 1 when launched, 0 when the plan's shape is outside what the kernel holds
@@ -234,24 +272,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 8 : 1) void tri3_energy_strea
 int launch_tri3_stream(const hfem_plan *plan, int n_grid, int tile_begin, const double *x_free, const double *x_fixed,
                        const double *u_free, const double *u_fixed, const Tri3Consts &kc, const double *T_edge,
                        double4 tc, double *partials, double *gx_free, double *gu_free, int skip_edges, int store_policy,
-                       const LagSum &lag, hipStream_t s) {
+                       const LagSum &lag, hipStream_t s, int ablate) {
     const HostPlan &h = plan->host;
     if (h.npe != 3 || h.max_chunk_elems <= 0 || h.max_chunk_elems > 512 || !plan->d_tile_chunks) return 0;
     if (h.max_nodes + 128 > 2 * 512) return 0;               // pieces(tile) <= nodes/64 + 2 <= MAXP * 8
     if (store_policy != 16) return 0;
     PlanDev pd = plan_dev(plan);
+#define HFEM_STREAM_ABL(A)                                                                                          \
+    case A:                                                                                                         \
+        hipLaunchKernelGGL((tri3_energy_stream_kernel<512, 2, 560, 16, A>), dim3(n_grid), dim3(512),                \
+                           (size_t)(h.max_nodes * 32 + 560 * 32 + 128), s, pd, tile_begin, (const double2 *)x_free, \
+                           (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed, kc,         \
+                           (const double4 *)T_edge, tc, partials, (double2 *)gx_free, (double2 *)gu_free,           \
+                           h.max_nodes, 560, skip_edges, lag, plan->d_stamps);                                      \
+        break;
     if (h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 38912) {
-        hipLaunchKernelGGL((tri3_energy_stream_kernel<512, 2, 560, 16>), dim3(n_grid), dim3(512),
-                           (size_t)(h.max_nodes * 32 + 560 * 32 + 128), s, pd, tile_begin, (const double2 *)x_free,
-                           (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed, kc,
-                           (const double4 *)T_edge, tc, partials, (double2 *)gx_free, (double2 *)gu_free, h.max_nodes,
-                           560, skip_edges, lag);
+        switch (ablate) {
+            HFEM_STREAM_ABL(0) HFEM_STREAM_ABL(1) HFEM_STREAM_ABL(2) HFEM_STREAM_ABL(4) HFEM_STREAM_ABL(5)
+            HFEM_STREAM_ABL(6) HFEM_STREAM_ABL(7) HFEM_STREAM_ABL(16) HFEM_STREAM_ABL(32) HFEM_STREAM_ABL(199) HFEM_STREAM_ABL(512) HFEM_STREAM_ABL(768) HFEM_STREAM_ABL(256) HFEM_STREAM_ABL(263) HFEM_STREAM_ABL(455) HFEM_STREAM_ABL(8) HFEM_STREAM_ABL(3) HFEM_STREAM_ABL(10) HFEM_STREAM_ABL(14)
+            default: return 0;
+        }
     } else {
         hipLaunchKernelGGL((tri3_energy_stream_kernel<512, 2, 0, 16>), dim3(n_grid), dim3(512),
                            (size_t)plan->lds_bytes, s, pd, tile_begin, (const double2 *)x_free,
                            (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed, kc,
                            (const double4 *)T_edge, tc, partials, (double2 *)gx_free, (double2 *)gu_free, h.max_nodes,
-                           h.max_owned, skip_edges, lag);
+                           h.max_owned, skip_edges, lag, plan->d_stamps);
     }
     return 1;
 }

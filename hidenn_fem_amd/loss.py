@@ -145,14 +145,19 @@ class EnergyLoss2D:
         f32 = xf.dtype == torch.float32
         if f32 and (plan.stats["max_tile_nodes"] > 1024 or plan.stats["max_tile_elems"] > 2048):
             raise RuntimeError("value_and_grad_: this tile plan has no fp32-storage kernel; use model.double()")
+        # cached per (model, dtype, device): only host-side constants and the static loss tensor.  The fixed rows are
+        # re-derived on every call -- `u_fixed_rows()` tracks `u_fixed._version`, `.to()` is a no-op when nothing
+        # changed -- so `model.to(device)` or an in-place edit of `u_fixed` / `node_coords_fixed` is never stale.
+        key = (id(model), xf.dtype, xf.device)
         cache = getattr(self, "_direct_cache", None)
-        if cache is None or cache[0] is not model or cache[1] != xf.dtype:
+        if cache is None or cache[0] != key:
             _, Tconst = self._traction(model, None)
             dv = lambda v: (C.c_double * len(v))(*v)
-            xfix, ufix = model.node_coords_fixed.to(xf.dtype).contiguous(), model.u_fixed_rows().to(xf.dtype).contiguous()
-            cache = self._direct_cache = (model, xf.dtype, dv(self._mat), dv([0.0] * 6), dv(Tconst), xfix, ufix,
+            cache = self._direct_cache = (key, dv(self._mat), dv([0.0] * 6), dv(Tconst),
                                           torch.zeros((), dtype=torch.float64, device=xf.device))
-        _, _, mat, Bk, Tc, xfix, ufix, loss = cache
+        _, mat, Bk, Tc, loss = cache
+        xfix = model.node_coords_fixed.to(device=xf.device, dtype=xf.dtype).contiguous()
+        ufix = model.u_fixed_rows().to(device=xf.device, dtype=xf.dtype).contiguous()
         flags = 0 if model.N_edges else HFEM_FLAG_NO_EDGES
         if quad:                                     # QUAD4-iso extension: same contract, tiled QUAD4 kernel
             _lib.check(_lib.lib().hfem_quad4_energy_plan(

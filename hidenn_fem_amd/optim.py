@@ -191,7 +191,9 @@ class FusedLBFGS(torch.optim.Optimizer):
         state = self.state[self._params[0]]
         state.setdefault("func_evals", 0)
         state.setdefault("n_iter", 0)
-        orig_loss = closure()
+        # snapshot: a closure may hand back a static tensor that later calls overwrite (EnergyLoss2D.value_and_grad_
+        # does); torch.optim.LBFGS.step returns the loss of the FIRST evaluation (torch/optim/lbfgs.py), so must we
+        orig_loss = closure().detach().clone()
         current_evals = 1
         state["func_evals"] += 1
         self._gather_flat_grad()

@@ -97,7 +97,7 @@ class TilePlan:
         elif name == "tile_chunks":
             out = out.reshape(-1, 4)
         elif name == "stamps":
-            out = out.view(np.uint64).reshape(-1, 8)
+            out = out.view(np.uint64).reshape(-1, 16)
         return out
 
     def shard_range(self, rank: int, world: int):

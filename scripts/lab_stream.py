@@ -89,7 +89,9 @@ def main():
         torch.cuda.synchronize()
         cur = (loss.item(), sets[0][2].clone(), sets[0][3].clone())
         ok = ""
-        if ref is None:
+        if "ablate" in optstr:
+            ok = "ablated"
+        elif ref is None:
             ref = cur
         else:
             dl = abs(cur[0] - ref[0]) / abs(ref[0])

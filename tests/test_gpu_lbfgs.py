@@ -124,3 +124,36 @@ def test_fused_lbfgs_on_example4_energy(g_lbfgs):
     np.testing.assert_allclose(got[:12], want[:12], rtol=1e-5)
     du = (m_got.u_free - m_ref.u_free).abs().max().item()
     assert du <= 1e-6 * m_ref.u_free.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_fused_lbfgs_step_returns_the_first_closure_value_with_a_static_loss_tensor():
+    """``EnergyLoss2D.value_and_grad_`` returns ONE static loss tensor that every later closure call overwrites;
+    ``FusedLBFGS.step`` must still return the loss of the step's FIRST evaluation, as torch.optim.LBFGS does
+    (example 4 with ``fused_lbfgs=True`` prints it)."""
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import FusedLBFGS
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(41, 21, jitter=0.1, seed=3, dtype=F64)
+    torch.manual_seed(0)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                 neumann_edges=edges).double().to(d)
+    lf = EnergyLoss2D(E=10e9, nu=0.3, device=d, dtype=F64)
+    opt = FusedLBFGS(m.parameters())
+    seen = []
+
+    def closure():
+        v = lf.value_and_grad_(m)
+        seen.append(v.item())
+        return v
+
+    for _ in range(2):
+        n0 = len(seen)
+        ret = opt.step(closure)
+        assert len(seen) - n0 > 1                       # the step really re-evaluated (and overwrote the static tensor)
+        assert ret.item() == seen[n0] != seen[-1]
+    import examples.example4 as e4                      # and the example's fused path runs end to end
+    _, final = e4.run(nx=40, ny=20, steps=2, dtype=F64, log_every=1, fused_lbfgs=True)
+    assert np.isfinite(final)

@@ -52,6 +52,10 @@ def parse():
                     "1-block launch after every energy kernel instead of inside the next launch")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed replays before each timed leg")
     ap.add_argument("--option", action="append", default=[], help="name=value for hfem_set_option (lab A/B runs)")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the extra cache-regime legs of the roofline block")
+    ap.add_argument("--only-regime", default="", help="rocprof helper: run ONLY this roofline leg (replayed | "
+                    "rewritten_inputs | rotating_sets) and exit")
+    ap.add_argument("--rotating-sets", type=int, default=10, help="parameter/gradient sets of the rotating leg (32 MB each)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the multi-rank path on fewer GPUs than ranks)")
     return ap.parse_args()
@@ -258,50 +262,85 @@ def main():
     mat, W, Bk, Tc = dv(loss_fn._mat), loss_fn._W, dv([0.0] * 6), dv(Tconst)
     stream = torch.cuda.current_stream()
 
-    def kernel_only():
-        _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None,
-                                           uf.data_ptr(), ufix.data_ptr() if ufix.numel() else None, mat, W, Bk, None,
-                                           Tc, lo, hi, loss_s.data_ptr(), gx_s.data_ptr(), gu_s.data_ptr(),
+    def kernel_only(bufs=None):
+        x_, u_, gx_, gu_ = bufs if bufs is not None else (xf, uf, gx_s, gu_s)
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, x_.data_ptr(), xfix.data_ptr() if xfix.numel() else None,
+                                           u_.data_ptr(), ufix.data_ptr() if ufix.numel() else None, mat, W, Bk, None,
+                                           Tc, lo, hi, loss_s.data_ptr(), gx_.data_ptr(), gu_.data_ptr(),
                                            8, stream.cuda_stream))           # HFEM_FLAG_NO_LOSS_SUM
 
     kreps = max(a.steps, 50)
-    kgraph = None
-    if not a.no_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                stream = s
-                kernel_only()
-            torch.cuda.current_stream().wait_stream(s)
+
+    def time_launches(body):
+        """Average time of one `body(i)` over `kreps` back-to-back calls (one hipGraph unless --no-graph), HIP events on
+        the launch stream, median of 5 regions after the clock pre-warm.  Returns (us, regions)."""
+        nonlocal stream
+        g = None
+        if not a.no_graph:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    stream = s
+                    body(0)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    stream = torch.cuda.current_stream()
+                    for i in range(kreps):
+                        body(i)
+            except Exception:
+                g = None
+        stream = torch.cuda.current_stream()
+        for i in range(5):
+            body(i)
+        t_pw = time.perf_counter()
+        while g is not None and time.perf_counter() - t_pw < a.prewarm:
+            g.replay()
             torch.cuda.synchronize()
-            kgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(kgraph):
-                stream = torch.cuda.current_stream()
-                for _ in range(kreps):
-                    kernel_only()
-        except Exception:
-            kgraph = None
-    stream = torch.cuda.current_stream()
-    for _ in range(5):
-        kernel_only()
-    t_pw = time.perf_counter()
-    while kgraph is not None and time.perf_counter() - t_pw < a.prewarm:
-        kgraph.replay()
-        torch.cuda.synchronize()
-    samples = []
-    for _ in range(5):                      # 5 timed regions of `kreps` back-to-back launches each
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(stream)
-        if kgraph is not None:
-            kgraph.replay()
-        else:
-            for _ in range(kreps):
-                kernel_only()
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        samples.append(ev0.elapsed_time(ev1) * 1e3 / kreps)
-    k_us = sorted(samples)[len(samples) // 2]       # median region; each value is already a kreps-launch average
+        regions = []
+        for _ in range(5):                      # 5 timed regions of `kreps` back-to-back bodies each
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+            if g is not None:
+                g.replay()
+            else:
+                for i in range(kreps):
+                    body(i)
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            regions.append(ev0.elapsed_time(ev1) * 1e3 / kreps)
+        return sorted(regions)[len(regions) // 2], regions       # median region; each value is a kreps-launch average
+
+    only = a.only_regime
+    k_us, samples = time_launches(lambda i: kernel_only()) if only in ("", "replayed") else (float("nan"), [])
+    # ---- the same kernel in the cache regimes a training loop sees (reported beside the headline leg, never instead):
+    #  rewritten_inputs: x and u are rewritten by another kernel before every launch (what an optimiser step does);
+    #                    the kernel's share = (rewrite + energy) - (rewrite alone), both as back-to-back graphs
+    #  rotating_sets:    R parameter / gradient sets (R x 32 MB > the 256 MB Infinity Cache) visited round-robin, so
+    #                    every read of x, u and every gradient line misses the Infinity Cache (plan arrays stay shared)
+    regimes = {}
+    if world == 1 and not a.no_regimes:
+        def rewrite(i):
+            with torch.cuda.stream(stream):
+                xf.mul_(1.0)
+                uf.mul_(1.0)
+        if only in ("", "rewritten_inputs"):
+            t_rw, _ = time_launches(rewrite)
+            t_pair, _ = time_launches(lambda i: (rewrite(i), kernel_only()))
+            regimes["rewritten_inputs"] = dict(pair_us=t_pair, rewrite_alone_us=t_rw, kernel_us=t_pair - t_rw)
+        if only in ("", "rotating_sets"):
+            R = max(2, a.rotating_sets)
+            sets = [(xf.clone(), uf.clone(), torch.empty_like(gx_s), torch.empty_like(gu_s)) for _ in range(R)]
+            t_rot, _ = time_launches(lambda i: kernel_only(sets[i % R]))
+            regimes["rotating_sets"] = dict(kernel_us=t_rot, sets=R,
+                                            working_set_mb=round(R * 4 * xf.numel() * 8 / 2 ** 20 + plan.stats["device_bytes"] / 2 ** 20, 1))
+            del sets
+    if only:
+        if rank == 0:
+            print(json.dumps(dict(only_regime=only, kernel_us=k_us, regimes=regimes)), flush=True)
+        return None
     # algorithmic bytes of ONE launch on this rank: its home elements and owned nodes
     ne_launch = int(td[lo:hi, 1].sum()) if world > 1 else ne      # (halo elements are not algorithmic work)
     if world > 1:
@@ -323,6 +362,11 @@ def main():
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, kernel="tri3_energy_fast_kernel", kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
                     alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
+    for name, r in regimes.items():
+        r["achieved"] = alg_bytes / (r["kernel_us"] * 1e-6) / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    if regimes:
+        roofline["regimes"] = dict(replayed=dict(kernel_us=k_us, achieved=achieved, frac=achieved / HBM_PEAK_GBS), **regimes)
 
     out = None
     if rank == 0:

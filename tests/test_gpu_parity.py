@@ -482,3 +482,85 @@ def test_fused_adam_matches_torch_adam():
         for a, b in zip(pa, pb):
             err = (a - b).abs().max().item() / a.abs().max().item()
             assert err <= tol, (dt, err)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs 2 and 3 at FULL size
+def test_cfg2_bar_10k_elements_r_adapt_vs_reference_chain():
+    """BASELINE config 2: example 3 at 10 001 nodes on [0, 10], 2 Gauss points per element,
+    E = 175, b_force of examples/example3.py:16-24, u0 = uN = 0, r-adaptivity on, u ~ 1e-2 N(0,1), increments
+    perturbed 5 %: fused bar energy (one launch: loss + d/du + d/d increments) against the reference's op chain
+    (oracle/ref_chain.py: grid_param -> bar_energy with autograd.grad(create_graph=True), example3.py:27-70)."""
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+    from hidenn_fem_amd.loss import bar_energy_loss
+    from hidenn_fem_amd.utils import gauss_legendre_points_weights
+    from oracle import ref_chain as R
+    d = dev()
+    n = 10001
+    g = torch.Generator().manual_seed(0)
+    grid0 = torch.linspace(0.0, 10.0, n, dtype=F64)
+    m = PiecewiseLinearShapeNN(grid0, r_adapt=True, u0=0.0, uN=0.0).double()
+    with torch.no_grad():
+        m.u.copy_(1e-2 * torch.randn(m.u.shape, generator=g, dtype=F64))
+        m.x_increments.mul_(1.0 + 0.05 * (2.0 * torch.rand(m.x_increments.shape, generator=g, dtype=F64) - 1.0))
+    u_cpu, inc_cpu = m.u.detach().clone(), m.x_increments.detach().clone()
+    m = m.to(d)
+    xi, wi = gauss_legendre_points_weights(2, device=d, dtype=F64)
+    loss = bar_energy_loss(m, xi, wi, R.example3_body_force, 175.0)
+    loss.backward()
+    # oracle: the reference chain on the CPU, same parameters
+    inc = inc_cpu.clone().requires_grad_(True)
+    u = u_cpu.clone().requires_grad_(True)
+    grid = R.grid_param(inc, grid0[:1], grid0[-1:])
+    u_full = torch.cat([torch.zeros(1, dtype=F64), u, torch.zeros(1, dtype=F64)])      # models.py:58-67 (u0 = uN = 0)
+    xi_c, wi_c = R.interval_gauss(2)
+    want = R.bar_energy(grid, u_full, xi_c, wi_c, R.example3_body_force, 175.0)
+    want.backward()
+    assert m.u.shape == u.shape and m.x_increments.shape == inc.shape
+    np.testing.assert_allclose(m.grid.detach().cpu().numpy(), grid.detach().numpy(), rtol=1e-13, atol=1e-14)
+    assert abs(loss.item() - want.item()) <= 1e-11 * abs(want.item())      # 20 000 terms of mixed sign
+    assert_grad_close(m.u.grad, u.grad.numpy(), "cfg2 gu")
+    assert_grad_close(m.x_increments.grad, inc.grad.numpy(), "cfg2 gincr")
+
+
+def test_cfg3_structured_256x256_l2_projection_vs_reference_chain():
+    """BASELINE config 3 (SURVEY cfg3): example 2 at 257 x 257 nodes (256 x 256 cells) on [0,1]^2, fixed nodes,
+    target sin 2 pi x cos 2 pi y, evaluated at 2 x 2 Gauss points per cell (M = 262 144): fused L2 loss + backward
+    against the reference's structured forward (oracle/ref_chain.rectq4_forward = src/models.py:180-212) + MSE
+    (examples/example2.py:46).  r-adaptivity on as well: gradients of both increment vectors."""
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import l2_projection_loss
+    from oracle import ref_chain as R
+    d = dev()
+    n = 257
+    gx0 = torch.linspace(0.0, 1.0, n, dtype=F64)
+    gq = torch.tensor([-1.0, 1.0], dtype=F64) / np.sqrt(3.0)
+    mid, half = 0.5 * (gx0[1:] + gx0[:-1]), 0.5 * (gx0[1:] - gx0[:-1])
+    q1 = (mid[:, None] + half[:, None] * gq[None, :]).reshape(-1)                      # 512 points per axis
+    X, Y = torch.meshgrid(q1, q1, indexing="ij")
+    pts = torch.stack([X.reshape(-1), Y.reshape(-1)], dim=1).contiguous()              # [262144, 2]
+    target = torch.sin(2 * torch.pi * pts[:, 0]) * torch.cos(2 * torch.pi * pts[:, 1])
+    assert pts.shape[0] == 4 * 256 * 256
+    for r_adapt in (False, True):
+        torch.manual_seed(0)
+        m = PiecewiseLinearShapeNN2D(grid_x=gx0, grid_y=gx0, r_adapt=r_adapt).double()
+        u_cpu = m.u.detach().clone()
+        m = m.to(d)
+        loss = l2_projection_loss(m, pts.to(d), target.to(d))
+        loss.backward()
+        u = u_cpu.clone().requires_grad_(True)
+        if r_adapt:
+            ix = m.increments_x.detach().cpu().clone().requires_grad_(True)
+            iy = m.increments_y.detach().cpu().clone().requires_grad_(True)
+            ends = torch.zeros(n, dtype=torch.bool)
+            ends[0] = ends[-1] = True                                   # default boundary masks, models.py:118-131
+            gx = R.masked_grid(R.grid_param(ix, gx0[:1], gx0[-1:]), ends, gx0)
+            gy = R.masked_grid(R.grid_param(iy, gx0[:1], gx0[-1:]), ends, gx0)
+        else:
+            gx = gy = gx0
+        want = R.mse_loss(R.rectq4_forward(gx, gy, u, pts), target)
+        want.backward()
+        assert abs(loss.item() - want.item()) <= LOSS_RTOL * abs(want.item()), (r_adapt, loss.item(), want.item())
+        assert_grad_close(m.u.grad, u.grad.numpy(), f"cfg3 gu r_adapt={r_adapt}")
+        if r_adapt:
+            assert_grad_close(m.increments_x.grad, ix.grad.numpy(), "cfg3 g increments_x")
+            assert_grad_close(m.increments_y.grad, iy.grad.numpy(), "cfg3 g increments_y")

@@ -74,8 +74,46 @@ class PiecewiseLinearShapeNN(nn.Module):
         return ops.Line2EvalFn.apply(self.grid, self.u_full, x_eval)
 
 
+# ============================================================================ one name, two element families
+def _pick_family_2d(args, kwargs):
+    """Which concrete class a ``PiecewiseLinearShapeNN2D(...)`` call means: the reference module defines the
+    name twice -- structured ``(grid_x, grid_y, ...)`` (models.py:93-212, shadowed) and triangular
+    ``(node_coords, connectivity, ...)`` (models.py:241-376)."""
+    structured_kw = {"grid_x", "grid_y", "boundary_mask_x", "boundary_mask_y", "r_adapt"}
+    tri_kw = {"node_coords", "connectivity", "boundary_mask", "dirichlet_mask", "neumann_edges"}
+    if structured_kw & kwargs.keys():
+        return StructuredShapeNN2D
+    conn = kwargs.get("connectivity", args[1] if len(args) >= 2 else None)
+    unstructured = bool(tri_kw & kwargs.keys()) or (
+        len(args) >= 2 and torch.is_tensor(args[1]) and args[1].dim() == 2 and not torch.is_floating_point(args[1]))
+    if unstructured:                                         # (node_coords [N,2], connectivity [Ne,3|4] int)
+        if conn is not None and conn.dim() == 2 and conn.shape[1] == 4:
+            return QuadShapeNN2D                             # extension element
+        return TriangularShapeNN2D
+    return StructuredShapeNN2D                               # (grid_x [Nx], grid_y [Ny])
+
+
+class PiecewiseLinearShapeNN2D(nn.Module):
+    """One name, two element families, like the reference module (SURVEY F1).
+
+    ``PiecewiseLinearShapeNN2D(grid_x=..., grid_y=..., ...)`` (examples/example2.py:31-36) builds the structured
+    model; ``PiecewiseLinearShapeNN2D(node_coords, connectivity, ...)`` (examples/example4.py:40-46) the triangular
+    one (``connectivity [Ne,4]``: the QUAD4 extension).  It is a real class: every model it builds is an instance
+    (``isinstance(m, PiecewiseLinearShapeNN2D)``), and a user subclass ``class My(PiecewiseLinearShapeNN2D)`` gets
+    the family its constructor arguments select mixed in behind it (``My.__init__`` may call
+    ``super().__init__(*args, **kwargs)`` as it would against the reference class)."""
+
+    def __new__(cls, *args, **kwargs):
+        if cls is PiecewiseLinearShapeNN2D:
+            cls = _pick_family_2d(args, kwargs)
+        elif not any(issubclass(cls, f) for f in (StructuredShapeNN2D, TriangularShapeNN2D)):
+            fam = _pick_family_2d(args, kwargs)              # user subclass of the dispatching name
+            cls = type(cls.__name__, (cls, fam), {"__module__": cls.__module__, "__qualname__": cls.__qualname__})
+        return super().__new__(cls)
+
+
 # ============================================================================ structured 2D
-class StructuredShapeNN2D(nn.Module):
+class StructuredShapeNN2D(PiecewiseLinearShapeNN2D):
     """Tensor-product rectilinear grid, bilinear interpolation (the reference's first,
     shadowed ``PiecewiseLinearShapeNN2D``, ``models.py:93-212``)."""
 
@@ -173,7 +211,7 @@ class ConnectivityWrapper:
         return self.connectivity.shape[0]
 
 
-class TriangularShapeNN2D(nn.Module):
+class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
     """Unstructured P1 triangles, vector field u in R^2, free node coordinates
     (r-adaptivity) and free nodal values as parameters (reference ``models.py:241-376``)."""
 
@@ -223,6 +261,18 @@ class TriangularShapeNN2D(nn.Module):
         e32 = (neumann_edges if neumann_edges is not None else torch.zeros((0, 2), dtype=torch.long))
         self.register_buffer("_edges32", e32.to(torch.int32).contiguous(), persistent=False)
         self._plans = {}
+
+    # -- copy / pickle: the tile plans wrap ctypes handles (not picklable) and the Dirichlet-row cache is derived;
+    #    both are rebuilt lazily, so copy.deepcopy(model) / torch.save(model) work as for the reference's plain Module
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plans"] = {}
+        state.pop("_ufix_cache", None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("_plans", {})
 
     # -- reference attribute surface ------------------------------------------------------
     @property
@@ -302,23 +352,3 @@ class QuadShapeNN2D(TriangularShapeNN2D):
         if not edge:
             return ops.Quad4EvalFn.apply(self.coords, self.u_full, self._conn32, x_eval, elem_id)
         return super().forward(x_eval, elem_id, edge=True)
-
-
-def PiecewiseLinearShapeNN2D(*args, **kwargs):
-    """One name, two element families, like the reference module (SURVEY F1).
-
-    ``PiecewiseLinearShapeNN2D(grid_x=..., grid_y=..., ...)`` (examples/example2.py:31-36) builds
-    the structured model; ``PiecewiseLinearShapeNN2D(node_coords, connectivity, ...)``
-    (examples/example4.py:40-46) builds the triangular one."""
-    structured_kw = {"grid_x", "grid_y", "boundary_mask_x", "boundary_mask_y", "r_adapt"}
-    tri_kw = {"node_coords", "connectivity", "boundary_mask", "dirichlet_mask", "neumann_edges"}
-    if structured_kw & kwargs.keys():
-        return StructuredShapeNN2D(*args, **kwargs)
-    conn = kwargs.get("connectivity", args[1] if len(args) >= 2 else None)
-    unstructured = bool(tri_kw & kwargs.keys()) or (
-        len(args) >= 2 and args[1].dim() == 2 and not torch.is_floating_point(args[1]))
-    if unstructured:                                         # (node_coords [N,2], connectivity [Ne,3|4] int)
-        if conn is not None and conn.dim() == 2 and conn.shape[1] == 4:
-            return QuadShapeNN2D(*args, **kwargs)            # extension element
-        return TriangularShapeNN2D(*args, **kwargs)
-    return StructuredShapeNN2D(*args, **kwargs)              # (grid_x [Nx], grid_y [Ny])

@@ -24,11 +24,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-def assert_grad_close(got, want, what=""):
+def assert_grad_close(got, want, what="", rtol=GRAD_RTOL):
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
     scale = max(np.abs(want).max(), 1e-300)
     err = np.abs(got - want).max()
-    assert err <= GRAD_RTOL * scale, f"{what}: max-abs err {err:.3e} vs scale {scale:.3e}"
+    assert err <= rtol * scale, f"{what}: max-abs err {err:.3e} vs scale {scale:.3e}"
 
 
 def tri_model_from_golden(g, case, device):
@@ -562,5 +562,8 @@ def test_cfg3_structured_256x256_l2_projection_vs_reference_chain():
         assert abs(loss.item() - want.item()) <= LOSS_RTOL * abs(want.item()), (r_adapt, loss.item(), want.item())
         assert_grad_close(m.u.grad, u.grad.numpy(), f"cfg3 gu r_adapt={r_adapt}")
         if r_adapt:
-            assert_grad_close(m.increments_x.grad, ix.grad.numpy(), "cfg3 g increments_x")
-            assert_grad_close(m.increments_y.grad, iy.grad.numpy(), "cfg3 g increments_y")
+            # each entry sums 131 072 point contributions of size O(1e-5) that cancel to O(1e-4 .. 1e-9) and then runs
+            # through a 256-term reverse cumsum: fp64 summation order (atomics here, autograd's tree there) leaves
+            # ~1e-16 * sqrt(N) * cancellation ~ 5e-10 of max|g|; 1e-8 is the stated tolerance for these two vectors
+            assert_grad_close(m.increments_x.grad, ix.grad.numpy(), "cfg3 g increments_x", rtol=1e-8)
+            assert_grad_close(m.increments_y.grad, iy.grad.numpy(), "cfg3 g increments_y", rtol=1e-8)

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "hfem_get_option": (C.c_int, [C.c_char_p]),
     "hfem_tri3_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hfem_tri3_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hfem_tri3_eval_fwd_conv": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "hfem_tri3_eval_bwd_conv": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "hfem_edge2_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "hfem_edge2_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hfem_quad4_energy_atomic": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

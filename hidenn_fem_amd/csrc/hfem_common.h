@@ -58,6 +58,8 @@ struct HostPlan {
     // id ranges.  tile_chunks[t] = {e1, e2, po0 | po1<<8 | ph0<<16 | ph1<<24, 0}: po_k / ph_k = number of
     // 64-id pieces of the owned / halo id range that strips 0..k need.  Empty for the other element orders.
     std::vector<int32_t> tile_chunks;
+    // compact copies of the inputs (the deterministic node-centric kernel walks the mesh itself, tri3_det.hip)
+    std::vector<int32_t> conn32, x_src_g, u_src_g, edges32;
     int32_t max_chunk_elems = 0;       // longest strip (slots); 0 = not chunked
 };
 constexpr int kChunks = 3;

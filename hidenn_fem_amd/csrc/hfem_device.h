@@ -90,11 +90,17 @@ __device__ __forceinline__ double fast_rcp(double x) {
 //   * a,b,c,d are pre-scaled by 1/det once (ai..di); H and dL/dG then need no trailing multiply;
 //   * sum_ij P_ij H_ij = A W (eps . sigma) = 2 A W psi, and A/det = sign(det), so
 //     dL/d(det) = sign(det) (W psi - beta) - 2 W sign(det) psi = -sign(det) (W psi + beta).
-template <bool GRAD, bool HASB = true>
+//
+// PHYS = true: the opt-in "physical" gradient convention, grad_u = G Jinv (dN_dx = Jinv^T dN_dxi; exact for linear
+// fields, invariant to the local node order) instead of the reference's G Jinv^T.  With
+// J = [[a, b], [c, d]]: Jinv = [[d, -b], [-c, a]] / det, so E_phys(a, b, c, d) = E_ref(a, c, b, d) -- the same code
+// with b and c swapped on the way in and dL/db, dL/dc swapped on the way out (det is symmetric in the swap).
+template <bool GRAD, bool HASB = true, bool PHYS = false>
 __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X1, const double2 X2,
                                                const double2 U0, const double2 U1, const double2 U2,
                                                const Tri3Consts &k, double2 (&gx)[3], double2 (&gu)[3]) {
-    const double a = X0.x - X2.x, b = X1.x - X2.x, c = X0.y - X2.y, d = X1.y - X2.y;
+    const double a = X0.x - X2.x, d = X1.y - X2.y;
+    const double b = PHYS ? X0.y - X2.y : X1.x - X2.x, c = PHYS ? X1.x - X2.x : X0.y - X2.y;
     const double det = a * d - b * c;
     const double inv = fast_rcp(det);
     const double A = fabs(det);
@@ -135,9 +141,9 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
         const double db = -q * (sxx * g1x + sxy * g1y) - ddet * c;
         const double dc = -q * (sxy * g0x + syy * g0y) - ddet * b;
         const double dd = q * (sxx * g0x + sxy * g0y) + ddet * a;
-        gx[0] = make_double2(da, dc);
-        gx[1] = make_double2(db, dd);
-        gx[2] = make_double2(-da - db, -dc - dd);
+        gx[0] = PHYS ? make_double2(da, db) : make_double2(da, dc);       // (dL/dx0, dL/dy0): y0 enters through c (b if PHYS)
+        gx[1] = PHYS ? make_double2(dc, dd) : make_double2(db, dd);
+        gx[2] = PHYS ? make_double2(-da - dc, -db - dd) : make_double2(-da - db, -dc - dd);
     }
     return A * dens;
 }

@@ -49,6 +49,14 @@ struct hfem_plan {
     uint32_t *d_edge_pack = nullptr;
     int32_t *d_edge_gid = nullptr;
     int4 *d_tile_chunks = nullptr;            // chunked element order only
+    // deterministic node-centric path (HFEM_FLAG_DETERMINISTIC): built and uploaded on first use
+    struct Det {
+        int32_t *conn = nullptr, *x_src = nullptr, *u_src = nullptr, *edges = nullptr;
+        int32_t *adj_ptr = nullptr, *adj = nullptr, *eadj_ptr = nullptr, *eadj = nullptr;
+        double *partials = nullptr;
+        int n_blocks = 0;
+        bool ready = false;
+    } det;
     double *d_partials = nullptr;             // two banks of [n_tiles] tile energies
     int bank = 0;                             // bank the most recent launch wrote (host state; one plan = one stream)
     int prev_begin = 0, prev_n = 0;           // partial range of the most recent HFEM_FLAG_NO_LOSS_SUM launch
@@ -74,6 +82,11 @@ int launch_tri3_stream(const hfem_plan *plan, int n_grid, int tile_begin, const 
                        const double *u_free, const double *u_fixed, const Tri3Consts &kc, const double *T_edge,
                        double4 tc, double *partials, double *gx_free, double *gu_free, int skip_edges, int store_policy,
                        const LagSum &lag, hipStream_t s, int ablate = 0);
+// tri3_det.hip: fixed-order (bit-reproducible) energy + gradients; phys: the physical gradient convention
+int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed, const double *u_free,
+                    const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,
+                    double *gx_free, double *gu_free, int skip_edges, bool phys, hipStream_t s);
+void free_tri3_det(hfem_plan *plan);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

@@ -524,6 +524,16 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
         const int rc = try_build(conn, npe, ne, nn, coords, x_src, u_src, edges, ned, T, node_cap, order, elem_order, chunk_cap, out);
         if (rc == 0 && npe == 4 && out.max_elems > kMaxQuadSlots) continue;   // QUAD4 kernel: <= 4 slots x 256 threads
+        if (rc == 0) {
+            out.conn32.assign(conn, conn + npe * ne);
+            out.edges32.assign(edges, edges + 2 * ned);
+            out.x_src_g.resize(nn);
+            out.u_src_g.resize(nn);
+            for (int64_t n = 0; n < nn; ++n) {
+                out.x_src_g[n] = x_src ? x_src[n] : (int32_t)n;
+                out.u_src_g[n] = u_src ? u_src[n] : (int32_t)n;
+            }
+        }
         if (rc <= 0) return rc;
     }
     set_error("plan: could not fit a tile into 1024 local nodes / element slots (node valence too high?)");

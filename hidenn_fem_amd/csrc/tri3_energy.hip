@@ -240,7 +240,7 @@ struct AdamFuse {                    // arguments of the fused optimiser write-o
 // address is then ONE scaled local id plus an immediate offset instead of a runtime base add per array.
 // ADAM: the write-out applies the Adam update instead of storing the gradient (struct AdamFuse below).
 template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2, int CAPN = 0,
-          int CAPO = 0, bool ADAM = false>
+          int CAPO = 0, bool ADAM = false, bool PHYS = false>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free,
     const V2 *__restrict__ x_fixed, const V2 *__restrict__ u_free,
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
             const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask),
                       l2 = (int)((p >> (2 * kLocalBits)) & kLocalMask);
             double2 gx[3], gu[3];
-            const double e = tri3_element<true, HASB>(nd_xy[l0], nd_xy[l1], nd_xy[l2], nd_uv[l0], nd_uv[l1],
-                                                      nd_uv[l2], k, gx, gu);
+            const double e = tri3_element<true, HASB, PHYS>(nd_xy[l0], nd_xy[l1], nd_xy[l2], nd_uv[l0], nd_uv[l1],
+                                                            nd_uv[l2], k, gx, gu);
             if (p & kHomeBit) e_loc += e;
             if (l0 < n_owned) {
                 unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
@@ -765,6 +765,7 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
         (void)hipFree(plan->d_edge_pack);
         (void)hipFree(plan->d_edge_gid);
         (void)hipFree(plan->d_tile_chunks);
+        free_tri3_det(plan);
         (void)hipFree(plan->d_partials);
         (void)hipFree(plan->d_stamps);
     }
@@ -885,6 +886,19 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     if (int rc = use_device(plan->device)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
+    const bool phys = (flags & HFEM_FLAG_PHYSICAL_GRAD) != 0;
+    const bool phys_fast = phys && !(flags & HFEM_FLAG_DETERMINISTIC) && g_tiled_block == 512 && g_tiled_ablate == 0 &&
+                           g_tiled_pipe == 0 && plan->host.max_nodes <= 2 * 512 && plan->host.max_elems <= 4 * 512;
+    if ((flags & HFEM_FLAG_DETERMINISTIC) || (phys && !phys_fast)) {
+        // fixed-order node-centric path (tri3_det.hip); also carries the physical convention for plan shapes the
+        // tiled PHYS instance does not hold
+        HFEM_ARG_CHECK(tile_begin == 0 && tile_end == nt, "HFEM_FLAG_DETERMINISTIC / physical fallback: whole plan only");
+        HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_LOSS_SUM | HFEM_FLAG_SUM_PREVIOUS)), "HFEM_FLAG_DETERMINISTIC always delivers the loss");
+        const double4 tcd = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+        return launch_tri3_det(plan, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk), T_edge, tcd, loss_out,
+                               (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free, (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free,
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, phys, s);
+    }
     // partials banks: a launch that leaves its tile energies unsummed writes the OTHER bank, so that the next launch
     // can reduce them with its one extra workgroup (HFEM_FLAG_SUM_PREVIOUS) while it fills this one
     const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0;
@@ -962,7 +976,19 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
                                (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, LagSum{});
             fast = true;
         }
-        if (abl == 0 && g_tiled_fast) {
+        if (phys_fast) {      // opt-in physical gradient convention: one general instance of the register-prefetched kernel
+            const HostPlan &h = plan->host;
+            HFEM_ARG_CHECK(!lag_consume, "HFEM_FLAG_PHYSICAL_GRAD: no HFEM_FLAG_SUM_PREVIOUS");
+            hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, true, false, 16, double2, 0, 0, false, true>), dim3(n),
+                               dim3(512), (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const double2 *)x_free,
+                               (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
+                               make_consts(mat, W, Bk), (const double4 *)T_edge, tc, pbase + tile_begin,
+                               (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
+                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, AdamFuse{}, LagSum{});
+            fast = true;
+        }
+        if (!fast && abl == 0 && g_tiled_fast) {
             const HostPlan &h = plan->host;
             bool hasb = false;
             for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);

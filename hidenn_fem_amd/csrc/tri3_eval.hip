@@ -18,7 +18,7 @@ constexpr int kBlockE = 256;
 __global__ __launch_bounds__(kBlockE) void tri3_eval_fwd_kernel(
     const double2 *__restrict__ X, const double2 *__restrict__ U, const int32_t *__restrict__ conn,
     const double2 *__restrict__ x_eval, const int64_t *__restrict__ elem_id, int64_t m,
-    double2 *__restrict__ u_h, double *__restrict__ detJ, double4 *__restrict__ grad_u) {
+    double2 *__restrict__ u_h, double *__restrict__ detJ, double4 *__restrict__ grad_u, int phys) {
     const int64_t stride = (int64_t)gridDim.x * kBlockE;
     for (int64_t p = (int64_t)blockIdx.x * kBlockE + threadIdx.x; p < m; p += stride) {
         const int64_t e = elem_id[p];
@@ -27,7 +27,9 @@ __global__ __launch_bounds__(kBlockE) void tri3_eval_fwd_kernel(
         const double2 r = x_eval[p];
         const double zeta = 1.0 - r.x - r.y;
         u_h[p] = make_double2(r.x * U0.x + r.y * U1.x + zeta * U2.x, r.x * U0.y + r.y * U1.y + zeta * U2.y);
-        const double a = X0.x - X2.x, b = X1.x - X2.x, c = X0.y - X2.y, d = X1.y - X2.y;
+        // phys: grad_u = G Jinv instead of the reference's G Jinv^T -- b and c trade places (hfem_device.h)
+        const double a = X0.x - X2.x, d = X1.y - X2.y;
+        const double b = phys ? X0.y - X2.y : X1.x - X2.x, c = phys ? X1.x - X2.x : X0.y - X2.y;
         const double det = a * d - b * c, inv = 1.0 / det;
         detJ[p] = det;
         const double g0x = U0.x - U2.x, g0y = U0.y - U2.y, g1x = U1.x - U2.x, g1y = U1.y - U2.y;
@@ -41,13 +43,14 @@ __global__ __launch_bounds__(kBlockE) void tri3_eval_bwd_kernel(
     const double2 *__restrict__ X, const double2 *__restrict__ U, const int32_t *__restrict__ conn,
     const double2 *__restrict__ x_eval, const int64_t *__restrict__ elem_id, int64_t m,
     const double2 *__restrict__ cu, const double *__restrict__ cd, const double4 *__restrict__ cg,
-    double *__restrict__ gX, double *__restrict__ gU) {
+    double *__restrict__ gX, double *__restrict__ gU, int phys) {
     const int64_t stride = (int64_t)gridDim.x * kBlockE;
     for (int64_t p = (int64_t)blockIdx.x * kBlockE + threadIdx.x; p < m; p += stride) {
         const int64_t e = elem_id[p];
         const int32_t n[3] = {conn[3 * e], conn[3 * e + 1], conn[3 * e + 2]};
         const double2 X0 = X[n[0]], X1 = X[n[1]], X2 = X[n[2]], U0 = U[n[0]], U1 = U[n[1]], U2 = U[n[2]];
-        const double a = X0.x - X2.x, b = X1.x - X2.x, c = X0.y - X2.y, d = X1.y - X2.y;
+        const double a = X0.x - X2.x, d = X1.y - X2.y;
+        const double b = phys ? X0.y - X2.y : X1.x - X2.x, c = phys ? X1.x - X2.x : X0.y - X2.y;
         const double det = a * d - b * c, inv = 1.0 / det;
         const double g0x = U0.x - U2.x, g0y = U0.y - U2.y, g1x = U1.x - U2.x, g1y = U1.y - U2.y;
         const double h00 = (g0x * d - g1x * b) * inv, h01 = (g1x * a - g0x * c) * inv;
@@ -67,7 +70,9 @@ __global__ __launch_bounds__(kBlockE) void tri3_eval_bwd_kernel(
         const double db = -(P.x * g1x + P.z * g1y) * inv - ddet * c;
         const double dc = -(P.y * g0x + P.w * g0y) * inv - ddet * b;
         const double dd = (P.x * g0x + P.z * g0y) * inv + ddet * a;
-        const double2 gx[3] = {make_double2(da, dc), make_double2(db, dd), make_double2(-(da + db), -(dc + dd))};
+        const double2 gx[3] = {phys ? make_double2(da, db) : make_double2(da, dc),
+                               phys ? make_double2(dc, dd) : make_double2(db, dd),
+                               phys ? make_double2(-(da + dc), -(db + dd)) : make_double2(-(da + db), -(dc + dd))};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             unsafeAtomicAdd(&gX[2 * (int64_t)n[j]], gx[j].x);
@@ -158,26 +163,41 @@ using namespace hfem;
 extern "C" int hfem_tri3_eval_fwd(int device, const double *X, const double *U, const int32_t *conn,
                                   const double *x_eval, const int64_t *elem_id, int64_t m, double *u_h,
                                   double *detJ, double *grad_u, void *stream) {
+    return hfem_tri3_eval_fwd_conv(device, X, U, conn, x_eval, elem_id, m, u_h, detJ, grad_u, HFEM_GRAD_REFERENCE, stream);
+}
+
+extern "C" int hfem_tri3_eval_fwd_conv(int device, const double *X, const double *U, const int32_t *conn,
+                                       const double *x_eval, const int64_t *elem_id, int64_t m, double *u_h,
+                                       double *detJ, double *grad_u, int32_t convention, void *stream) {
+    HFEM_ARG_CHECK(convention == HFEM_GRAD_REFERENCE || convention == HFEM_GRAD_PHYSICAL, "unknown gradient convention");
     HFEM_ARG_CHECK(m >= 0, "negative point count");
     if (m == 0) return 0;
     HFEM_ARG_CHECK(X && U && conn && x_eval && elem_id && u_h && detJ && grad_u, "null pointer");
     if (int rc = use_device(device)) return rc;
     hipLaunchKernelGGL(tri3_eval_fwd_kernel, dim3(grid_e(m)), dim3(kBlockE), 0, (hipStream_t)stream,
                        (const double2 *)X, (const double2 *)U, conn, (const double2 *)x_eval, elem_id, m,
-                       (double2 *)u_h, detJ, (double4 *)grad_u);
+                       (double2 *)u_h, detJ, (double4 *)grad_u, (int)convention);
     return launch_status("hfem_tri3_eval_fwd");
 }
 
 extern "C" int hfem_tri3_eval_bwd(int device, const double *X, const double *U, const int32_t *conn,
                                   const double *x_eval, const int64_t *elem_id, int64_t m, const double *cu,
                                   const double *cd, const double *cg, double *gX, double *gU, void *stream) {
+    return hfem_tri3_eval_bwd_conv(device, X, U, conn, x_eval, elem_id, m, cu, cd, cg, gX, gU, HFEM_GRAD_REFERENCE, stream);
+}
+
+extern "C" int hfem_tri3_eval_bwd_conv(int device, const double *X, const double *U, const int32_t *conn,
+                                       const double *x_eval, const int64_t *elem_id, int64_t m, const double *cu,
+                                       const double *cd, const double *cg, double *gX, double *gU,
+                                       int32_t convention, void *stream) {
+    HFEM_ARG_CHECK(convention == HFEM_GRAD_REFERENCE || convention == HFEM_GRAD_PHYSICAL, "unknown gradient convention");
     HFEM_ARG_CHECK(m >= 0, "negative point count");
     if (m == 0) return 0;
     HFEM_ARG_CHECK(X && U && conn && x_eval && elem_id && gX && gU, "null pointer");
     if (int rc = use_device(device)) return rc;
     hipLaunchKernelGGL(tri3_eval_bwd_kernel, dim3(grid_e(m)), dim3(kBlockE), 0, (hipStream_t)stream,
                        (const double2 *)X, (const double2 *)U, conn, (const double2 *)x_eval, elem_id, m,
-                       (const double2 *)cu, cd, (const double4 *)cg, gX, gU);
+                       (const double2 *)cu, cd, (const double4 *)cg, gX, gU, (int)convention);
     return launch_status("hfem_tri3_eval_bwd");
 }
 

@@ -17,12 +17,24 @@ from . import ops
 from .utils import interval_gauss_points, triangle_gauss_points
 
 HFEM_FLAG_NO_EDGES = 4
+HFEM_FLAG_PHYSICAL_GRAD = 64
+HFEM_FLAG_DETERMINISTIC = 128
 
 
 class EnergyLoss2D:
     def __init__(self, E: float = 10e9, nu: float = 0.3, length: float = 1.0, height: float = 1.0,
                  gauss_order: int = 4, gauss_order_1d: int = 2, device: Optional[torch.device] = None,
-                 dtype: torch.dtype = torch.float32, tile_elems: int = 0):
+                 dtype: torch.dtype = torch.float32, tile_elems: int = 0, grad_convention: Optional[str] = None,
+                 deterministic: bool = False):
+        """Reference signature (loss.py:7-17) plus three opt-in switches:
+        ``grad_convention``: ``"reference"`` (``dN_dx = Jinv * dN_dxi`` exactly as models.py:351, the parity contract),
+        ``"physical"`` (``Jinv^T``: exact for linear fields, invariant to an element's local node order) or
+        ``None`` = whatever the model says (``model.grad_convention``, ``"reference"`` unless set);
+        ``deterministic``: fixed-order accumulation -- loss and gradients bit-identical run to run (node-centric
+        cross-check kernel, ~3-4x slower); ``tile_elems``: home elements per tile (0 = library default)."""
+        if grad_convention not in (None, "reference", "physical"):
+            raise ValueError("grad_convention must be 'reference', 'physical' or None")
+        self.grad_convention, self.deterministic = grad_convention, bool(deterministic)
         self.E, self.nu = E, nu
         self.length, self.height = length, height          # stored, never read (as upstream, F9)
         self.gauss_order, self.gauss_order_1d = gauss_order, gauss_order_1d
@@ -84,7 +96,14 @@ class EnergyLoss2D:
             return False
         return bool(model.free_mask[model.neumann_edges.reshape(-1)].any().item())
 
+    def _mode_flags(self, model) -> int:
+        conv = self.grad_convention or getattr(model, "grad_convention", "reference")
+        if conv not in ("reference", "physical"):
+            raise ValueError(f"unknown grad_convention {conv!r}")
+        return (HFEM_FLAG_PHYSICAL_GRAD if conv == "physical" else 0) | (HFEM_FLAG_DETERMINISTIC if self.deterministic else 0)
+
     def _fused(self, model, b_force, T_edge, Tconst, flags, tile_range=(0, -1)):
+        flags |= self._mode_flags(model)
         plan = model.tile_plan(self.tile_elems)
         return ops.Tri3EnergyFn.apply(model.node_coords_free, model.u_free,
                                       model.node_coords_fixed.to(model.dtype), model.u_fixed_rows(), plan,
@@ -116,6 +135,8 @@ class EnergyLoss2D:
         body force, constant traction; planless fused kernels on the assembled arrays."""
         if b_force is not None or t_force is not None:
             raise NotImplementedError("QUAD4 extension: body force / custom traction are not built")
+        if self._mode_flags(model):
+            raise NotImplementedError("QUAD4 extension: grad_convention='physical' / deterministic are TRI3 switches")
         _, Tconst = self._traction(model, None)
         if self.quad4_planless:                                    # cross-check path: fp64 global atomics
             edges = model._edges32 if model.N_edges else None
@@ -158,7 +179,9 @@ class EnergyLoss2D:
         _, mat, Bk, Tc, loss = cache
         xfix = model.node_coords_fixed.to(device=xf.device, dtype=xf.dtype).contiguous()
         ufix = model.u_fixed_rows().to(device=xf.device, dtype=xf.dtype).contiguous()
-        flags = 0 if model.N_edges else HFEM_FLAG_NO_EDGES
+        flags = (0 if model.N_edges else HFEM_FLAG_NO_EDGES) | self._mode_flags(model)
+        if flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC) and (quad or f32):
+            raise NotImplementedError("grad_convention='physical' / deterministic: fp64 TRI3 models")
         if quad:                                     # QUAD4-iso extension: same contract, tiled QUAD4 kernel
             _lib.check(_lib.lib().hfem_quad4_energy_plan(
                 plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),

@@ -220,6 +220,8 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
         super().__init__()
         self.scale = 1e-5
         self.dim_u = 2
+        # opt-in: "reference" = dN_dx = Jinv * dN_dxi exactly as models.py:351; "physical" = Jinv^T
+        self.grad_convention = "reference"
         self.register_buffer("initial_node_coords", node_coords.clone())
         self.Nnodes = node_coords.shape[0]
         self.register_buffer("connectivity", connectivity.long().clone())
@@ -334,7 +336,8 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
     # -- the (x_ref, element_id) forward contract -------------------------------------------
     def forward(self, x_eval, elem_id, edge=False):
         if not edge:
-            return ops.Tri3EvalFn.apply(self.coords, self.u_full, self._conn32, x_eval, elem_id)
+            return ops.Tri3EvalFn.apply(self.coords, self.u_full, self._conn32, x_eval, elem_id,
+                                        1 if self.grad_convention == "physical" else 0)
         if self.neumann_edges is None:
             raise AttributeError("model was built without neumann_edges")
         return ops.Edge2EvalFn.apply(self.coords, self.u_full, self._edges32, x_eval[:, 0], elem_id)

@@ -56,7 +56,7 @@ class Tri3EnergyFn(torch.autograd.Function):
         tcv = None if Tconst is None else _dvec(Tconst)
         ctx.dtypes = (x_free.dtype, u_free.dtype)
         F32 = torch.float32
-        if (x_free.dtype == F32 and u_free.dtype == F32 and not any(float(b) != 0.0 for b in Bk)
+        if (x_free.dtype == F32 and u_free.dtype == F32 and not any(float(b) != 0.0 for b in Bk) and not (flags & (64 | 128))
                 and plan.stats["max_tile_nodes"] <= 1024 and plan.stats["max_tile_elems"] <= 2048):
             # fp32 model (the reference's default dtype): float rows in and out, fp64 arithmetic inside -- no widening copies
             xf, uf = require_gpu_tensor(x_free.detach(), "node_coords_free", F32), require_gpu_tensor(u_free.detach(), "u_free", F32)
@@ -127,7 +127,7 @@ class Tri3EvalFn(torch.autograd.Function):
     """(u_h, detJ, grad_u) at reference points of given elements; reference src/models.py:316-357."""
 
     @staticmethod
-    def forward(ctx, X, U, conn32, x_eval, elem_id):
+    def forward(ctx, X, U, conn32, x_eval, elem_id, convention=0):
         dev = X.device
         Xd, Ud, xe = _f64(X, "coords"), _f64(U, "u_full"), _f64(x_eval, "x_eval")
         eid = require_gpu_tensor(elem_id.contiguous(), "elem_id", torch.int64)
@@ -135,10 +135,11 @@ class Tri3EvalFn(torch.autograd.Function):
         u_h = torch.empty((m, 2), dtype=F64, device=dev)
         detJ = torch.empty((m,), dtype=F64, device=dev)
         grad_u = torch.empty((m, 2, 2), dtype=F64, device=dev)
-        check(_lib.lib().hfem_tri3_eval_fwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid), m,
-                                            ptr(u_h), ptr(detJ), ptr(grad_u), stream_ptr(dev)), "hfem_tri3_eval_fwd")
+        check(_lib.lib().hfem_tri3_eval_fwd_conv(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid), m,
+                                                 ptr(u_h), ptr(detJ), ptr(grad_u), int(convention), stream_ptr(dev)),
+              "hfem_tri3_eval_fwd")
         ctx.save_for_backward(Xd, Ud, conn32, xe, eid)
-        ctx.dt = X.dtype
+        ctx.dt, ctx.convention = X.dtype, int(convention)
         if X.dtype != F64:
             return u_h.to(X.dtype), detJ.to(X.dtype), grad_u.to(X.dtype)
         return u_h, detJ, grad_u
@@ -150,10 +151,10 @@ class Tri3EvalFn(torch.autograd.Function):
         dev = Xd.device
         gX, gU = torch.zeros_like(Xd), torch.zeros_like(Ud)
         cu, cd, cg = _f64(cu, "cu"), _f64(cd, "cd"), _f64(cg, "cg")
-        check(_lib.lib().hfem_tri3_eval_bwd(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid),
-                                            eid.shape[0], ptr(cu), ptr(cd), ptr(cg), ptr(gX), ptr(gU),
-                                            stream_ptr(dev)), "hfem_tri3_eval_bwd")
-        return gX.to(ctx.dt), gU.to(ctx.dt), None, None, None
+        check(_lib.lib().hfem_tri3_eval_bwd_conv(dev_index(dev), ptr(Xd), ptr(Ud), ptr(conn32), ptr(xe), ptr(eid),
+                                                 eid.shape[0], ptr(cu), ptr(cd), ptr(cg), ptr(gX), ptr(gU),
+                                                 ctx.convention, stream_ptr(dev)), "hfem_tri3_eval_bwd")
+        return gX.to(ctx.dt), gU.to(ctx.dt), None, None, None, None
 
 
 class Edge2EvalFn(torch.autograd.Function):

@@ -112,6 +112,13 @@ int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t ca
 #define HFEM_FLAG_NO_EDGES 4 /* domain energy only (EnergyLoss2D.domain_energy, src/loss.py:55-88) */
 #define HFEM_FLAG_NO_LOSS_SUM 8 /* leave the per-tile partial energies unsummed, loss_out untouched
                                    (gradient-only callers; bench.py's kernel-only roofline leg) */
+#define HFEM_FLAG_PHYSICAL_GRAD 64 /* opt-in: grad_u = G Jinv (HFEM_GRAD_PHYSICAL below) instead of the reference's
+                                   * G Jinv^T (src/models.py:351).  fp64 TRI3 plan path.            */
+#define HFEM_FLAG_DETERMINISTIC 128 /* fixed-order accumulation: gradients (and the loss) are bit-identical run to
+                                   * run.  Node-centric gather over the node -> element adjacency (every element
+                                   * is re-evaluated by each of its corners: 3x the flops, no atomics); the
+                                   * cross-check of the atomic kernels SURVEY section 5 asks for, ~3-4x slower.
+                                   * Whole plan only (tile_begin = 0, tile_end = -1 / n_tiles), fp64.          */
 #define HFEM_FLAG_SUM_PREVIOUS 32 /* with NO_LOSS_SUM: one extra workgroup of THIS launch sums the tile energies the
                                    * PREVIOUS NO_LOSS_SUM launch on this plan left (the plan keeps two banks) into
                                    * loss_out -- the energy of evaluation k arrives with launch k+1, and the 1-block
@@ -178,6 +185,19 @@ int hfem_tri3_eval_bwd(int device, const double *X, const double *U, const int32
                        const double *x_eval, const int64_t *elem_id, int64_t m,
                        const double *cu, const double *cd, const double *cg,
                        double *gX, double *gU, void *stream);
+/* Same two with an explicit gradient convention.  HFEM_GRAD_REFERENCE: dN_dx = Jinv * dN_dxi exactly as
+ * src/models.py:351 computes it (grad_u = G Jinv^T; the parity contract and the default everywhere).
+ * HFEM_GRAD_PHYSICAL (opt-in): dN_dx = Jinv^T * dN_dxi, i.e. grad_u = G Jinv -- the physical
+ * gradient: exact for linear fields and invariant to the local node order of an element.            */
+#define HFEM_GRAD_REFERENCE 0
+#define HFEM_GRAD_PHYSICAL 1
+int hfem_tri3_eval_fwd_conv(int device, const double *X, const double *U, const int32_t *conn,
+                            const double *x_eval, const int64_t *elem_id, int64_t m,
+                            double *u_h, double *detJ, double *grad_u, int32_t convention, void *stream);
+int hfem_tri3_eval_bwd_conv(int device, const double *X, const double *U, const int32_t *conn,
+                            const double *x_eval, const int64_t *elem_id, int64_t m,
+                            const double *cu, const double *cd, const double *cg,
+                            double *gX, double *gU, int32_t convention, void *stream);
 /* Edge branch of src/models.py:359-376: u_h [M][2], ds [M]; and its backward. */
 int hfem_edge2_eval_fwd(int device, const double *X, const double *U, const int32_t *edges,
                         const double *xi, const int64_t *edge_id, int64_t m,

@@ -90,12 +90,14 @@ def assemble_u(n_nodes, u_free_mask, u_free, dirichlet_mask, u_fixed):
     return out
 
 
-def tri3_forward(coords, u_full, conn, x_eval, elem_id):
+def tri3_forward(coords, u_full, conn, x_eval, elem_id, convention="reference"):
     """Domain branch of ``forward``, models.py:317-357.
 
     Returns ``u_h [M,2]``, ``detJ [M]``, ``grad_u [M,2,2]``.  ``dN_dx`` is
     ``Jinv @ dN_dxi`` exactly as models.py:351 (not the transposed, textbook
-    contraction -- SURVEY F4)."""
+    contraction -- SURVEY F4).  ``convention="physical"`` is NOT the reference: it is
+    the build's opt-in switch (``Jinv^T @ dN_dxi``), restated here so that its kernels
+    have an autograd checker too."""
     tri = coords[conn[elem_id]]                              # models.py:320,235
     xi, eta = x_eval[:, 0:1], x_eval[:, 1:2]
     N = torch.cat([xi, eta, 1.0 - xi - eta], dim=1)          # models.py:323-328
@@ -106,7 +108,10 @@ def tri3_forward(coords, u_full, conn, x_eval, elem_id):
     detJ = torch.linalg.det(Jmat)                            # models.py:340
     Jinv = torch.linalg.inv(Jmat)                            # models.py:343
     dN_dxi = torch.tensor([[1., 0., -1.], [0., 1., -1.]], dtype=coords.dtype)
-    dN_dx = torch.einsum("mij,jk->mik", Jinv, dN_dxi)        # models.py:351
+    if convention == "physical":
+        dN_dx = torch.einsum("mji,jk->mik", Jinv, dN_dxi)    # opt-in: Jinv^T (no reference counterpart)
+    else:
+        dN_dx = torch.einsum("mij,jk->mik", Jinv, dN_dxi)    # models.py:351
     grad_u = torch.einsum("mai,mja->mij", u_nodes, dN_dx)    # models.py:355
     return u_h, detJ, grad_u
 
@@ -139,13 +144,13 @@ def default_traction(x, L=1.0, F_total=100e3):
     return torch.stack([tx, torch.zeros_like(tx)], dim=1)
 
 
-def domain_energy(coords, u_full, conn, C, xg, wg, b_force=None):
+def domain_energy(coords, u_full, conn, C, xg, wg, b_force=None, convention="reference"):
     """loss.py:55-88.  ``b_force`` receives the *reference* points (F6)."""
     ne, ng = conn.shape[0], xg.shape[0]
     x_eval = xg.unsqueeze(0).expand(ne, ng, 2).reshape(-1, 2)             # loss.py:60
     elem_id = torch.arange(ne).unsqueeze(1).repeat(1, ng).reshape(-1)     # loss.py:61
     w_flat = wg.unsqueeze(0).repeat(ne, 1).reshape(-1)                    # loss.py:62
-    u_eval, detJ, grad_u = tri3_forward(coords, u_full, conn, x_eval, elem_id)
+    u_eval, detJ, grad_u = tri3_forward(coords, u_full, conn, x_eval, elem_id, convention)
     gx, gy = grad_u[:, 0, :], grad_u[:, 1, :]
     eps = torch.stack([gx[:, 0], gy[:, 1], 2 * (0.5 * (gx[:, 1] + gy[:, 0]))], dim=1)  # loss.py:70-73
     sig = eps @ C.T                                                       # loss.py:76
@@ -171,7 +176,7 @@ def edge_energy(coords, u_full, edges, xg1, wg1, t_force=None):
 
 
 def total_energy(coords_free, u_free, mesh, E=10e9, nu=0.3, gauss_order=4,
-                 gauss_order_1d=2, b_force=None, t_force=None):
+                 gauss_order_1d=2, b_force=None, t_force=None, convention="reference"):
     """``EnergyLoss2D.__call__`` (loss.py:113-116) on top of the model's
     ``coords`` / ``u_full`` assembly (models.py:292-305).
 
@@ -192,7 +197,7 @@ def total_energy(coords_free, u_free, mesh, E=10e9, nu=0.3, gauss_order=4,
         return assemble_u(mesh["n_nodes"], mesh["u_free_mask"], u_free,
                           mesh["dirichlet_mask"], mesh["u_fixed"])
 
-    dom = domain_energy(coords(), ufull(), mesh["conn"], C, xg, wg, b_force)
+    dom = domain_energy(coords(), ufull(), mesh["conn"], C, xg, wg, b_force, convention)
     if mesh.get("edges") is not None and mesh["edges"].shape[0] > 0:
         edg = edge_energy(coords(), ufull(), mesh["edges"], xg1, wg1, t_force)
     else:

@@ -11,7 +11,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhidenn_hip.so")
+# HFEM_LAB=1 (set by the tools under scripts/): the lab build of the same library (ablations, stamps, staggers, variant
+# kernels; `python hidenn_fem_amd/csrc/build.py --lab`).  The product never loads it.
+LIB_PATH = os.path.join(_HERE, "csrc", "libhidenn_hip_lab.so" if os.environ.get("HFEM_LAB") == "1" else "libhidenn_hip.so")
 
 _vp = C.c_void_p
 _i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double

@@ -1,6 +1,6 @@
 """Build libhidenn_hip.so in-tree with hipcc for gfx950 (MI355X / CDNA4 only).
 
-    python hidenn_fem_amd/csrc/build.py [--force] [--keep-temps]
+    python hidenn_fem_amd/csrc/build.py [--force] [--keep-temps] [--lab]
 
 One object per source (compiled in parallel), one link.  ``-munsafe-fp-atomics``
 selects the hardware fp64 atomics (``global_atomic_add_f64`` / ``ds_add_f64``)
@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["plan.cpp", "tri3_energy.hip", "tri3_stream.hip", "tri3_det.hip", "tri3_eval.hip", "line_rect.hip", "quad4.hip", "optim.hip", "exchange.hip", "post.hip", "lbfgs.hip"]
 HEADERS = ["hfem_common.h", "hfem_device.h", "hfem_plan_dev.h", os.path.join(ROOT, "include", "hidenn_fem.h")]
 OUT = os.path.join(HERE, "libhidenn_hip.so")
+OUT_LAB = os.path.join(HERE, "libhidenn_hip_lab.so")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
             "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
@@ -31,21 +32,28 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, keep_temps: bool = False) -> str:
+def build(force: bool = False, keep_temps: bool = False, lab: bool = False) -> str:
+    """``lab=True`` builds the second target, ``libhidenn_hip_lab.so`` (``-DHFEM_LAB``): the same library plus the
+    kernel-lab instrumentation -- ablation instances, s_memrealtime stamps, start staggers, the pipelined and the
+    streamed kernel variants -- that ``scripts/`` drives (``HFEM_LAB=1`` selects it in ``hidenn_fem_amd._lib``).
+    None of that is compiled into the product library."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bdir = os.path.join(HERE, "build", "lab") if lab else os.path.join(HERE, "build")
+    out = OUT_LAB if lab else OUT
+    flags = CXXFLAGS + (["-DHFEM_LAB"] if lab else [])
     srcs = [os.path.join(HERE, s) for s in SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
-    objs = [os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o") for s in SOURCES]
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objs = [os.path.join(bdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    os.makedirs(bdir, exist_ok=True)
 
     def compile_one(pair):
         src, obj = pair
         if not force and not _stale(obj, [src] + hdrs + [__file__]):
             return
-        cmd = [hipcc] + CXXFLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj]
         if keep_temps:
             cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-        r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.join(HERE, "build"))
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=bdir)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if keep_temps and r.stderr:
@@ -54,13 +62,13 @@ def build(force: bool = False, keep_temps: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
-    if force or _stale(OUT, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+    if force or _stale(out, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv))
+    print(build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv, lab="--lab" in sys.argv))

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "hfem_device.h"
 
 namespace hfem {
@@ -58,9 +60,15 @@ struct hfem_plan {
         bool ready = false;
     } det;
     double *d_partials = nullptr;             // two banks of [n_tiles] tile energies
-    int bank = 0;                             // bank the most recent launch wrote (host state; one plan = one stream)
+    // host-side launch state of the lagged loss sum, guarded by `mu`: one plan = one stream at a time (a
+    // HFEM_FLAG_SUM_PREVIOUS launch on a stream other than `prev_stream` is refused)
+    std::mutex mu;
+    int bank = 0;                             // bank the most recent launch wrote
     int prev_begin = 0, prev_n = 0;           // partial range of the most recent HFEM_FLAG_NO_LOSS_SUM launch
-    unsigned long long *d_stamps = nullptr;   // lab only: [n_tiles][8] s_memrealtime stamps
+    void *prev_stream = nullptr;              // ... and the stream it went to
+    // tuning options captured at creation (hfem_set_option only changes the defaults of LATER plans)
+    struct Tune { int tiled_block = 512, store_policy = 16, tiled_fast = 1, fast_const_caps = 1; } tune;
+    unsigned long long *d_stamps = nullptr;   // lab build only: [n_tiles][16] s_memrealtime stamps (NULL otherwise)
     int64_t device_bytes = 0;
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records

@@ -19,14 +19,14 @@ namespace hfem {
 
 constexpr int kBlockQ = 256;
 
-int g_quad4_stagger_groups = 2;
-// Lab: phase offset of groups of resident workgroups (bit `shift` of the launch index upward), in 10 ns ticks;
-// -1 = 2 us when the launch has at least 1.5 rounds of tiles.  On a warm chip it changes nothing on Q1M (27.8 us
-// with and without; the gain first read on a cold chip was clock ramp), so the default is off.
-int g_quad4_stagger = 0, g_quad4_stagger_shift = 8;
 int g_quad4_const_caps = 1;   // default tile shape: instance with a compile-time accumulator stride
+// Lab build only (-DHFEM_LAB): phase offset of groups of resident workgroups (bit `shift` of the launch index
+// upward), in 10 ns ticks; -1 = 2 us when the launch has at least 1.5 rounds of tiles.  On a warm chip it changes
+// nothing on Q1M (27.8 us with and without; the gain first read on a cold chip was clock ramp).
+int g_quad4_stagger_groups = 2;
+int g_quad4_stagger = 0, g_quad4_stagger_shift = 8;
 int g_quad4_pipe = 0;     // 0: one workgroup per tile; k > 0: persistent pipelined kernel, k workgroups per CU
-int g_quad4_ablate = 0;   // lab only: bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
+int g_quad4_ablate = 0;   // bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
 
 struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1
     double da, db, dc, dd;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
     int stagger_ticks, int stagger_shift, unsigned long long *__restrict__ stamps) {
 #define HFEM_QSTAMP(I)                                                                              \
-    if ((ABL & 4) && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+    if ((ABL & 4) && threadIdx.x == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_QSTAMP(0)
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     extern __shared__ double2 lds[];
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
 
     const int tid = threadIdx.x;
     const int slot = xcd_tile(blockIdx.x, gridDim.x);
+#ifdef HFEM_LAB
     // Phase offset between co-resident workgroups: without it every resident tile gathers at the same time and
     // then computes at the same time (HBM idle while the fp64 VALU works and vice versa).
     if (stagger_ticks > 0) {
@@ -306,9 +307,10 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
         const long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz: 10 ns ticks
         while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
     }
+#endif
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
-    if ((ABL & 4) && threadIdx.x == 0 && n_owned >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if ((ABL & 4) && threadIdx.x == 0 && n_owned >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
     int2 s[NPT];
     uint32_t pk[EPT], pk3[EPT];
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
 #undef HFEM_QSTAMP
 }
 
+#ifdef HFEM_LAB
 // ------------------------------------------------------------------ persistent, pipelined (QUAD4)
 // The one-workgroup-per-tile kernel above spends its memory phases (gather, write-out: ~16 us on Q1M) with the
 // fp64 VALU idle and its element stage (~11 us) with the memory system idle -- the two add up.  QUAD4's element
@@ -631,6 +634,8 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_pipe_kernel(
     const double tot = block_sum(e_loc, red);
     if (tid == 0) partials[blockIdx.x] = tot;
 }
+#endif  // HFEM_LAB
+
 
 __global__ __launch_bounds__(256) void quad4_sum_partials_kernel(const double *__restrict__ partials, int n,
                                                                  double *__restrict__ out) {
@@ -722,7 +727,9 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
                        plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free, \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
                        (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger, g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps)
+#ifdef HFEM_LAB
         const int abl = g_quad4_ablate;
+        const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
         if (g_quad4_pipe > 0 && abl == 0 && h.max_nodes <= 3 * 256 && h.max_elems <= 4 * 256 &&
             plan->lds_bytes_pipe <= 64 * 1024) {
             int G = g_quad4_pipe * 256;
@@ -740,12 +747,15 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
             hipLaunchKernelGGL(quad4_sum_partials_kernel, dim3(1), dim3(256), 0, s, plan->d_partials + tile_begin, G, loss_out);
             return launch_status("hfem_quad4_energy_plan(sum)");
         }
-        const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
         if (abl == 1) HFEM_LAUNCH_Q4(4, 4, 1);                       // lab instances (hfem_set_option("quad4_ablate"))
         else if (abl == 2) HFEM_LAUNCH_Q4(4, 4, 2);
         else if (abl == 3) HFEM_LAUNCH_Q4(4, 4, 3);
         else if (abl == 4) HFEM_LAUNCH_Q4(4, 4, 4);                  // s_memrealtime phase stamps (scripts/stamps.py)
-        else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
+        else
+#else
+        const int stagger = 0;
+#endif
+        if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
         else if (g_quad4_const_caps && h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 40960) {
             // default tile shape: compile-time accumulator stride (launched with the matching LDS size)
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 4, 4, 0, 560>), dim3(n), dim3(256),

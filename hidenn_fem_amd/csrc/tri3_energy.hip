@@ -13,8 +13,11 @@
 //    16-B store.  Bandwidth-bound, no MFMA (2x2 / 2x3 contractions).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "hfem_device.h"
 #include "hfem_plan_dev.h"
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(kBlock) void edge2_energy_atomic_kernel(
 }
 
 // ------------------------------------------------------------------ tiled plan
-// Ablation bits of the lab build (hfem_set_option("tiled_ablate", bits)); 0 in production.
+// Ablation bits (ABL) exist for the lab build only (hfem_set_option("tiled_ablate", bits) of libhidenn_hip_lab.so);
+// the product library instantiates ABL = 0, so every `if (ABL & ...)` below is compiled out of it.
 //   1: LDS atomics -> plain LDS stores    2: skip the element/edge phase
 //   4: skip the global node gather        8: skip the gradient write-out
 //  16: no LDS node reads in the element loop (synthetic operands)   32: no LDS accumulate at all
@@ -106,8 +110,9 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
     const int tid = threadIdx.x;
     const int slot = xcd_tile(blockIdx.x, gridDim.x);
 #define HFEM_STAMP(I)                                                                              \
-    if ((ABL & 64) && tid == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+    if ((ABL & 64) && tid == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_STAMP(0)
+#ifdef HFEM_LAB
     // Stagger the start of co-resident workgroups: all resident tiles otherwise gather at the same
     // time and then compute at the same time (HBM idle while the VALU/LDS work, and vice versa).
     if (stagger_ticks > 0) {
@@ -120,8 +125,9 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
         const long long t_start = __builtin_amdgcn_s_memrealtime();
         while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
     }
+#endif
     const TileDesc d = pd.tiles[tile_begin + slot];
-    if ((ABL & 64) && tid == 0 && d.n_node >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if ((ABL & 64) && tid == 0 && d.n_node >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 1: gather node data through the free/fixed maps, clear accumulators
     const int2 *src = pd.node_src + d.node_off;
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     V2 *__restrict__ gu_free, int cap_nodes_rt, int cap_owned_rt, int skip_edges, int stagger_ticks, int stagger_cfg,
     unsigned long long *__restrict__ stamps, AdamFuse af, LagSum lag) {
 #define HFEM_FSTAMP(I)                                                                             \
-    if (STAMP && threadIdx.x == 0) stamps[8 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+    if (STAMP && threadIdx.x == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_FSTAMP(0)
     const int cap_nodes = CAPN > 0 ? CAPN : cap_nodes_rt, cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     extern __shared__ double2 lds[];
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         return;
     }
     const int slot = xcd_tile(blockIdx.x, n_launch);
+#ifdef HFEM_LAB
     // lab (hfem_set_option("fast_stagger")): phase offset between groups of co-resident workgroups, so that one
     // group gathers while another is in its element stage.  stagger_cfg = bit | (groups - 1) << 8.
     if (stagger_ticks > 0) {
@@ -281,9 +288,10 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         const long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz: 10 ns ticks
         while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
     }
+#endif
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
-    if (STAMP && threadIdx.x == 0 && n_owned >= 0) stamps[8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (STAMP && threadIdx.x == 0 && n_owned >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- all index loads first: row maps and element records
     int2 s[NPT];
@@ -447,6 +455,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
 #undef HFEM_FSTAMP
 }
 
+#ifdef HFEM_LAB
 // ------------------------------------------------------------------ persistent, pipelined
 // Same tile algorithm, but a workgroup walks a contiguous run of tiles and overlaps the HBM
 // phase of tile t+1 with the VALU/LDS phase of tile t (register-staged prefetch): the gather of
@@ -666,6 +675,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
     const double tot = block_sum(e_loc, red);
     if (tid == 0) partials[blockIdx.x] = tot;
 }
+#endif  // HFEM_LAB
 
 // Deterministic sum of the per-tile partial energies (fixed order).
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double *__restrict__ partials, int n,
@@ -678,40 +688,190 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double *__re
 }
 
 }  // namespace hfem
-
 // ====================================================================== C ABI
 using namespace hfem;
 
-// ---- tuning / lab options (process-wide; hfem_set_option)
-static int g_tiled_block = 512;    // threads per tile (measured best on T1M: 512 at 1024-element tiles)
-static int g_tiled_ablate = 0;
-static int g_plan_elem_order = 3;  // 3: LDS-bank-aware 16-lane groups (plan.cpp); 4: the same inside three spatial strips per tile (streamed kernel)
-static int g_tiled_stagger = 0;  // total start-time spread of the tiled kernel's workgroups, in 10 ns ticks
-static int g_tiled_stagger_mode = 0;
-static int g_plan_node_cap = -1; // max distinct nodes among a tile's own elements; 0: cut by element count only;
-                                 // -1 (auto): 557 when tile_elems is left to the library, else 0.  557 nodes keep
-                                 // (n_node + n_owned) * 32 B <= 38.9 KB, the largest footprint that still lets four
-                                 // 512-thread workgroups share a CU's 160 KB of LDS (measured).
-static int g_store_policy = 16;  // gradient stores of the fast kernel: 16 = sc1 (write-through: the line is dropped from
-                                 // the XCD's L2 and does not evict the re-read inputs / plan arrays), 0 = plain
-static int g_tiled_fast = 1;     // register-prefetched tiled kernel (falls back to the loop kernel)
-// Lab: phase offset between groups of co-resident workgroups of the fast kernel (group = bits [shift, shift+log2
-// groups) of the launch index; group g starts g/(groups-1) * ticks later), in 10 ns ticks; -1 = 1.5 us when the
-// launch fills the chip.  Measured on a warm chip (bench.py A/B, T1M): 11.25 us without, 11.3 us with -- no gain
-// for TRI3 (its element stage is short), so the default is off.  (The tiled QUAD4 kernel does gain, quad4.hip.)
-static int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
-static int g_fast_const_caps = 1; // default tile shape: instance with compile-time LDS strides
-static int g_plan_chunk_cap = 512; // chunked plans: longest strip a tile may have (slots); the streamed kernel walks a strip per pass
-static int g_stream_ablate = 0;   // lab
-static int g_tri3_stream = 0;    // 1: chunked plans (plan_elem_order 4) take the streamed kernel (tri3_stream.hip) -- measured slower, kept for the lab
-static int g_tiled_pipe = 0;     // 0: one workgroup per tile; k>0: persistent pipelined, k workgroups per CU
+// ---- tuning options.  hfem_set_option changes the DEFAULTS (atomics: no data race); hfem_plan_create captures them into
+// the plan (hfem_plan::tune), and a plan keeps the values it was created with -- so an option change never alters what
+// a concurrent launch on an existing plan does.  Lab knobs (ablations, stamps, staggers, pipelined / streamed variants)
+// exist in the -DHFEM_LAB build only (libhidenn_hip_lab.so, hidenn_fem_amd/csrc/build.py --lab).
+namespace {
+struct Defaults {
+    std::atomic<int> tiled_block{512};      // threads per tile (measured best on T1M: 512)
+    std::atomic<int> store_policy{16};      // gradient stores: 16 = sc1 (write-through: the line is dropped from the XCD's
+                                            // L2 and does not evict the re-read inputs / plan arrays), 0 = plain
+    std::atomic<int> tiled_fast{1};         // register-prefetched kernel (0: the generic loop kernel)
+    std::atomic<int> fast_const_caps{1};    // default tile shape: instance with compile-time accumulator strides
+    std::atomic<int> plan_elem_order{3};    // 3: LDS-bank-aware 16-lane groups (plan.cpp); 4: the same inside three strips
+    std::atomic<int> plan_node_cap{-1};     // max distinct nodes among a tile's own elements; 0: cut by element count only;
+                                            // -1 (auto): 557 when tile_elems is left to the library, else 0.  557 nodes keep
+                                            // (n_node + n_owned) * 32 B <= 38.9 KB: four 512-thread workgroups per CU
+    std::atomic<int> plan_chunk_cap{512};   // chunked plans: longest strip of a tile (slots)
+} g_def;
 
-static int grid_for(int64_t n, int cap = 256 * 8) {
+#ifdef HFEM_LAB
+int g_tiled_ablate = 0, g_tiled_stagger = 0, g_tiled_stagger_mode = 0;
+int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
+int g_tiled_pipe = 0;      // k > 0: persistent pipelined kernel, k workgroups per CU
+int g_tri3_stream = 0;     // chunked plans take the streamed kernel (tri3_stream.hip)
+int g_stream_ablate = 0;
+#endif
+
+hfem_plan::Tune current_tune() {
+    hfem_plan::Tune t;
+    t.tiled_block = g_def.tiled_block.load();
+    t.store_policy = g_def.store_policy.load();
+    t.tiled_fast = g_def.tiled_fast.load();
+    t.fast_const_caps = g_def.fast_const_caps.load();
+    return t;
+}
+
+int grid_for(int64_t n, int cap = 256 * 8) {
     int64_t g = (n + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return (int)g;
 }
+
+// everything a tiled launch passes to its kernel, whatever the instance
+struct Tri3Launch {
+    PlanDev pd;
+    int tile_begin = 0;
+    const void *x_free = nullptr, *x_fixed = nullptr, *u_free = nullptr, *u_fixed = nullptr;
+    Tri3Consts k;
+    const double4 *T_edge = nullptr;
+    double4 tc;
+    double *partials = nullptr;
+    void *gx = nullptr, *gu = nullptr;
+    int max_nodes = 0, max_owned = 0, skip_edges = 0;
+    unsigned long long *stamps = nullptr;
+    size_t lds = 0;
+    hipStream_t s = nullptr;
+    int stagger = 0, stagger_cfg = 0x108;          // lab only (0 in the product build)
+};
+
+template <int BLK, int NPT, int EPT, bool HB, int SP, typename V2, int CO, bool ADAM, bool PHYS, bool STAMP = false>
+void launch_fast(const Tri3Launch &A, int grid, const AdamFuse &af, const LagSum &lag) {
+    const size_t lds = CO > 0 ? (size_t)(A.max_nodes * 32 + CO * 32 + 128) : A.lds;
+    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, STAMP, SP, V2, 0, CO, ADAM, PHYS>), dim3(grid), dim3(BLK),
+                       lds, A.s, A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
+                       (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
+                       CO > 0 ? CO : A.max_owned, A.skip_edges, A.stagger, A.stagger_cfg, A.stamps, af, lag);
+}
+
+template <int BLK>
+void launch_generic(const Tri3Launch &A, int grid) {
+    hipLaunchKernelGGL((tri3_energy_tiled_kernel<BLK, 0>), dim3(grid), dim3(BLK), A.lds, A.s, A.pd, A.tile_begin,
+                       (const double2 *)A.x_free, (const double2 *)A.x_fixed, (const double2 *)A.u_free,
+                       (const double2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (double2 *)A.gx, (double2 *)A.gu,
+                       A.max_nodes, A.max_owned, A.skip_edges, 0, 0, A.stamps);
+}
+
+// fp64 rows, reference convention: the instance of the register-prefetched kernel that holds this plan's tile shape
+// (false: none does -- the caller takes the generic loop kernel).  `lag` only reaches the default instances
+// (512 threads, no body force, write-through stores); the entry point has checked that before asking for it.
+bool launch_fast_f64(const hfem_plan *plan, const Tri3Launch &A, int n, bool hasb, const LagSum &lag) {
+    const HostPlan &h = plan->host;
+    const int blk = plan->tune.tiled_block, sp = plan->tune.store_policy;
+    const int n_lag = n + (lag.prev ? 1 : 0);
+    // default shape (auto tile policy: <= 557 owned nodes): compile-time stride of the four accumulator arrays (12 of an
+    // element's 18 LDS addresses); the footprint must stay <= 38 912 B (four workgroups per CU)
+    if (plan->tune.fast_const_caps && blk == 512 && !hasb && sp == 16 && h.max_nodes > 512 && h.max_owned <= 560 &&
+        h.max_nodes * 32 + 560 * 32 + 128 <= 38912 && h.max_elems <= 3 * 512) {
+        launch_fast<512, 2, 3, false, 16, double2, 560, false, false>(A, n_lag, AdamFuse{}, lag);
+        return true;
+    }
+#define HFEM_FAST_HB(BLK, NPT, EPT)                                                                                       \
+    {                                                                                                                     \
+        if (hasb) launch_fast<BLK, NPT, EPT, true, 0, double2, 0, false, false>(A, n, AdamFuse{}, LagSum{});             \
+        else if (sp == 0) launch_fast<BLK, NPT, EPT, false, 0, double2, 0, false, false>(A, n, AdamFuse{}, LagSum{});    \
+        else launch_fast<BLK, NPT, EPT, false, 16, double2, 0, false, false>(A, n_lag, AdamFuse{}, lag);                 \
+        return true;                                                                                                      \
+    }
+    if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_FAST_HB(512, 1, 2)
+    if (blk == 256 && h.max_nodes <= 2 * 256 && h.max_elems <= 4 * 256) HFEM_FAST_HB(256, 2, 4)
+    if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
+    if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) HFEM_FAST_HB(512, 2, 4)
+    if (blk == 256 && h.max_nodes <= 4 * 256 && h.max_elems <= 6 * 256) HFEM_FAST_HB(256, 4, 6)
+    if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_FAST_HB(1024, 1, 2)
+#undef HFEM_FAST_HB
+    return false;
+}
+
+#ifdef HFEM_LAB
+// lab variants of the TRI3 plan launch (ablations, stamps, pipelined and streamed kernels).  true: launched.
+bool launch_tri3_lab(const hfem_plan *plan, Tri3Launch &A, int n, bool hasb, const LagSum &lag, int *n_partials) {
+    const HostPlan &h = plan->host;
+    const int blk = plan->tune.tiled_block, abl = g_tiled_ablate;
+    if (g_tiled_pipe > 0 && abl == 0) {
+        int G = std::min(g_tiled_pipe * 256, n);
+        if ((n + G - 1) / G > kPipeMaxTiles) G = (n + kPipeMaxTiles - 1) / kPipeMaxTiles;
+#define HFEM_LAUNCH_PIPE(BLK, NPT, EPT)                                                                                  \
+    {                                                                                                                    \
+        hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes_pipe,   \
+                           A.s, A.pd, A.tile_begin, n, (const double2 *)A.x_free, (const double2 *)A.x_fixed,            \
+                           (const double2 *)A.u_free, (const double2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials,       \
+                           (double2 *)A.gx, (double2 *)A.gu, h.max_nodes, h.max_owned, A.skip_edges);                    \
+        *n_partials = G;                                                                                                 \
+        return true;                                                                                                     \
+    }
+        if (A.x_free && A.u_free && h.nn > 0 && h.ne > 0) {      // clamped (branch-free) prefetch loads read row 0
+            if (blk == 256 && h.max_nodes <= 512 && h.max_elems <= 3 * 256) HFEM_LAUNCH_PIPE(256, 2, 3)
+            if (blk == 256 && h.max_nodes <= 1024 && h.max_elems <= 6 * 256) HFEM_LAUNCH_PIPE(256, 4, 6)
+            if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_LAUNCH_PIPE(512, 1, 2)
+            if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 3 * 512) HFEM_LAUNCH_PIPE(512, 2, 3)
+            if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 4 * 512) HFEM_LAUNCH_PIPE(512, 2, 4)
+            if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_LAUNCH_PIPE(1024, 1, 2)
+        }
+#undef HFEM_LAUNCH_PIPE
+    }
+    if (abl == 64 && plan->tune.tiled_fast && blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 2048) {
+        launch_fast<512, 2, 4, false, 16, double2, 0, false, false, true>(A, n, AdamFuse{}, LagSum{});   // stamped instance
+        return true;
+    }
+    if (abl == 0 && g_tri3_stream && !hasb && blk == 512 &&
+        launch_tri3_stream(plan, n + (lag.prev ? 1 : 0), A.tile_begin, (const double *)A.x_free, (const double *)A.x_fixed,
+                           (const double *)A.u_free, (const double *)A.u_fixed, A.k, (const double *)A.T_edge, A.tc,
+                           A.partials, (double *)A.gx, (double *)A.gu, A.skip_edges, plan->tune.store_policy, lag, A.s,
+                           g_stream_ablate) == 1)
+        return true;
+    if (abl != 0) {      // ablations of the generic loop kernel at 256 / 512 threads
+#define HFEM_LAUNCH_ABL(BLK, ABL)                                                                                        \
+    hipLaunchKernelGGL((tri3_energy_tiled_kernel<BLK, ABL>), dim3(n), dim3(BLK), A.lds, A.s, A.pd, A.tile_begin,          \
+                       (const double2 *)A.x_free, (const double2 *)A.x_fixed, (const double2 *)A.u_free,                 \
+                       (const double2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (double2 *)A.gx, (double2 *)A.gu,    \
+                       A.max_nodes, A.max_owned, A.skip_edges, g_tiled_stagger, g_tiled_stagger_mode, A.stamps)
+#define HFEM_ABL_CASE(V) case V: if (blk == 512) HFEM_LAUNCH_ABL(512, V); else HFEM_LAUNCH_ABL(256, V); return true;
+        switch (abl) {
+            HFEM_ABL_CASE(1) HFEM_ABL_CASE(2) HFEM_ABL_CASE(4) HFEM_ABL_CASE(6) HFEM_ABL_CASE(8) HFEM_ABL_CASE(5)
+            HFEM_ABL_CASE(13) HFEM_ABL_CASE(128) HFEM_ABL_CASE(384) HFEM_ABL_CASE(640) HFEM_ABL_CASE(129) HFEM_ABL_CASE(64)
+            HFEM_ABL_CASE(10) HFEM_ABL_CASE(14) HFEM_ABL_CASE(32) HFEM_ABL_CASE(48) HFEM_ABL_CASE(16)
+            default: break;
+        }
+#undef HFEM_ABL_CASE
+#undef HFEM_LAUNCH_ABL
+    }
+    return false;
+}
+#endif  // HFEM_LAB
+
+// Host-side launch state of a plan (partials bank of the lagged loss sum).  One plan = one stream at a time: the state
+// is guarded by the plan's mutex, and a HFEM_FLAG_SUM_PREVIOUS launch must come on the stream that left the partials.
+struct PlanLock {
+    explicit PlanLock(hfem_plan *p) : g(p->mu) {}
+    std::lock_guard<std::mutex> g;
+};
+
+template <typename T>
+int hfem_upload(T **dst, const void *src, size_t count, int64_t &bytes) {
+    const size_t nb = std::max<size_t>(count, 1) * sizeof(T);
+    HFEM_HIP_CHECK(hipMalloc((void **)dst, nb));
+    if (count && src) HFEM_HIP_CHECK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    if (!src) HFEM_HIP_CHECK(hipMemset(*dst, 0, nb));
+    bytes += (int64_t)nb;
+    return 0;
+}
+}  // namespace
 
 extern "C" int hfem_tri3_energy_atomic(int device, const double *X, const double *U, const int32_t *conn,
                                        int64_t e_begin, int64_t e_end, int64_t nn, const double mat[4],
@@ -744,16 +904,6 @@ extern "C" int hfem_edge2_energy_atomic(int device, const double *X, const doubl
     return launch_status("hfem_edge2_energy_atomic");
 }
 
-template <typename T>
-int hfem_upload(T **dst, const void *src, size_t count, int64_t &bytes) {
-    const size_t nb = std::max<size_t>(count, 1) * sizeof(T);
-    HFEM_HIP_CHECK(hipMalloc((void **)dst, nb));
-    if (count && src) HFEM_HIP_CHECK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
-    if (!src) HFEM_HIP_CHECK(hipMemset(*dst, 0, nb));
-    bytes += (int64_t)nb;
-    return 0;
-}
-
 extern "C" int hfem_plan_destroy(hfem_plan *plan) {
     if (!plan) return 0;
     if (plan->device >= 0) {
@@ -773,10 +923,6 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
     return 0;
 }
 
-extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, int64_t nn, int32_t nodes_per_elem,
-                                   const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
-                                   const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out);
-
 extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
                                 const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
                                 const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out) {
@@ -789,10 +935,13 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     HFEM_ARG_CHECK(out, "null out pointer");
     *out = nullptr;
     std::unique_ptr<hfem_plan> p(new hfem_plan);
-    int32_t node_cap = g_plan_node_cap;
+    p->tune = current_tune();
+    int32_t node_cap = g_def.plan_node_cap.load();
     if (node_cap < 0) node_cap = tile_elems <= 0 ? 557 : 0;
     if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
-    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, g_plan_elem_order, g_plan_chunk_cap, p->host)) return -1;
+    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap,
+                        g_def.plan_elem_order.load(), g_def.plan_chunk_cap.load(), p->host))
+        return -1;
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
@@ -809,8 +958,10 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
         if (!rc && !h.tile_chunks.empty()) rc = hfem_upload(&raw->d_tile_chunks, h.tile_chunks.data(), h.tile_chunks.size() / 4, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
+#ifdef HFEM_LAB
         if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, (h.tiles.size() + 1) * 16, raw->device_bytes);
-        if (!rc && p->lds_bytes_pipe > 64 * 1024) {
+#endif
+        if (!rc && p->lds_bytes > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
             rc = -1;
         }
@@ -851,10 +1002,10 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 5: src = h.elem_gid.data(); n = (int64_t)h.elem_gid.size(); break;
         case 7: src = h.elem_pack_hi.data(); n = (int64_t)h.elem_pack_hi.size(); break;
         case 8: src = h.tile_chunks.data(); n = (int64_t)h.tile_chunks.size(); break;
-        case 6: {   // lab: device stamps, 16 x uint64 per tile, returned as 32 x int32 per tile
+        case 6: {   // lab build: device stamps, 16 x uint64 per tile, returned as 32 x int32 per tile
             n = (int64_t)h.tiles.size() * 32;
             if (buf) {
-                if (cap_elems < n || plan->device < 0) { set_error("hfem_plan_export: stamps need a device plan + buffer"); return -1; }
+                if (cap_elems < n || plan->device < 0 || !plan->d_stamps) { set_error("hfem_plan_export: stamps need the lab build, a device plan and a buffer"); return -1; }
                 (void)hipSetDevice(plan->device);
                 if (hipMemcpy(buf, plan->d_stamps, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("hfem_plan_export: stamp copy failed"); return -1; }
             }
@@ -879,23 +1030,30 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4: use hfem_quad4_energy_plan");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
-    const int32_t nt = (int32_t)plan->host.tiles.size();
+    const HostPlan &h = plan->host;
+    const int32_t nt = (int32_t)h.tiles.size();
     if (tile_end < 0) tile_end = nt;
     HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
-    HFEM_ARG_CHECK(plan->host.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
+    HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
     if (int rc = use_device(plan->device)) return rc;
+    PlanLock lock(plan);
+#ifdef HFEM_LAB
+    plan->tune = current_tune();              // lab tooling flips options between launches on one plan (single-threaded)
+#endif
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
+    const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+    bool hasb = false;
+    for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
     const bool phys = (flags & HFEM_FLAG_PHYSICAL_GRAD) != 0;
-    const bool phys_fast = phys && !(flags & HFEM_FLAG_DETERMINISTIC) && g_tiled_block == 512 && g_tiled_ablate == 0 &&
-                           g_tiled_pipe == 0 && plan->host.max_nodes <= 2 * 512 && plan->host.max_elems <= 4 * 512;
+    const bool phys_fast = phys && !(flags & HFEM_FLAG_DETERMINISTIC) && plan->tune.tiled_block == 512 &&
+                           h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512;
     if ((flags & HFEM_FLAG_DETERMINISTIC) || (phys && !phys_fast)) {
         // fixed-order node-centric path (tri3_det.hip); also carries the physical convention for plan shapes the
         // tiled PHYS instance does not hold
         HFEM_ARG_CHECK(tile_begin == 0 && tile_end == nt, "HFEM_FLAG_DETERMINISTIC / physical fallback: whole plan only");
         HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_LOSS_SUM | HFEM_FLAG_SUM_PREVIOUS)), "HFEM_FLAG_DETERMINISTIC always delivers the loss");
-        const double4 tcd = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
-        return launch_tri3_det(plan, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk), T_edge, tcd, loss_out,
+        return launch_tri3_det(plan, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk), T_edge, tc, loss_out,
                                (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free, (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free,
                                (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, phys, s);
     }
@@ -904,199 +1062,54 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0;
     HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
     HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
+    HFEM_ARG_CHECK(!lag_consume || plan->prev_stream == stream,
+                   "HFEM_FLAG_SUM_PREVIOUS: the previous unsummed launch went to another stream (one plan = one stream)");
     const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
     double *pbase = plan->d_partials + (size_t)wbank * nt;
     LagSum lag;
     if (lag_consume) {
-        bool hasb0 = false;
-        for (int i = 0; i < 6; ++i) hasb0 = hasb0 || (Bk && Bk[i] != 0.0);
-        HFEM_ARG_CHECK(g_tiled_fast && g_tiled_pipe == 0 && g_tiled_ablate == 0 && g_tiled_block == 512 && !hasb0 &&
-                       g_store_policy == 16 && plan->host.max_nodes <= 1024 && plan->host.max_elems <= 2048,
+        HFEM_ARG_CHECK(plan->tune.tiled_fast && plan->tune.tiled_block == 512 && !hasb && !phys && plan->tune.store_policy == 16 &&
+                       h.max_nodes <= 1024 && h.max_elems <= 2048,
                        "HFEM_FLAG_SUM_PREVIOUS: only the default (register-prefetched, 512-thread) kernel path implements it");
         lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
         lag.prev_n = plan->prev_n;
         lag.out = loss_out;
     }
-    const int n_grid = n + (lag_consume ? 1 : 0);
+    int n_partials = n;
     if (n > 0) {
-        PlanDev pd = plan_dev(plan);
-        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
-        int n_partials = n;
+        Tri3Launch A;
+        A.pd = plan_dev(plan); A.tile_begin = (int)tile_begin;
+        A.x_free = x_free; A.x_fixed = x_fixed; A.u_free = u_free; A.u_fixed = u_fixed;
+        A.k = make_consts(mat, W, Bk); A.T_edge = (const double4 *)T_edge; A.tc = tc; A.partials = pbase + tile_begin;
+        A.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; A.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
+        A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
+        A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
         bool launched = false;
-        if (g_tiled_pipe > 0 && g_tiled_ablate == 0) {
-            const HostPlan &h = plan->host;
-            int G = g_tiled_pipe * 256;
-            if (G > n) G = n;
-            if ((n + G - 1) / G > kPipeMaxTiles) G = (n + kPipeMaxTiles - 1) / kPipeMaxTiles;
-#define HFEM_LAUNCH_PIPE(BLK, NPT, EPT)                                                                     \
-    hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes_pipe, s, \
-                       pd, (int)tile_begin, n, (const double2 *)x_free, (const double2 *)x_fixed,           \
-                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
-                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0)
-            const int blk = g_tiled_block;
-            // clamped (branch-free) prefetch loads read row 0 of every array: all four must exist
-            const bool rows0 = x_free && u_free && h.nn > 0 && h.ne > 0;
-            const double *xfix0 = x_fixed ? x_fixed : x_free, *ufix0 = u_fixed ? u_fixed : u_free;
-            (void)xfix0; (void)ufix0;
-            if (!rows0) {
-            } else if (blk == 256 && h.max_nodes <= 512 && h.max_elems <= 3 * 256) { HFEM_LAUNCH_PIPE(256, 2, 3); launched = true; }
-            else if (blk == 256 && h.max_nodes <= 1024 && h.max_elems <= 6 * 256) { HFEM_LAUNCH_PIPE(256, 4, 6); launched = true; }
-            else if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) { HFEM_LAUNCH_PIPE(512, 1, 2); launched = true; }
-            else if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 3 * 512) { HFEM_LAUNCH_PIPE(512, 2, 3); launched = true; }
-            else if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 4 * 512) { HFEM_LAUNCH_PIPE(512, 2, 4); launched = true; }
-            else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) { HFEM_LAUNCH_PIPE(1024, 1, 2); launched = true; }
-#undef HFEM_LAUNCH_PIPE
-            if (launched) n_partials = G;
+#ifdef HFEM_LAB
+        A.stagger = g_fast_stagger >= 0 ? g_fast_stagger : (n >= 768 ? 150 : 0);
+        A.stagger_cfg = g_fast_stagger_shift | ((g_fast_stagger_groups - 1) << 8);
+        if (!phys) launched = launch_tri3_lab(plan, A, n, hasb, lag, &n_partials);
+#endif
+        if (!launched && phys_fast) {     // opt-in physical convention: one general instance of the register-prefetched kernel
+            launch_fast<512, 2, 4, true, 16, double2, 0, false, true>(A, n, AdamFuse{}, LagSum{});
+            launched = true;
         }
+        if (!launched && plan->tune.tiled_fast) launched = launch_fast_f64(plan, A, n, hasb, lag);
         if (!launched) {
-#define HFEM_LAUNCH_TILED(BLK, ABL)                                                                        \
-    hipLaunchKernelGGL((tri3_energy_tiled_kernel<BLK, ABL>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, pd, \
-                       (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,                  \
-                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
-                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, plan->host.max_nodes,      \
-                       plan->host.max_owned, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, g_tiled_stagger,         \
-                       g_tiled_stagger_mode, plan->d_stamps)
-        const int abl = g_tiled_ablate;
-        const int fast_stagger_cfg = g_fast_stagger_shift | ((g_fast_stagger_groups - 1) << 8);
-        const int fast_stagger = g_fast_stagger >= 0 ? g_fast_stagger : (n >= 768 ? 150 : 0);
-        bool fast = false;
-        if (abl == 64 && g_tiled_fast && g_tiled_block == 512 && plan->host.max_nodes <= 1024 &&
-            plan->host.max_elems <= 2048) {      // lab: stamped instance of the production kernel
-            const HostPlan &h = plan->host;
-            hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, false, true, 16>), dim3(n), dim3(512),
-                               (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const double2 *)x_free,
-                               (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
-                               make_consts(mat, W, Bk), (const double4 *)T_edge, tc, pbase + tile_begin,
-                               (double2 *)gx_free, (double2 *)gu_free, h.max_nodes, h.max_owned,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, LagSum{});
-            fast = true;
-        }
-        if (phys_fast) {      // opt-in physical gradient convention: one general instance of the register-prefetched kernel
-            const HostPlan &h = plan->host;
-            HFEM_ARG_CHECK(!lag_consume, "HFEM_FLAG_PHYSICAL_GRAD: no HFEM_FLAG_SUM_PREVIOUS");
-            hipLaunchKernelGGL((tri3_energy_fast_kernel<512, 2, 4, true, false, 16, double2, 0, 0, false, true>), dim3(n),
-                               dim3(512), (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const double2 *)x_free,
-                               (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,
-                               make_consts(mat, W, Bk), (const double4 *)T_edge, tc, pbase + tile_begin,
-                               (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
-                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, AdamFuse{}, LagSum{});
-            fast = true;
-        }
-        if (!fast && abl == 0 && g_tiled_fast) {
-            const HostPlan &h = plan->host;
-            bool hasb = false;
-            for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
-            if (g_tri3_stream && !hasb && g_tiled_block == 512 &&
-                launch_tri3_stream(plan, n_grid, (int)tile_begin, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk),
-                                   T_edge, tc, pbase + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free,
-                                   (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free, (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0,
-                                   g_store_policy, lag, s, g_stream_ablate) == 1)
-                fast = true;
-            if (!fast) {
-#define HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, HB, SPV)                                                         \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, false, SPV>), dim3(n_grid), dim3(BLK), (size_t)plan->lds_bytes, s, \
-                       pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
-                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
-                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, lag)
-#define HFEM_LAUNCH_FAST(BLK, NPT, EPT, HB)                                                                 \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB>), dim3(n), dim3(BLK), (size_t)plan->lds_bytes, s, \
-                       pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
-                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
-                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, LagSum{})
-#define HFEM_LAUNCH_FAST_CC(NPT, EPT, CN, CO)                                                               \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, CN, CO>), dim3(n_grid), dim3(512), \
-                       (size_t)((CN > 0 ? CN : h.max_nodes) * 32 + CO * 32 + 128), s,                       \
-                       pd, (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,              \
-                       (const double2 *)u_free, (const double2 *)u_fixed, make_consts(mat, W, Bk),          \
-                       (const double4 *)T_edge, tc, pbase + tile_begin,                          \
-                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,                            \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, CO,           \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, fast_stagger, fast_stagger_cfg, plan->d_stamps, AdamFuse{}, lag)
-#define HFEM_FAST_HB(BLK, NPT, EPT)                                                   \
-    {                                                                                 \
-        if (hasb) HFEM_LAUNCH_FAST(BLK, NPT, EPT, true);                              \
-        else if (g_store_policy == 0) HFEM_LAUNCH_FAST(BLK, NPT, EPT, false);         \
-        else HFEM_LAUNCH_FAST_SP(BLK, NPT, EPT, false, 16);                           \
-        fast = true;                                                                  \
-    }
-            const int blk = g_tiled_block;
-            // default shape (auto tile policy: <= 557 owned nodes): compile-time stride of the four accumulator arrays
-            // (12 of an element's 18 LDS addresses); a constant node stride as well costs spills in the 64-VGPR budget.
-            // The footprint must stay <= 38 912 B (four workgroups per CU).
-            if (g_fast_const_caps && blk == 512 && !hasb && g_store_policy == 16 && h.max_nodes > 512 && h.max_owned <= 560 &&
-                h.max_nodes * 32 + 560 * 32 + 128 <= 38912 && h.max_elems <= 3 * 512) {
-                HFEM_LAUNCH_FAST_CC(2, 3, 0, 560);
-                fast = true;
-            } else if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_FAST_HB(512, 1, 2)
-            else if (blk == 256 && h.max_nodes <= 2 * 256 && h.max_elems <= 4 * 256) HFEM_FAST_HB(256, 2, 4)
-            else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 3 * 512) HFEM_FAST_HB(512, 2, 3)
-            else if (blk == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) HFEM_FAST_HB(512, 2, 4)
-            else if (blk == 256 && h.max_nodes <= 4 * 256 && h.max_elems <= 6 * 256) HFEM_FAST_HB(256, 4, 6)
-            else if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_FAST_HB(1024, 1, 2)
-#undef HFEM_FAST_HB
-#undef HFEM_LAUNCH_FAST_CC
-#undef HFEM_LAUNCH_FAST
-#undef HFEM_LAUNCH_FAST_SP
+            HFEM_ARG_CHECK(!lag_consume, "HFEM_FLAG_SUM_PREVIOUS: this plan's tile shape has no register-prefetched instance");
+            switch (plan->tune.tiled_block) {
+                case 512: launch_generic<512>(A, n); break;
+                case 1024: launch_generic<1024>(A, n); break;
+                default: launch_generic<256>(A, n); break;
             }
-        }
-        if (fast) {
-        } else if (abl == 0) {
-            switch (g_tiled_block) {
-                case 512: HFEM_LAUNCH_TILED(512, 0); break;
-                case 1024: HFEM_LAUNCH_TILED(1024, 0); break;
-                default: HFEM_LAUNCH_TILED(256, 0); break;
-            }
-        } else {   // lab build: ablations at 256 and 512 threads
-            const bool b512 = g_tiled_block == 512;
-            switch (abl) {
-                case 1: if (b512) HFEM_LAUNCH_TILED(512, 1); else HFEM_LAUNCH_TILED(256, 1); break;
-                case 2: if (b512) HFEM_LAUNCH_TILED(512, 2); else HFEM_LAUNCH_TILED(256, 2); break;
-                case 4: if (b512) HFEM_LAUNCH_TILED(512, 4); else HFEM_LAUNCH_TILED(256, 4); break;
-                case 6: if (b512) HFEM_LAUNCH_TILED(512, 6); else HFEM_LAUNCH_TILED(256, 6); break;
-                case 8: if (b512) HFEM_LAUNCH_TILED(512, 8); else HFEM_LAUNCH_TILED(256, 8); break;
-                case 5: if (b512) HFEM_LAUNCH_TILED(512, 5); else HFEM_LAUNCH_TILED(256, 5); break;
-                case 13: if (b512) HFEM_LAUNCH_TILED(512, 13); else HFEM_LAUNCH_TILED(256, 13); break;
-                case 128: if (b512) HFEM_LAUNCH_TILED(512, 128); else HFEM_LAUNCH_TILED(256, 128); break;
-                case 384: if (b512) HFEM_LAUNCH_TILED(512, 384); else HFEM_LAUNCH_TILED(256, 384); break;
-                case 640: if (b512) HFEM_LAUNCH_TILED(512, 640); else HFEM_LAUNCH_TILED(256, 640); break;
-                case 129: if (b512) HFEM_LAUNCH_TILED(512, 129); else HFEM_LAUNCH_TILED(256, 129); break;
-                case 64: if (b512) HFEM_LAUNCH_TILED(512, 64); else HFEM_LAUNCH_TILED(256, 64); break;
-                case 10: if (b512) HFEM_LAUNCH_TILED(512, 10); else HFEM_LAUNCH_TILED(256, 10); break;
-                case 14: if (b512) HFEM_LAUNCH_TILED(512, 14); else HFEM_LAUNCH_TILED(256, 14); break;
-                case 32: if (b512) HFEM_LAUNCH_TILED(512, 32); else HFEM_LAUNCH_TILED(256, 32); break;
-                case 48: if (b512) HFEM_LAUNCH_TILED(512, 48); else HFEM_LAUNCH_TILED(256, 48); break;
-                case 16: if (b512) HFEM_LAUNCH_TILED(512, 16); else HFEM_LAUNCH_TILED(256, 16); break;
-                default: set_error("hfem_tri3_energy_plan: unsupported tiled_ablate value"); return -1;
-            }
-        }
-#undef HFEM_LAUNCH_TILED
         }
         if (int rc = launch_status("hfem_tri3_energy_plan")) return rc;
-        if (flags & HFEM_FLAG_NO_LOSS_SUM) {
-            plan->bank = wbank; plan->prev_begin = tile_begin; plan->prev_n = n_partials;
-            return 0;
-        }
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase + tile_begin,
-                           n_partials, loss_out);
-        return launch_status("hfem_tri3_energy_plan(sum)");
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) {
-        plan->bank = wbank; plan->prev_begin = tile_begin; plan->prev_n = 0;
+        plan->bank = wbank; plan->prev_begin = tile_begin; plan->prev_n = n > 0 ? n_partials : 0; plan->prev_stream = stream;
         return 0;
     }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase + tile_begin, n, loss_out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase + tile_begin, n_partials, loss_out);
     return launch_status("hfem_tri3_energy_plan(sum)");
 }
 
@@ -1113,6 +1126,8 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS)),
+                   "fp32-storage path: reference convention, atomic accumulation, no lagged loss sum");
     const HostPlan &h = plan->host;
     const int32_t nt = (int32_t)h.tiles.size();
     if (tile_end < 0) tile_end = nt;
@@ -1123,28 +1138,26 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(!hasb && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
                    "fp32-storage path: needs a zero body force and tiles of <= 1024 nodes / 2048 element slots");
     if (int rc = use_device(plan->device)) return rc;
+    PlanLock lock(plan);
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
+    double *pbase = plan->d_partials + (size_t)plan->bank * nt + tile_begin;
     if (n > 0) {
-        PlanDev pd = plan_dev(plan);
-        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
-#define HFEM_LAUNCH_F32(NPT, EPT)                                                                          \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, float2>), dim3(n), dim3(512),   \
-                       (size_t)plan->lds_bytes, s, pd, (int)tile_begin, (const float2 *)x_free,             \
-                       (const float2 *)x_fixed, (const float2 *)u_free, (const float2 *)u_fixed,            \
-                       make_consts(mat, W, Bk), (const double4 *)T_edge, tc,                                \
-                       plan->d_partials + (size_t)plan->bank * nt + tile_begin,                             \
-                       (flags & HFEM_FLAG_NO_GX) ? nullptr : (float2 *)gx_free,                             \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (float2 *)gu_free, h.max_nodes, h.max_owned,   \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, AdamFuse{}, LagSum{})
-        if (h.max_elems <= 3 * 512) HFEM_LAUNCH_F32(2, 3);
-        else HFEM_LAUNCH_F32(2, 4);
-#undef HFEM_LAUNCH_F32
+        Tri3Launch A;
+        A.pd = plan_dev(plan); A.tile_begin = (int)tile_begin;
+        A.x_free = x_free; A.x_fixed = x_fixed; A.u_free = u_free; A.u_fixed = u_fixed;
+        A.k = make_consts(mat, W, Bk); A.T_edge = (const double4 *)T_edge;
+        A.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+        A.partials = pbase;
+        A.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; A.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
+        A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
+        A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
+        if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, float2, 0, false, false>(A, n, AdamFuse{}, LagSum{});
+        else launch_fast<512, 2, 4, false, 16, float2, 0, false, false>(A, n, AdamFuse{}, LagSum{});
         if (int rc = launch_status("hfem_tri3_energy_plan_f32")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, plan->d_partials + (size_t)plan->bank * nt + tile_begin,
-                       n, loss_out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase, n, loss_out);
     return launch_status("hfem_tri3_energy_plan_f32(sum)");
 }
 
@@ -1173,12 +1186,16 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
     HFEM_ARG_CHECK(h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
                    "fused Adam step: needs tiles of <= 1024 nodes / 2048 element slots");
     HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_GX | HFEM_FLAG_NO_GU)), "fused Adam step updates both parameter tensors");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC)), "fused Adam step: reference convention, atomic accumulation");
     if (int rc = use_device(plan->device)) return rc;
+    PlanLock lock(plan);
     hipStream_t s = (hipStream_t)stream;
     const int n = (int)h.tiles.size(), nt = n;
     const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0;
     HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
     HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
+    HFEM_ARG_CHECK(!lag_consume || plan->prev_stream == stream,
+                   "HFEM_FLAG_SUM_PREVIOUS: the previous unsummed launch went to another stream (one plan = one stream)");
     const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
     double *pbase = plan->d_partials + (size_t)wbank * nt;
     LagSum lag;
@@ -1188,27 +1205,25 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
         lag.out = loss_out;
     }
     if (n > 0) {
-        PlanDev pd = plan_dev(plan);
-        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
         AdamFuse af;
         af.x_out = (double2 *)x_out; af.u_out = (double2 *)u_out;
         af.mx = (double2 *)m_x; af.vx = (double2 *)v_x; af.mu = (double2 *)m_u; af.vu = (double2 *)v_u;
         af.bc = bc_dev; af.lr_x = lr_x; af.lr_u = lr_u; af.b1 = beta1; af.b2 = beta2; af.eps = eps;
-#define HFEM_LAUNCH_ADAM(NPT, EPT)                                                                          \
-    hipLaunchKernelGGL((tri3_energy_fast_kernel<512, NPT, EPT, false, false, 16, double2, 0, 0, true>),            \
-                       dim3(n + (lag_consume ? 1 : 0)),                                                     \
-                       dim3(512), (size_t)plan->lds_bytes, s, pd, 0, (const double2 *)x_free,               \
-                       (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed,         \
-                       make_consts(mat, W, nullptr), (const double4 *)T_edge, tc, pbase,                    \
-                       (double2 *)nullptr, (double2 *)nullptr, h.max_nodes, h.max_owned,                    \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, 0, 0x108, plan->d_stamps, af, lag)
-        if (h.max_elems <= 3 * 512) HFEM_LAUNCH_ADAM(2, 3);
-        else HFEM_LAUNCH_ADAM(2, 4);
-#undef HFEM_LAUNCH_ADAM
+        Tri3Launch A;
+        A.pd = plan_dev(plan); A.tile_begin = 0;
+        A.x_free = x_free; A.x_fixed = x_fixed; A.u_free = u_free; A.u_fixed = u_fixed;
+        A.k = make_consts(mat, W, nullptr); A.T_edge = (const double4 *)T_edge;
+        A.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+        A.partials = pbase;
+        A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
+        A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
+        const int grid = n + (lag_consume ? 1 : 0);
+        if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, double2, 0, true, false>(A, grid, af, lag);
+        else launch_fast<512, 2, 4, false, 16, double2, 0, true, false>(A, grid, af, lag);
         if (int rc = launch_status("hfem_tri3_energy_adam_step")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) {
-        plan->bank = wbank; plan->prev_begin = 0; plan->prev_n = n;
+        plan->bank = wbank; plan->prev_begin = 0; plan->prev_n = n; plan->prev_stream = stream;
         return 0;
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase, n, loss_out);
@@ -1226,39 +1241,51 @@ extern "C" int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t t
     if (tile_end < 0) tile_end = nt;
     HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
     if (int rc = use_device(plan->device)) return rc;
+    PlanLock lock(plan);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
                        plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, loss_out);
     return launch_status("hfem_plan_loss_sum");
 }
 
+// Options.  Product: tiled_block (256 / 512 / 1024 threads per tile), store_policy (0 plain, 16 sc1 write-through),
+// tiled_fast, fast_const_caps, quad4_const_caps, plan_elem_order (0..4), plan_node_cap, plan_chunk_cap, plan_curve
+// (0 Morton, 1 Hilbert): DEFAULTS that the next hfem_plan_create captures (a plan keeps what it was created with).
+// Everything else (ablations, stamps, staggers, pipelined / streamed kernels) exists in the lab build only.
 extern "C" int hfem_set_option(const char *name, int value) {
     HFEM_ARG_CHECK(name, "null option name");
     const std::string n(name);
     if (n == "tiled_block") {
         HFEM_ARG_CHECK(value == 256 || value == 512 || value == 1024, "tiled_block must be 256, 512 or 1024");
-        g_tiled_block = value;
-    } else if (n == "tiled_ablate") {
-        g_tiled_ablate = value;
-    } else if (n == "quad4_stagger") {
-        HFEM_ARG_CHECK(value >= -1 && value <= 100000, "quad4_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
-        g_quad4_stagger = value;
-    } else if (n == "quad4_stagger_groups") {
-        HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "quad4_stagger_groups: 2, 4 or 8");
-        g_quad4_stagger_groups = value;
-    } else if (n == "quad4_stagger_shift") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 20, "quad4_stagger_shift: bit of the workgroup index, 0..20");
-        g_quad4_stagger_shift = value;
+        g_def.tiled_block = value;
+    } else if (n == "store_policy") {
+        HFEM_ARG_CHECK(value == 0 || value == 16, "store_policy: 0 (plain) or 16 (sc1 write-through)");
+        g_def.store_policy = value;
+    } else if (n == "tiled_fast") {
+        g_def.tiled_fast = value ? 1 : 0;
+    } else if (n == "fast_const_caps") {
+        g_def.fast_const_caps = value ? 1 : 0;
     } else if (n == "quad4_const_caps") {
         g_quad4_const_caps = value ? 1 : 0;
-    } else if (n == "quad4_pipe") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 8, "quad4_pipe: 0 (one workgroup per tile) or 1..8 persistent workgroups per CU");
-        g_quad4_pipe = value;
-    } else if (n == "quad4_ablate") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 4, "quad4_ablate: lab variants 0..4");
-        g_quad4_ablate = value;
+    } else if (n == "plan_elem_order") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 4, "plan_elem_order must be 0..4");
+        g_def.plan_elem_order = value;
+    } else if (n == "plan_node_cap") {
+        HFEM_ARG_CHECK(value >= -1 && value <= 1024, "plan_node_cap must be -1 (auto), 0 (off) or 1..1024");
+        g_def.plan_node_cap = value;
+    } else if (n == "plan_chunk_cap") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 4096, "plan_chunk_cap: 0 (no limit) .. 4096 slots");
+        g_def.plan_chunk_cap = value;
+    } else if (n == "plan_curve") {
+        HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");
+        set_plan_curve(value);
+#ifdef HFEM_LAB
+    } else if (n == "tiled_ablate") {
+        g_tiled_ablate = value;
     } else if (n == "tiled_stagger") {
         HFEM_ARG_CHECK(value >= 0 && value <= 100000, "tiled_stagger is in 10 ns ticks, 0..100000");
         g_tiled_stagger = value;
+    } else if (n == "tiled_stagger_mode") {
+        g_tiled_stagger_mode = value;
     } else if (n == "fast_stagger") {
         HFEM_ARG_CHECK(value >= -1 && value <= 100000, "fast_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
         g_fast_stagger = value;
@@ -1268,36 +1295,31 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "fast_stagger_groups") {
         HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "fast_stagger_groups: 2, 4 or 8");
         g_fast_stagger_groups = value;
-    } else if (n == "tiled_stagger_mode") {
-        g_tiled_stagger_mode = value;
-    } else if (n == "plan_node_cap") {
-        HFEM_ARG_CHECK(value >= -1 && value <= 1024, "plan_node_cap must be -1 (auto), 0 (off) or 1..1024");
-        g_plan_node_cap = value;
-    } else if (n == "plan_curve") {
-        HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");
-        set_plan_curve(value);
-    } else if (n == "store_policy") {
-        HFEM_ARG_CHECK(value == 0 || value == 16, "store_policy: 0 (plain) or 16 (sc1 write-through)");
-        g_store_policy = value;
-    } else if (n == "fast_const_caps") {
-        g_fast_const_caps = value ? 1 : 0;
-    } else if (n == "plan_chunk_cap") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 4096, "plan_chunk_cap: 0 (no limit) .. 4096 slots");
-        g_plan_chunk_cap = value;
-    } else if (n == "stream_ablate") {
-        g_stream_ablate = value;
-    } else if (n == "tri3_stream") {
-        g_tri3_stream = value ? 1 : 0;
-    } else if (n == "tiled_fast") {
-        g_tiled_fast = value ? 1 : 0;
     } else if (n == "tiled_pipe") {
         HFEM_ARG_CHECK(value >= 0 && value <= 8, "tiled_pipe must be 0..8 workgroups per CU");
         g_tiled_pipe = value;
-    } else if (n == "plan_elem_order") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 4, "plan_elem_order must be 0..4");
-        g_plan_elem_order = value;
+    } else if (n == "tri3_stream") {
+        g_tri3_stream = value ? 1 : 0;
+    } else if (n == "stream_ablate") {
+        g_stream_ablate = value;
+    } else if (n == "quad4_stagger") {
+        HFEM_ARG_CHECK(value >= -1 && value <= 100000, "quad4_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
+        g_quad4_stagger = value;
+    } else if (n == "quad4_stagger_groups") {
+        HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "quad4_stagger_groups: 2, 4 or 8");
+        g_quad4_stagger_groups = value;
+    } else if (n == "quad4_stagger_shift") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 20, "quad4_stagger_shift: bit of the workgroup index, 0..20");
+        g_quad4_stagger_shift = value;
+    } else if (n == "quad4_pipe") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 8, "quad4_pipe: 0 (one workgroup per tile) or 1..8 persistent workgroups per CU");
+        g_quad4_pipe = value;
+    } else if (n == "quad4_ablate") {
+        HFEM_ARG_CHECK(value >= 0 && value <= 4, "quad4_ablate: lab variants 0..4");
+        g_quad4_ablate = value;
+#endif
     } else {
-        set_error("hfem_set_option: unknown option '" + n + "'");
+        set_error("hfem_set_option: unknown option '" + n + "' (lab knobs need libhidenn_hip_lab.so)");
         return -1;
     }
     return 0;
@@ -1306,22 +1328,32 @@ extern "C" int hfem_set_option(const char *name, int value) {
 extern "C" int hfem_get_option(const char *name) {
     if (!name) return -1;
     const std::string n(name);
-    if (n == "tiled_block") return g_tiled_block;
+    if (n == "tiled_block") return g_def.tiled_block.load();
+    if (n == "store_policy") return g_def.store_policy.load();
+    if (n == "tiled_fast") return g_def.tiled_fast.load();
+    if (n == "fast_const_caps") return g_def.fast_const_caps.load();
+    if (n == "quad4_const_caps") return g_quad4_const_caps;
+    if (n == "plan_elem_order") return g_def.plan_elem_order.load();
+    if (n == "plan_node_cap") return g_def.plan_node_cap.load();
+    if (n == "plan_chunk_cap") return g_def.plan_chunk_cap.load();
+    if (n == "lab_build") {
+#ifdef HFEM_LAB
+        return 1;
+#else
+        return 0;
+#endif
+    }
+#ifdef HFEM_LAB
     if (n == "tiled_ablate") return g_tiled_ablate;
-    if (n == "quad4_ablate") return g_quad4_ablate;
-    if (n == "plan_elem_order") return g_plan_elem_order;
+    if (n == "tiled_stagger") return g_tiled_stagger;
+    if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
+    if (n == "fast_stagger") return g_fast_stagger;
     if (n == "tiled_pipe") return g_tiled_pipe;
-    if (n == "tiled_fast") return g_tiled_fast;
     if (n == "tri3_stream") return g_tri3_stream;
     if (n == "stream_ablate") return g_stream_ablate;
-    if (n == "plan_chunk_cap") return g_plan_chunk_cap;
-    if (n == "fast_const_caps") return g_fast_const_caps;
-    if (n == "store_policy") return g_store_policy;
-    if (n == "plan_node_cap") return g_plan_node_cap;
-    if (n == "tiled_stagger") return g_tiled_stagger;
-    if (n == "fast_stagger") return g_fast_stagger;
     if (n == "quad4_stagger") return g_quad4_stagger;
     if (n == "quad4_pipe") return g_quad4_pipe;
-    if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
+    if (n == "quad4_ablate") return g_quad4_ablate;
+#endif
     return -1;
 }

@@ -14,6 +14,9 @@
 //     the earlier strips;
 //   * gradients accumulate in LDS (ds_add_f64) and every owned row leaves with one write-through 16-B store.
 // HBM-bound, no MFMA (2x2 / 2x3 contractions).  Algorithmic bytes per launch: 12 Ne + 64 Nn + 8.
+// LAB BUILD ONLY (-DHFEM_LAB, libhidenn_hip_lab.so): measured slower than the register-prefetched kernel (round 2:
+// 11.9 vs 11.1 us on T1M) -- kept as the evidence behind that section, not shipped.
+#ifdef HFEM_LAB
 #include <hip/hip_runtime.h>
 
 #include "hfem_device.h"
@@ -303,3 +306,4 @@ int launch_tri3_stream(const hfem_plan *plan, int n_grid, int tile_begin, const 
 }
 
 }  // namespace hfem
+#endif  // HFEM_LAB

@@ -65,10 +65,17 @@ class TilePlan:
         def p(a):
             return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
 
-        if elem_order is not None:
-            _lib.check(_lib.lib().hfem_set_option(b"plan_elem_order", int(elem_order)), "hfem_set_option")
-        rc = _lib.lib().hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
-                                            p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
+        L = _lib.lib()
+        prev_order = None
+        if elem_order is not None:            # a creation-time default of the library: set, create, restore
+            prev_order = L.hfem_get_option(b"plan_elem_order")
+            _lib.check(L.hfem_set_option(b"plan_elem_order", int(elem_order)), "hfem_set_option")
+        try:
+            rc = L.hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
+                                       p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
+        finally:
+            if prev_order is not None and prev_order >= 0:
+                L.hfem_set_option(b"plan_elem_order", prev_order)
         _lib.check(rc, "hfem_plan_create")
         st = _lib.PlanStats()
         _lib.check(_lib.lib().hfem_plan_get_stats(self._h, C.byref(st)), "hfem_plan_get_stats")

@@ -4,6 +4,7 @@ tile sizes / threads per tile / ablation bits.  Usage on the GPU box:
 
     python scripts/kernel_lab.py --tiles 512,768,1024 --blocks 256,512 --ablate 0,1,2,4,8
 """
+import os; os.environ.setdefault("HFEM_LAB", "1")   # kernel-lab tool: needs libhidenn_hip_lab.so (build.py --lab)
 import argparse
 import ctypes as C
 import json

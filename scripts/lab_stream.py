@@ -11,6 +11,7 @@ variants (plan element order x library options), in three cache regimes:
 
 Every variant is checked against the first one (loss / gradients) before it is timed.
 """
+import os; os.environ.setdefault("HFEM_LAB", "1")   # kernel-lab tool: needs libhidenn_hip_lab.so (build.py --lab)
 import argparse
 import ctypes as C
 import json

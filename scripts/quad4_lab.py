@@ -4,6 +4,7 @@
 
     python scripts/quad4_lab.py --tiles 0,512,768
 """
+import os; os.environ.setdefault("HFEM_LAB", "1")   # kernel-lab tool: needs libhidenn_hip_lab.so (build.py --lab)
 import argparse
 import ctypes as C
 import json

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Lab: per-workgroup phase timeline of the tiled kernel (s_memrealtime stamps, 10 ns ticks)."""
+import os; os.environ.setdefault("HFEM_LAB", "1")   # kernel-lab tool: needs libhidenn_hip_lab.so (build.py --lab)
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -38,7 +39,7 @@ for _ in range(5):
     _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr(), uf.data_ptr(), ufix.data_ptr(), dv(lf._mat), lf._W,
                dv([0.0]*6), None, dv(Tconst), 0, -1, loss.data_ptr(), gx.data_ptr(), gu.data_ptr(), 8, torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
-st = plan.export("stamps").astype(np.int64)
+st = plan.export("stamps").astype(np.int64)[:, :8]
 t0 = st[:, 0].min()
 rel = (st - t0) * 0.01          # us
 names = ["start", "desc", "gathered", "bar1", "elems", "bar2", "stored", "end"]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Lab: per-workgroup timeline of the streamed TRI3 kernel (s_memrealtime stamps, 10 ns ticks).
    python scripts/stamps_stream.py --ablate 256   (256 = stamps only; 263 = + no math / gather / stores ...)"""
+import os; os.environ.setdefault("HFEM_LAB", "1")   # kernel-lab tool: needs libhidenn_hip_lab.so (build.py --lab)
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -65,3 +65,24 @@ def test_models_construct_on_cpu_but_compute_raises():
             l1(torch.rand(4))
         with pytest.raises(RuntimeError):
             EnergyLoss2D(device=torch.device("cpu"))(m)
+
+
+def test_product_library_carries_no_lab_code():
+    """The kernel-lab instrumentation (ablations, stamps, staggers, pipelined / streamed variants) lives in the second
+    build target (libhidenn_hip_lab.so, -DHFEM_LAB); the product library rejects its knobs and exports no such kernel."""
+    import subprocess
+    L = _lib.lib()
+    assert L.hfem_get_option(b"lab_build") == 0
+    for knob in (b"tiled_ablate", b"tiled_stagger", b"fast_stagger", b"tiled_pipe", b"tri3_stream", b"stream_ablate",
+                 b"quad4_ablate", b"quad4_pipe", b"quad4_stagger"):
+        assert L.hfem_set_option(knob, 1) != 0, knob
+        assert L.hfem_get_option(knob) == -1
+    assert b"lab knobs need libhidenn_hip_lab.so" in L.hfem_last_error()
+    # product knobs: defaults that the NEXT plan captures; round-trip and restore
+    for knob, val in ((b"tiled_block", 256), (b"store_policy", 0), (b"plan_elem_order", 4)):
+        old = L.hfem_get_option(knob)
+        assert L.hfem_set_option(knob, val) == 0 and L.hfem_get_option(knob) == val
+        assert L.hfem_set_option(knob, old) == 0
+    syms = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "tri3_energy_fast_kernel" in syms
+    assert "pipe_kernel" not in syms and "stream_kernel" not in syms

@@ -223,3 +223,60 @@ def test_shard_ranges_cover_all_tiles():
         r = [plan.shard_range(k, world) for k in range(world)]
         assert r[0][0] == 0 and r[-1][1] == plan.n_tiles
         assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+
+
+def test_planner_under_address_and_ub_sanitizers(tmp_path):
+    """the CPU side of the C ABI (the tile planner, csrc/plan.cpp -- no HIP call in it) built with
+    -fsanitize=address,undefined and run on structured, permuted, flipped, unstructured (Delaunay), QUAD4 and degenerate
+    meshes in every element order, incl. the chunked order and the 1024-local-node retry.  CPU only, never on the GPU box."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    from hidenn_fem_amd.mesh import structured_quad_mesh, unstructured_tri_mesh
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "plan_san")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           os.path.join(here, "host", "plan_san_main.cpp"),
+           os.path.join(here, "..", "hidenn_fem_amd", "csrc", "plan.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr
+
+    def write(name, conn, xy, edges, npe=3, tile_elems=0, node_cap=0, order=3, chunk_cap=512, maps=None):
+        conn = np.ascontiguousarray(conn, dtype=np.int64).reshape(-1, npe)
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        edges = np.ascontiguousarray(edges, dtype=np.int64).reshape(-1, 2)
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(struct.pack("<9q", conn.shape[0], xy.shape[0], edges.shape[0], npe, tile_elems, node_cap, order,
+                                chunk_cap, 0 if maps is None else 1))
+            f.write(conn.tobytes()); f.write(xy.tobytes()); f.write(edges.tobytes())
+            if maps is not None:
+                f.write(np.ascontiguousarray(maps[0], dtype=np.int32).tobytes())
+                f.write(np.ascontiguousarray(maps[1], dtype=np.int32).tobytes())
+        return path
+
+    files = []
+    c, cn, geom, bc, mn, ed = structured_tri_mesh(81, 61, jitter=0.3, seed=2, diagonal="random", permute=True,
+                                                  flip_fraction=0.3, dtype=torch.float64)
+    maps = (row_maps((~geom).numpy()), row_maps((~bc).numpy()))
+    for order in (0, 1, 2, 3, 4):
+        files.append(write(f"perm_o{order}.bin", cn.numpy(), c.numpy(), ed.numpy(), tile_elems=700, order=order, maps=maps))
+    files.append(write("auto_cap.bin", cn.numpy(), c.numpy(), ed.numpy(), tile_elems=1200, node_cap=557, order=4, maps=maps))
+    cu, cnu, _, _, _, edu = unstructured_tri_mesh(6000, seed=4, dtype=torch.float64)
+    files.append(write("delaunay_retry.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=4096, order=3))
+    files.append(write("delaunay_chunked.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=900, order=4))
+    cq, cnq, _, _, _, edq = structured_quad_mesh(41, 37, jitter=0.2, seed=1, dtype=torch.float64)
+    files.append(write("quad4.bin", cnq.numpy(), cq.numpy(), edq.numpy(), npe=4, tile_elems=500))
+    files.append(write("one_element.bin", [[0, 1, 2]], [[0, 0], [1, 0], [0, 1]], np.zeros((0, 2))))
+    files.append(write("orphans.bin", [[0, 1, 2]], np.random.default_rng(0).random((700, 2)), [[3, 4]]))   # nodes without elements
+    files.append(write("empty.bin", np.zeros((0, 3)), np.zeros((5, 2)), np.zeros((0, 2))))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count(": ok ") == len(files), r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr

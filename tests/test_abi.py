@@ -71,6 +71,7 @@ def test_product_library_carries_no_lab_code():
     """The kernel-lab instrumentation (ablations, stamps, staggers, pipelined / streamed variants) lives in the second
     build target (libhidenn_hip_lab.so, -DHFEM_LAB); the product library rejects its knobs and exports no such kernel."""
     import subprocess
+    from hidenn_fem_amd import _lib
     L = _lib.lib()
     assert L.hfem_get_option(b"lab_build") == 0
     for knob in (b"tiled_ablate", b"tiled_stagger", b"fast_stagger", b"tiled_pipe", b"tri3_stream", b"stream_ablate",

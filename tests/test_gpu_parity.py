@@ -405,9 +405,10 @@ def test_examples_run_against_the_drop_in_api(g_lbfgs):
 
 
 def test_kernel_variants_agree(g_tri):
-    """Every launch variant of the tiled energy (register-prefetched 'fast' kernel with sc1 or plain stores,
-    generic loop kernel at 256/512/1024 threads, experimental persistent pipelined kernel) gives the same
-    numbers on a mid-size mesh with free boundary nodes, a body force and Neumann edges."""
+    """Every product launch variant of the tiled energy (register-prefetched 'fast' kernel with sc1 or plain stores,
+    compile-time or runtime strides, generic loop kernel at 256/1024 threads) gives the same numbers on a mid-size
+    mesh with free boundary nodes, a body force and Neumann edges.  Options are defaults captured by the NEXT plan:
+    every variant builds its own model (hence its own plan)."""
     from hidenn_fem_amd import _lib
     from hidenn_fem_amd.mesh import structured_tri_mesh
     from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
@@ -418,12 +419,12 @@ def test_kernel_variants_agree(g_tri):
     coords, conn, geom, bc, mn, edges = structured_tri_mesh(181, 95, jitter=0.25, seed=9, dtype=F64)
     results = {}
     settings = {
-        "fast_sc1": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0, fast_const_caps=1),
-        "fast_runtime_strides": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0, fast_const_caps=0),
-        "fast_plain": dict(tiled_fast=1, store_policy=0, tiled_block=512, tiled_pipe=0),
-        "loop_256": dict(tiled_fast=0, store_policy=16, tiled_block=256, tiled_pipe=0),
-        "loop_1024": dict(tiled_fast=0, store_policy=16, tiled_block=1024, tiled_pipe=0),
-        "pipe_512x2": dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=2),
+        "fast_sc1": dict(tiled_fast=1, store_policy=16, tiled_block=512, fast_const_caps=1),
+        "fast_runtime_strides": dict(tiled_fast=1, store_policy=16, tiled_block=512, fast_const_caps=0),
+        "fast_plain": dict(tiled_fast=1, store_policy=0, tiled_block=512),
+        "fast_256": dict(tiled_fast=1, store_policy=16, tiled_block=256),
+        "loop_256": dict(tiled_fast=0, store_policy=16, tiled_block=256),
+        "loop_1024": dict(tiled_fast=0, store_policy=16, tiled_block=1024),
     }
     try:
         for body in (None, b_force_fn):
@@ -447,7 +448,7 @@ def test_kernel_variants_agree(g_tri):
                 assert np.abs(got[1] - ref[1]).max() <= 1e-12 * np.abs(ref[1]).max(), name
                 assert np.abs(got[2] - ref[2]).max() <= 1e-12 * np.abs(ref[2]).max(), name
     finally:
-        for k, v in dict(tiled_fast=1, store_policy=16, tiled_block=512, tiled_pipe=0, fast_const_caps=1).items():
+        for k, v in dict(tiled_fast=1, store_policy=16, tiled_block=512, fast_const_caps=1).items():
             L.hfem_set_option(k.encode(), v)
 
 

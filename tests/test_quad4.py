@@ -65,18 +65,6 @@ def test_quad4_kernels_match_the_autograd_oracle():
     assert abs(loss_a.item() - ref.item()) <= 1e-12 * abs(ref.item())
     assert np.abs(m.node_coords_free.grad.cpu().numpy() - gx).max() <= 1e-10 * np.abs(gx).max()
     assert np.abs(m.u_free.grad.cpu().numpy() - gu).max() <= 1e-10 * np.abs(gu).max()
-    # the experimental persistent pipelined variant (lab option "quad4_pipe") computes the same numbers
-    from hidenn_fem_amd import _lib
-    m.zero_grad()
-    _lib.check(_lib.lib().hfem_set_option(b"quad4_pipe", 2))
-    try:
-        loss_p = lf(m)
-        loss_p.backward()
-    finally:
-        _lib.check(_lib.lib().hfem_set_option(b"quad4_pipe", 0))
-    assert abs(loss_p.item() - ref.item()) <= 1e-12 * abs(ref.item())
-    assert np.abs(m.node_coords_free.grad.cpu().numpy() - gx).max() <= 1e-10 * np.abs(gx).max()
-    assert np.abs(m.u_free.grad.cpu().numpy() - gu).max() <= 1e-10 * np.abs(gu).max()
     # autograd-free form: gradients straight into .grad
     with torch.no_grad():
         for p_ in m.parameters():

@@ -73,6 +73,13 @@ PROTOTYPES = {
     "hfem_plan_loss_sum": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "hfem_iface_pack": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "hfem_iface_unpack": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    "hfem_mg_load": (C.c_int, [C.c_char_p]),
+    "hfem_mg_unique_id": (C.c_int, [_vp]),
+    "hfem_mg_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "hfem_mg_comm_destroy": (C.c_int, [_vp]),
+    "hfem_mg_allreduce_sum": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "hfem_mg_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "hfem_adam_step_rows_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _vp, _vp]),
     "hfem_quad4_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hfem_quad4_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -53,6 +53,28 @@ __global__ __launch_bounds__(256) void adam_step_dev_kernel(T *__restrict__ p, c
     }
 }
 
+// the same update on the [.][2] fp64 rows listed in rows[] only (owner-sharded multi-GPU mode: a rank updates exactly the
+// parameter rows its tiles own); one thread per row
+__global__ __launch_bounds__(256) void adam_step_rows_dev_kernel(double2 *__restrict__ p, const double2 *__restrict__ g,
+                                                                 double2 *__restrict__ m, double2 *__restrict__ v,
+                                                                 const int32_t *__restrict__ rows, int64_t n_rows,
+                                                                 double b1, double b2, double lr, double eps,
+                                                                 const int64_t *__restrict__ step_dev) {
+    const double step = (double)step_dev[0];
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const double step_size = lr / bc1, sqrt_bc2 = sqrt(bc2), w1 = 1.0 - b1, w2 = 1.0 - b2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const int32_t r = rows[i];
+    const double2 gi = g[r], m0 = m[r], v0 = v[r], p0 = p[r];
+    double2 mi, vi, pi;
+    mi.x = m0.x + w1 * (gi.x - m0.x); mi.y = m0.y + w1 * (gi.y - m0.y);
+    vi.x = v0.x * b2 + w2 * (gi.x * gi.x); vi.y = v0.y * b2 + w2 * (gi.y * gi.y);
+    pi.x = p0.x - step_size * (mi.x / (sqrt(vi.x) / sqrt_bc2 + eps));
+    pi.y = p0.y - step_size * (mi.y / (sqrt(vi.y) / sqrt_bc2 + eps));
+    m[r] = mi; v[r] = vi; p[r] = pi;
+}
+
 __global__ void counter_add_kernel(int64_t *c, int64_t inc) { c[0] += inc; }
 
 // step += 1; bc = {1 - b1^step, sqrt(1 - b2^step)}: the scalars of one Adam step, for kernels that fuse the update
@@ -108,6 +130,19 @@ extern "C" int hfem_adam_step_dev(int device, void *p, const void *g, void *m, v
         hipLaunchKernelGGL(adam_step_dev_kernel<float>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float *)p,
                            (const float *)g, (float *)m, (float *)v, n, beta1, beta2, lr, eps, step_dev);
     return launch_status("hfem_adam_step_dev");
+}
+
+extern "C" int hfem_adam_step_rows_dev(int device, double *p, const double *g, double *m, double *v, const int32_t *rows,
+                                       int64_t n_rows, double lr, double beta1, double beta2, double eps,
+                                       const int64_t *step_dev, void *stream) {
+    HFEM_ARG_CHECK(n_rows >= 0, "negative row count");
+    if (n_rows == 0) return 0;
+    HFEM_ARG_CHECK(p && g && m && v && rows && step_dev, "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(adam_step_rows_dev_kernel, dim3((int)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (double2 *)p, (const double2 *)g, (double2 *)m, (double2 *)v, rows, n_rows, beta1, beta2, lr, eps,
+                       step_dev);
+    return launch_status("hfem_adam_step_rows_dev");
 }
 
 extern "C" int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream) {

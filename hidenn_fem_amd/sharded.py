@@ -5,17 +5,19 @@ hot path needs.  The energy is a plain sum over elements (``/root/reference/src/
 and the gradients are sums of per-element contributions, so:
 
 * every rank holds the full (replicated) parameters and the same tile plan;
-* rank ``r`` evaluates the contiguous tile range ``plan.shard_range(r, world)`` -- tiles are
-  Morton-ordered, so a range is a spatially compact strip -- and thereby produces the
+* rank ``r`` evaluates the contiguous tile range ``plan.shard_range(r, world)`` -- tiles follow a
+  Hilbert curve, so a range is a spatially compact patch -- and thereby produces the
   complete gradient rows of the nodes those tiles own, plus a partial scalar energy;
-* ONE collective per evaluation: a sum all-reduce (RCCL over xGMI under the ``nccl``
-  backend) of the packed buffer ``[gx_free | gu_free | loss]``, after which every rank
-  holds the identical full gradient and can take the identical optimiser step.
+* ONE collective per evaluation, in one of two modes.
 
-Rows a rank does not own stay zero in its send buffer (the kernel never writes them),
-so the reduction is exact: each row has exactly one non-zero contributor.
+Dense mode (``exchange``; the north-star's literal wording): a sum all-reduce (RCCL over xGMI) of the packed
+buffer ``[gx_free | gu_free | loss]``, after which every rank holds the identical full gradient and can take the
+identical optimiser step.  Rows a rank does not own stay zero in its send buffer (the kernel never writes them),
+so the reduction is exact: each row has exactly one non-zero contributor.  16 B x 2 x nodes on the wire per rank
+and step: bandwidth-bound by construction; ``bench.py`` reports it as ``config.alt_exchange``.
 
-Owner-sharded mode (``exchange_halo``).  Because tiles are owner-computes with halo
+Owner-sharded mode (``exchange_halo`` / ``owner_step`` / ``owner_train_step``; the mode ``bench.py
+--gpus N`` times as its headline).  Because tiles are owner-computes with halo
 recompute, the gradient rows a rank produces for the nodes its tiles own are already complete:
 gradients never need to cross ranks.  A node-sharded optimiser updates exactly those rows; what the
 next evaluation then needs from the other ranks is the *parameter* rows of their interface nodes
@@ -37,6 +39,53 @@ from . import _lib
 F64 = torch.float64
 
 
+class LibraryComm:
+    """One in-library RCCL communicator per rank (``hfem_mg_*``, ``csrc/mg.cpp``): its collectives are plain
+    enqueues on the caller's stream, so -- unlike ``torch.distributed`` calls -- a whole multi-GPU step can be
+    captured into one hipGraph and costs no Python per replay.  The 128-byte unique id is created on rank 0 and
+    broadcast over the already-initialised ``torch.distributed`` group (any backend); ``world == 1`` needs none."""
+
+    def __init__(self, device: torch.device, group=None):
+        L = _lib.lib()
+        self.device = device
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        import os
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")      # share torch's RCCL instance
+        _lib.check(L.hfem_mg_load(bundled.encode() if os.path.exists(bundled) else None), "hfem_mg_load")
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(L.hfem_mg_unique_id(uid), "hfem_mg_unique_id")
+        if self.world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(box[0])
+        self._h = C.c_void_p()
+        _lib.check(L.hfem_mg_comm_create(_lib.dev_index(device), self.rank, self.world, uid, C.byref(self._h)),
+                   "hfem_mg_comm_create")
+
+    def all_reduce_sum(self, send: torch.Tensor, recv: torch.Tensor):
+        _lib.check(_lib.lib().hfem_mg_allreduce_sum(self._h, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                                    _lib.stream_ptr(self.device)), "hfem_mg_allreduce_sum")
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor):
+        _lib.check(_lib.lib().hfem_mg_allgather(self._h, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                                _lib.stream_ptr(self.device)), "hfem_mg_allgather")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                _lib.lib().hfem_mg_comm_destroy(self._h)
+            finally:
+                self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedTri3Energy:
     """``loss = sharded(model); loss.backward()`` with elements sharded over the ranks of
     ``group``.  ``evaluate`` is the per-rank evaluator ``(lo, hi, loss_view, gx_view, gu_view)``;
@@ -45,8 +94,10 @@ class ShardedTri3Energy:
     for the kernel."""
 
     def __init__(self, model, loss_fn, group=None, evaluate: Optional[Callable] = None, plan=None,
-                 rank: Optional[int] = None, world: Optional[int] = None):
-        self.model, self.loss_fn, self.group = model, loss_fn, group
+                 rank: Optional[int] = None, world: Optional[int] = None, comm: Optional["LibraryComm"] = None):
+        """``comm``: a ``LibraryComm`` -> the collectives are in-library RCCL calls on the current stream
+        (hipGraph-capturable); ``None`` -> ``torch.distributed`` on ``group`` (any backend; what the CPU tests use)."""
+        self.model, self.loss_fn, self.group, self.comm = model, loss_fn, group, comm
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is not None and world is not None:      # planning / single-process tests: act as rank of world
@@ -74,11 +125,12 @@ class ShardedTri3Energy:
                 raise RuntimeError("sharded evaluation needs an fp64 model (model.double())")
             _, Tconst = lf._traction(m, None)
             dv = lambda a: (C.c_double * len(a))(*a)
-            xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()  # cached by the model: no per-step allocation
-            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst),
-                                xfix.data_ptr() if xfix.numel() else None, ufix.data_ptr() if ufix.numel() else None,
-                                (xfix, ufix), _lib.lib().hfem_tri3_energy_plan)
-        mat, W, Bk, Tc, pxfix, pufix, _, fn = c
+            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst), _lib.lib().hfem_tri3_energy_plan)
+        mat, W, Bk, Tc, fn = c
+        # fixed rows are looked up on every call (the model caches them and tracks u_fixed._version / device): an
+        # in-place edit of u_fixed or model.to(device) is never served from a stale pointer
+        xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()
+        pxfix, pufix = (xfix.data_ptr() if xfix.numel() else None), (ufix.data_ptr() if ufix.numel() else None)
         rc = fn(self.plan.handle, m.node_coords_free.data_ptr(), pxfix, m.u_free.data_ptr(), pufix, mat, W, Bk, None,
                 Tc, int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), int(flags), _lib.stream_ptr(dev))
         _lib.check(rc, "hfem_tri3_energy_plan")
@@ -112,6 +164,9 @@ class ShardedTri3Energy:
 
     def exchange(self):
         """The single collective: recv = sum over ranks of send."""
+        if self.comm is not None:                      # in-library RCCL, out of place: no staging copy
+            self.comm.all_reduce_sum(self.send, self.recv)
+            return self._views(self.recv)
         self.recv.copy_(self.send)
         if self.world > 1:
             dist.all_reduce(self.recv, op=dist.ReduceOp.SUM, group=self.group)
@@ -216,12 +271,17 @@ class ShardedTri3Energy:
         parameters).  Returns (global loss, local gx view, local gu view)."""
         _, gx_v, gu_v = self._views(self.send)
         self._pack()
-        if self.world > 1:
+        self._gather_payloads()
+        self._unpack()
+        return self.loss_global, gx_v, gu_v
+
+    def _gather_payloads(self):
+        if self.comm is not None:
+            self.comm.all_gather(self.payload, self.gathered)
+        elif self.world > 1:
             dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
         else:
             self.gathered.copy_(self.payload)
-        self._unpack()
-        return self.loss_global, gx_v, gu_v
 
     def owner_step(self):
         """evaluate_owner() + exchange_halo() with every Python-side lookup hoisted (views, parameter objects, ctypes
@@ -231,7 +291,9 @@ class ShardedTri3Energy:
             _, gx_v, gu_v = self._views(self.send)
             m, L = self.model, _lib.lib()
             self._evaluate_hip(self.lo, self.hi, self.payload[self.iface_rows, 0:1], gx_v, gu_v)   # fills self._consts
-            mat, W, Bk, Tc, pxfix, pufix, _, fn = self._consts
+            mat, W, Bk, Tc, fn = self._consts
+            xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()      # hoisted: owner_step assumes they do not change
+            pxfix, pufix = (xfix.data_ptr() if xfix.numel() else None), (ufix.data_ptr() if ufix.numel() else None)
             dev = self.send.device
             c = self._step_cache = dict(
                 xf=m.node_coords_free, uf=m.u_free, dev=dev, di=_lib.dev_index(dev), fn=fn, pack=L.hfem_iface_pack,
@@ -249,15 +311,48 @@ class ShardedTri3Energy:
         rc = c["pack"](c["di"], px, pu, c["rows"], c["pub"][0], c["pub"][1], c["payload"], sp)
         if rc:
             _lib.check(rc, "hfem_iface_pack")
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
-        else:
-            self.gathered.copy_(self.payload)
+        self._gather_payloads()
         rc = c["unpack"](c["di"], c["gathered"], c["src"], c["dst"], c["need"][0], c["need"][1], px, pu, self.world,
                          self.iface_stride, self.iface_rows, c["loss"], sp)
         if rc:
             _lib.check(rc, "hfem_iface_unpack")
         return self.loss_global, c["out"][0], c["out"][1]
+
+    # ------------------------------------------------------------------ a whole owner-sharded training iteration
+    def init_owner_adam(self, lr_x: float, lr_u: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        """State of ``owner_train_step``: Adam moments of the rows this rank OWNS (full-size arrays, only owned rows
+        are ever touched), the device step counter and the owned-row lists.  Call once, before any graph capture."""
+        dev = self.send.device
+        xr, ur = self.owned_rows()
+        m = self.model
+        self._adam = dict(rows_x=xr.to(torch.int32).contiguous(), rows_u=ur.to(torch.int32).contiguous(),
+                          mx=torch.zeros_like(m.node_coords_free.data), vx=torch.zeros_like(m.node_coords_free.data),
+                          mu=torch.zeros_like(m.u_free.data), vu=torch.zeros_like(m.u_free.data),
+                          step=torch.zeros(1, dtype=torch.int64, device=dev), lr=(float(lr_x), float(lr_u)),
+                          betas=(float(betas[0]), float(betas[1])), eps=float(eps))
+        return self
+
+    def owner_train_step(self):
+        """ONE training iteration of the owner-sharded mode, all stream-ordered launches (capturable when ``comm`` is
+        a ``LibraryComm``): energy + gradients of this rank's tiles -> Adam on the rows this rank owns
+        (``hfem_adam_step_rows_dev``) -> pack the updated interface rows + the partial energy -> ONE all_gather ->
+        copy in the interface rows this rank's tiles read, sum the partial energies in rank order.  Returns the
+        global energy at the parameters BEFORE the update (as ``loss = closure(); optimizer.step()`` reports it)."""
+        a, L, m = self._adam, _lib.lib(), self.model
+        dev = self.send.device
+        di, sp = _lib.dev_index(dev), _lib.stream_ptr(dev)
+        _, gx_v, gu_v = self._views(self.send)
+        self._evaluate_hip(self.lo, self.hi, self.payload[self.iface_rows, 0:1], gx_v, gu_v)
+        _lib.check(L.hfem_counter_add(di, a["step"].data_ptr(), 1, sp), "hfem_counter_add")
+        for p, g, mm, vv, rows, lr in ((m.node_coords_free, gx_v, a["mx"], a["vx"], a["rows_x"], a["lr"][0]),
+                                       (m.u_free, gu_v, a["mu"], a["vu"], a["rows_u"], a["lr"][1])):
+            _lib.check(L.hfem_adam_step_rows_dev(di, p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(),
+                                                 rows.data_ptr(), rows.numel(), lr, a["betas"][0], a["betas"][1],
+                                                 a["eps"], a["step"].data_ptr(), sp), "hfem_adam_step_rows_dev")
+        self._pack()
+        self._gather_payloads()
+        self._unpack()
+        return self.loss_global
 
     def owned_rows(self):
         """(x rows, u rows) of node_coords_free / u_free that this rank's tiles own (int64 tensors)."""

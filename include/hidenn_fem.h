@@ -298,6 +298,26 @@ int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const 
                       int32_t n_u, double *x_free, double *u_free, int32_t world, int64_t stride,
                       int64_t loss_slot, double *loss_out, void *stream);
 
+/* In-library collectives: one RCCL communicator per rank (one process per GPU).  Rank 0 calls
+ * hfem_mg_unique_id and broadcasts the 128 bytes by any side channel (torch.distributed, a file, MPI); every rank
+ * then calls hfem_mg_comm_create.  The collectives only ENQUEUE on the caller's stream -- in stream order right
+ * after the energy kernel -- so a whole multi-GPU step can be captured into one hipGraph.  fp64, sum.
+ * hfem_mg_allgather: recv = [rank 0's `count` doubles | rank 1's | ...].  send == recv + rank * count is allowed.
+ * RCCL is bound at run time (dlopen: the librccl already in the process, else hfem_mg_load(path) /
+ * $HFEM_RCCL_PATH, else the ROCm installation); without it these calls return an error, the rest works.      */
+typedef struct hfem_mg_comm hfem_mg_comm;
+int hfem_mg_load(const char *librccl_path);
+int hfem_mg_unique_id(void *id_out_128_bytes);
+int hfem_mg_comm_create(int device, int rank, int world, const void *id_128_bytes, hfem_mg_comm **out);
+int hfem_mg_comm_destroy(hfem_mg_comm *comm);
+int hfem_mg_allreduce_sum(hfem_mg_comm *comm, const double *send, double *recv, int64_t count, void *stream);
+int hfem_mg_allgather(hfem_mg_comm *comm, const double *send, double *recv, int64_t count, void *stream);
+/* Adam on the ROWS a rank owns (owner-sharded mode: a rank updates exactly the parameter rows its tiles own):
+ * hfem_adam_step_dev restricted to rows[n_rows] of [.][2] fp64 arrays p, g, m, v.                          */
+int hfem_adam_step_rows_dev(int device, double *p, const double *g, double *m, double *v, const int32_t *rows,
+                            int64_t n_rows, double lr, double beta1, double beta2, double eps,
+                            const int64_t *step_dev, void *stream);
+
 /* ------------------------------------------------------------------ 1D / structured
  * Grid parametrisation softplus -> clamp(1e-6) -> cumsum -> renormalise
  * (src/models.py:45-56, 146-168): p[n] -> grid[n+1]; backward ggrid[n+1] -> gp[n].

@@ -241,3 +241,88 @@ def test_lagged_loss_sum_delivers_every_energy_bit_exactly():
         _lib.check(L.hfem_tri3_energy_plan(p2.handle, m2.node_coords_free.data_ptr(), m2.node_coords_fixed.data_ptr(),
                                            m2.u_free.data_ptr(), m2.u_fixed_rows().data_ptr(), dv(lf._mat), lf._W,
                                            dv([0.0] * 6), None, dv(Tconst), 0, -1, scratch.data_ptr(), None, None, 8 | 32 | 3, st))
+
+
+@pytest.mark.gpu
+def test_library_comm_owner_training_step_captures_into_a_graph():
+    """In-library RCCL (hfem_mg_*, csrc/mg.cpp) on one rank: a whole owner-sharded training iteration -- energy,
+    Adam on the owned rows, pack, ncclAllGather on the caller's stream, unpack -- is captured into ONE hipGraph
+    (4 iterations per replay) and replayed; parameters and per-iteration energies must equal the eager sequence and
+    the plain single-GPU loop (EnergyLoss2D.value_and_grad_ + FusedAdam).  Also the dense mode's out-of-place
+    ncclAllReduce, captured."""
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import FusedAdam
+    from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(161, 121, jitter=0.2, seed=6, dtype=F64)
+
+    def model():
+        torch.manual_seed(2)
+        return PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                        neumann_edges=edges).to(d)
+    lr_x, lr_u, n_iter, per = 1e-6, 1e-8, 12, 4
+    # (a) the plain single-GPU loop
+    m0 = model()
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    opt = FusedAdam([dict(params=[m0.node_coords_free], lr=lr_x), dict(params=[m0.u_free], lr=lr_u)])
+    ref_losses = []
+    for _ in range(n_iter):
+        ref_losses.append(lf.value_and_grad_(m0).item())
+        opt.step()
+    # (b) owner-sharded, in-library comm, eager
+    comm = LibraryComm(d)
+    assert comm.world == 1
+
+    def sharded(m):
+        sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm)
+        sh.setup_interfaces()
+        sh.init_owner_adam(lr_x, lr_u)
+        return sh
+    m1 = model()
+    sh1 = sharded(m1)
+    eager = [sh1.owner_train_step().item() for _ in range(n_iter)]
+    np.testing.assert_allclose(eager, ref_losses, rtol=1e-12)
+    for a, b in zip(m1.parameters(), m0.parameters()):
+        assert (a - b).abs().max().item() <= 1e-12 * b.abs().max().item()
+    # (c) the same, `per` iterations per hipGraph replay
+    m2 = model()
+    sh2 = sharded(m2)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        first = sh2.owner_train_step().item()                  # warm-up iteration (counts)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    losses = torch.zeros(per, dtype=F64, device=d)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(per):
+            losses[i].copy_(sh2.owner_train_step())
+    got = [first]
+    n_replays = (n_iter - 1) // per
+    for _ in range(n_replays):
+        g.replay()
+        torch.cuda.synchronize()
+        got += losses.tolist()
+    np.testing.assert_allclose(got, ref_losses[:1 + n_replays * per], rtol=1e-12)
+    assert int(sh2._adam["step"].item()) == 1 + n_replays * per
+    # dense mode: out-of-place all-reduce on the caller's stream, captured
+    sh2.evaluate_local()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        sh2.exchange()
+    torch.cuda.current_stream().wait_stream(s2)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g2):
+        sh2.evaluate_local()
+        sh2.exchange()
+    sh2.recv.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(sh2.recv, sh2.send)
+    comm.close()

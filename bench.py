@@ -11,9 +11,13 @@ Workload at N = 1: BASELINE.json configs[3] "Example 4", reading (i) of SURVEY F
 plate [0,2]x[0,1], 1001x501 nodes -> 1,000,000 TRI3 (each structured quad split in two),
 interior nodes jittered 0.2 h (seed 0), outer boundary fixed, left edge Dirichlet, right edge
 Neumann (500 edges), u_free ~ 1e-5 N(0,1), E=10e9, nu=0.3, gauss_order=4, fp64, r-adaptivity on.
-N > 1 (weak scaling): the plate grows to N x 1,000,000 elements (N*1000+1 x 501 nodes); every
-rank evaluates its contiguous tile range and ONE all-reduce of the packed [gX|gU|loss] buffer
-follows.
+N > 1 (weak scaling): the plate grows to N x 1,000,000 elements (N*1000+1 x 501 nodes); every rank evaluates its
+contiguous tile range (one process per GPU), then ONE collective.  Headline (`value`) = OWNER-SHARDED mode: owner-computes
+tiles give each rank complete gradient rows for the nodes it owns, so what crosses ranks is one small all_gather of the
+interface parameter rows + the partial energies -- in-library RCCL (hfem_mg_*, csrc/mg.cpp) enqueued on the kernel's
+stream, the K steps captured in one hipGraph.  Reported beside it: `config.train_step` (the same loop with Adam on the
+owned rows inside, so the exchanged rows change every step) and `config.alt_exchange`, the north-star's literal wording:
+a dense sum all-reduce of the packed [gX|gU|loss] buffer.
 
 One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel
 (tri3_energy_fast_kernel): algorithmic bytes (12 Ne + 64 Nn + 8) over its
@@ -116,7 +120,7 @@ def main():
     from hidenn_fem_amd.mesh import structured_tri_mesh
     from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
     from hidenn_fem_amd.loss import EnergyLoss2D
-    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
 
     f64 = torch.float64
     nx = (a.nx - 1) * world + 1
@@ -130,7 +134,14 @@ def main():
         name, val = kv.split("=")
         _lib.check(_lib.lib().hfem_set_option(name.encode(), int(val)), "hfem_set_option")
     loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
-    sh = ShardedTri3Energy(model, loss_fn)
+    comm = None
+    if world > 1 and a.backend == "nccl":        # in-library RCCL communicator: collectives on the kernel's stream, capturable
+        try:
+            comm = LibraryComm(dev)
+        except Exception as e:  # pragma: no cover
+            if rank == 0:
+                print(f"[bench] in-library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+    sh = ShardedTri3Energy(model, loss_fn, comm=comm)
     plan = sh.plan
     lo, hi = sh.lo, sh.hi
     td = plan.export("tile_desc")
@@ -138,6 +149,7 @@ def main():
 
     if world > 1:
         sh.setup_interfaces()
+        sh.init_owner_adam(lr_x=1e-9, lr_u=1e-12)      # tiny steps: the mesh stays valid over any number of iterations
 
     def step_dense():           # north-star literal: one all-reduce of [gX|gU|loss] (every rank gets everything)
         sh.evaluate_local()
@@ -172,7 +184,7 @@ def main():
         assert abs(loss_gpu - loss_dense) <= 1e-12 * abs(loss_dense), (loss_gpu, loss_dense)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier+synchronize
-    use_graph = (world == 1) and not a.no_graph
+    use_graph = (world == 1 or comm is not None) and not a.no_graph
     graph = None
     if use_graph:
         try:
@@ -236,21 +248,52 @@ def main():
 
     # ---- N > 1 only, reported beside the headline: the north-star's literal exchange, a dense all-reduce of the
     #      full gradient + loss (every rank ends with everything; 16 B x 2 x nodes x N on the wire)
-    alt = None
-    if world > 1:
+    def timed_alt(body):
+        """W warm-up + K timed iterations of `body` (one hipGraph of K when the in-library comm allows capture),
+        bracketed like the headline; returns seconds (max over ranks)."""
+        g = None
+        if comm is not None and not a.no_graph:
+            try:
+                s_ = torch.cuda.Stream()
+                s_.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s_):
+                    for _ in range(2):
+                        body()
+                torch.cuda.current_stream().wait_stream(s_)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(a.steps):
+                        body()
+            except Exception:  # pragma: no cover
+                g = None
         for _ in range(a.warmup):
-            step_dense()
+            body()
+        if g is not None:
+            g.replay()
         sync_all()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step_dense()
+        t0_ = time.perf_counter()
+        if g is not None:
+            g.replay()
+        else:
+            for _ in range(a.steps):
+                body()
         sync_all()
-        el2 = time.perf_counter() - t0
-        t = torch.tensor([el2], dtype=f64, device=dev)
+        el = time.perf_counter() - t0_
+        t = torch.tensor([el], dtype=f64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = t.item()
-        alt = dict(mode=f"dense: all_reduce([gX|gU|loss]) fp64, {sh.send.numel() * 8} B per rank, backend {a.backend}",
-                   value=ne / (el2 / a.steps), ms_per_step=el2 / a.steps * 1e3)
+        return t.item(), g is not None
+
+    alt = train = None
+    if world > 1:
+        el2, g2 = timed_alt(step_dense)
+        alt = dict(mode=f"dense: sum all-reduce of [gX|gU|loss] fp64, {sh.send.numel() * 8} B per rank, "
+                        f"{'in-library RCCL on the kernel stream' if comm is not None else 'torch.distributed ' + a.backend}",
+                   value=ne / (el2 / a.steps), ms_per_step=el2 / a.steps * 1e3, launch="hipgraph" if g2 else "eager")
+        el3, g3 = timed_alt(sh.owner_train_step)
+        train = dict(mode="owner-sharded training iteration: energy -> Adam on the rows the rank owns -> pack -> all_gather "
+                          "-> unpack (the exchanged interface rows change every step)",
+                     value=ne / (el3 / a.steps), ms_per_step=el3 / a.steps * 1e3, launch="hipgraph" if g3 else "eager")
 
     # ---- roofline leg: the dominant kernel alone, K back-to-back launches, HIP events on its stream
     L = _lib.lib()
@@ -350,13 +393,18 @@ def main():
     alg_bytes = 12 * ne_launch + 64 * nn_launch + 8
     achieved = alg_bytes / (k_us * 1e-6) / 1e9
     # HBM traffic per launch: PMC numbers cannot be collected from inside this process; they come from the
-    # committed rocprofv3 passes of the SAME kernel/workload (profiles/r01_hbm_traffic_T1M.json), else null
-    traffic = None
+    # committed rocprofv3 passes of the SAME kernel/workload (profiles/r02_hbm_traffic_T1M.json, scripts/prof_regimes.sh),
+    # else null; likewise the profiler's own per-kernel average of every regime (profiles/r02/regimes_rocprof.json)
+    traffic, rocprof_us = None, {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_T1M.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_T1M.json")) as f:
             tr = json.load(f)
         if world == 1 and tr["workload"] == dict(elements=ne, nodes=nn, tiles=plan.stats["n_tiles"]):
             traffic = tr["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02", "regimes_rocprof.json")) as f:
+            rp = json.load(f)
+        if world == 1 and rp["workload"] == dict(elements=ne, nodes=nn, tiles=plan.stats["n_tiles"]):
+            rocprof_us = {k: v["avg_us"] for k, v in rp["regimes"].items()}
     except (OSError, KeyError, ValueError):
         pass
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
@@ -367,6 +415,15 @@ def main():
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
     if regimes:
         roofline["regimes"] = dict(replayed=dict(kernel_us=k_us, achieved=achieved, frac=achieved / HBM_PEAK_GBS), **regimes)
+        if "rewritten_inputs" in regimes:
+            regimes["rewritten_inputs"]["note"] = (
+                "kernel_us = (rewrite + energy) - (rewrite alone): an UPPER bound -- the two rewrite kernels themselves "
+                "slow down inside the pair (rocprofv3: 5.7 us each vs 3.5 us alone); the profiler's own duration of the "
+                "energy kernel in this sequence is rocprof_kernel_us")
+        for name, r in roofline["regimes"].items():      # the profiler's per-kernel average of the same leg (committed run)
+            if name in rocprof_us:
+                r["rocprof_kernel_us"] = rocprof_us[name]
+                r["rocprof_frac"] = alg_bytes / (rocprof_us[name] * 1e-6) / 1e9 / HBM_PEAK_GBS
 
     out = None
     if rank == 0:
@@ -394,12 +451,15 @@ def main():
                         exchange="none" if world == 1 else
                         f"owner-sharded: gradient rows stay with the rank whose tiles own the node; one all_gather per "
                         f"step of interface parameter rows + partial energy ({sh.interface_stats['payload_bytes']} B "
-                        f"per rank), backend {a.backend}",
+                        f"per rank), " + ("in-library RCCL (hfem_mg_allgather) on the kernel stream" if comm is not None
+                                          else f"torch.distributed {a.backend}"),
                         loss=loss_gpu),
             roofline=roofline,
         )
         if alt is not None:
             out["config"]["alt_exchange"] = alt
+        if train is not None:
+            out["config"]["train_step"] = train
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -34,9 +34,11 @@ struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1
 };
 
 // energy density * |det| at one point with weight w, and its gradient w.r.t. (a..d, G0, G1)
+// beta_w (body-force instances): w * b(xi_q).u_h(xi_q) of this point -- the density is w psi - beta_w; with the
+// cotangents below it adds only the sign(det) (-beta_w) cof(J) term (u_h's own gradient is added by the caller).
 template <bool GRAD>
 __device__ __forceinline__ double jac_point(double a, double b, double c, double d, double2 g0, double2 g1,
-                                            double w, const Tri3Consts &k, JacGrad &o) {
+                                            double w, const Tri3Consts &k, JacGrad &o, double beta_w = 0.0, double *A_out = nullptr) {
     const double det = a * d - b * c;
     const double inv = fast_rcp(det);
     const double A = fabs(det);
@@ -45,7 +47,8 @@ __device__ __forceinline__ double jac_point(double a, double b, double c, double
     const double h10 = g0.y * di - g1.y * bi, h11 = g1.y * ai - g0.y * ci;
     const double gam = h01 + h10;
     const double sxx = k.c11 * h00 + k.c12 * h11, syy = k.c12 * h00 + k.c22 * h11, sxy = k.c33 * gam;
-    const double wpsi = (0.5 * w) * (h00 * sxx + h11 * syy + gam * sxy);
+    const double wpsi = (0.5 * w) * (h00 * sxx + h11 * syy + gam * sxy) - beta_w;
+    if (A_out) *A_out = A;
     if (GRAD) {
         const double aw = A * w;
         const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;
@@ -80,9 +83,11 @@ __device__ __forceinline__ void shape_derivs(double xi, double eta, double (&D0)
 // coefficients with weight 1/16; cotangents are accumulated per coefficient (the a3 part as +-da +-db, scaled by
 // 1/sqrt(3) once) and spread to the nodes with +-1 at the end.  ~370 fp64 instructions per element with
 // gradients (the node-by-node D_N form above costs ~490).
-template <bool GRAD>
+// HASB: body force b(xi_q) at the four Gauss points (k.Bk... is the TRI3 table; QUAD4 takes Bq[q] = b at point q):
+// e -= sum_q |det_q| u_h(q).b_q, dU_k -= sum_q |det_q| N_k(q) b_q, and the |det_q| dependence through jac_point.
+template <bool GRAD, bool HASB = false>
 __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const double2 (&Un)[4], const Tri3Consts &k,
-                                                double2 (&gx)[4], double2 (&gu)[4]) {
+                                                double2 (&gx)[4], double2 (&gu)[4], const double2 *Bq = nullptr) {
     const double gp = 0.57735026918962576451;   // 1/sqrt(3)
     double a1[4], a2[4], a3[4];                  // components: x, y, ux, uy
     {
@@ -99,6 +104,7 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
     // Points in the order (-,-) (+,-) (-,+) (+,+).  With u_q = dE/d(4 dv/dxi) and v_q = dE/d(4 dv/deta) at point q:
     //   d a1 = sum u_q, d a2 = sum v_q, d a3 = gp ((u2+u3) - (u0+u1) + (v1+v3) - (v0+v2)); the pair sums are shared.
     double U[4][4], V[4][4];
+    double2 gub[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
     double e = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -108,7 +114,27 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
         const double2 g0 = make_double2(a1[2] + eta * a3[2], a1[3] + eta * a3[3]);
         const double2 g1 = make_double2(a2[2] + xi * a3[2], a2[3] + xi * a3[3]);
         JacGrad o;
-        e += jac_point<GRAD>(a, b, c, d, g0, g1, 0.0625, k, o);
+        if (HASB) {
+            // N_k(q) = (1 + xi_k xi)(1 + eta_k eta) / 4; the unscaled coefficients carry |det| x 16: weight 1/16
+            double nk[4], uhx = 0.0, uhy = 0.0, A16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nk[j] = 0.25 * (1.0 + corner_xi(j) * xi) * (1.0 + corner_eta(j) * eta);
+                uhx += nk[j] * Un[j].x;
+                uhy += nk[j] * Un[j].y;
+            }
+            const double2 bq = Bq[q];
+            e += jac_point<GRAD>(a, b, c, d, g0, g1, 0.0625, k, o, 0.0625 * (uhx * bq.x + uhy * bq.y), &A16);
+            if (GRAD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gub[j].x -= (0.0625 * A16) * nk[j] * bq.x;
+                    gub[j].y -= (0.0625 * A16) * nk[j] * bq.y;
+                }
+            }
+        } else {
+            e += jac_point<GRAD>(a, b, c, d, g0, g1, 0.0625, k, o);
+        }
         if (GRAD) {
             U[q][0] = o.da; U[q][1] = o.dc; U[q][2] = o.dg0.x; U[q][3] = o.dg0.y;
             V[q][0] = o.db; V[q][1] = o.dd; V[q][2] = o.dg1.x; V[q][3] = o.dg1.y;
@@ -130,7 +156,7 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             gx[j] = make_double2(g[j][0], g[j][1]);
-            gu[j] = make_double2(g[j][2], g[j][3]);
+            gu[j] = HASB ? make_double2(g[j][2] + gub[j].x, g[j][3] + gub[j].y) : make_double2(g[j][2], g[j][3]);
         }
     }
     return e;
@@ -278,13 +304,15 @@ __global__ __launch_bounds__(kBlockQ) void quad4_eval_bwd_kernel(
 // every owned gradient row written once with an sc1 (write-through) store.  Element records are two
 // words per slot: {l0 | l1<<10 | l2<<20 | home<<30 | skip<<31} and {l3}.
 // CAPO > 0: compile-time stride of the four accumulator arrays (their LDS addresses become one scaled id + immediate).
-template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0>
+struct Quad4Body { double2 b[4]; };      // body force at the 2x2 Gauss points (reference coordinates)
+
+template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false>
 __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
     const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    int stagger_ticks, int stagger_shift, unsigned long long *__restrict__ stamps) {
+    int stagger_ticks, int stagger_shift, unsigned long long *__restrict__ stamps, Quad4Body body) {
 #define HFEM_QSTAMP(I)                                                                              \
     if ((ABL & 4) && threadIdx.x == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_QSTAMP(0)
@@ -360,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { gx[j] = Xn[j]; gu[j] = Un[j]; }
             } else {
-                e = quad4_element<true>(Xn, Un, k, gx, gu);
+                e = HASB ? quad4_element<true, true>(Xn, Un, k, gx, gu, body.b) : quad4_element<true>(Xn, Un, k, gx, gu);
             }
             if (ABL & 2) {          // lab: no LDS atomics (keep the math live)
 #pragma unroll
@@ -704,7 +732,24 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
                                       const double *T_edge, const double Tconst[4], int32_t tile_begin,
                                       int32_t tile_end, double *loss_out, double *gx_free, double *gu_free,
                                       int32_t flags, void *stream) {
+    return hfem_quad4_energy_plan_body(plan, x_free, x_fixed, u_free, u_fixed, mat, nullptr, T_edge, Tconst, tile_begin,
+                                       tile_end, loss_out, gx_free, gu_free, flags, stream);
+}
+
+extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                                           const double *u_free, const double *u_fixed, const double mat[4],
+                                           const double Bq[8], const double *T_edge, const double Tconst[4],
+                                           int32_t tile_begin, int32_t tile_end, double *loss_out, double *gx_free,
+                                           double *gu_free, int32_t flags, void *stream) {
     HFEM_ARG_CHECK(plan && mat && loss_out, "null pointer");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS)),
+                   "QUAD4 extension: reference convention, atomic accumulation, inline loss sum");
+    Quad4Body body;
+    bool hasb = false;
+    for (int q = 0; q < 4; ++q) {
+        body.b[q] = Bq ? make_double2(Bq[2 * q], Bq[2 * q + 1]) : make_double2(0.0, 0.0);
+        hasb = hasb || body.b[q].x != 0.0 || body.b[q].y != 0.0;
+    }
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(plan->host.npe == 4, "this plan was built for TRI3: use hfem_tri3_energy_plan");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
@@ -726,7 +771,7 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
                        (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,   \
                        plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free, \
                        (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger, g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps)
+                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger, g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps, body)
 #ifdef HFEM_LAB
         const int abl = g_quad4_ablate;
         const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
@@ -755,7 +800,8 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
 #else
         const int stagger = 0;
 #endif
-        if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
+        if (hasb) HFEM_LAUNCH_Q4(4, 4, 0, 0, true);                  // body force: general instance (runtime strides)
+        else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
         else if (g_quad4_const_caps && h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 40960) {
             // default tile shape: compile-time accumulator stride (launched with the matching LDS size)
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 4, 4, 0, 560>), dim3(n), dim3(256),
@@ -765,7 +811,7 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
                                (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
                                (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, 560,
                                (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger,
-                               g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps);
+                               g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps, body);
         } else HFEM_LAUNCH_Q4(4, 4, 0);
 #undef HFEM_LAUNCH_Q4
         if (int rc = launch_status("hfem_quad4_energy_plan")) return rc;

@@ -130,20 +130,38 @@ class EnergyLoss2D:
         t_edge = t_force(xq_flat) if t_force is not None else self.uniform_edge_force(xq_flat)
         return torch.sum((u_edge * t_edge).sum(dim=1) * (wq_flat * ds))
 
+    def _quad4_body(self, b_force):
+        """b at the 2x2 Gauss points of the reference square (order (-,-) (+,-) (-,+) (+,+)): as on triangles the body
+        force receives REFERENCE coordinates (loss.py:60,80)."""
+        if b_force is None:
+            return None
+        g = 1.0 / 3.0 ** 0.5
+        pts = torch.tensor([[-g, -g], [g, -g], [-g, g], [g, g]], dtype=self.dtype, device=self.device)
+        return b_force(pts).to(torch.float64).reshape(-1).cpu().tolist()
+
     def _quad4(self, model, b_force, t_force):
-        """QUAD4 extension: 2x2 Gauss (gauss_order is a triangle-rule setting and does not apply), zero
-        body force, constant traction; planless fused kernels on the assembled arrays."""
-        if b_force is not None or t_force is not None:
-            raise NotImplementedError("QUAD4 extension: body force / custom traction are not built")
+        """QUAD4 extension: 2x2 Gauss (``gauss_order`` is a triangle-rule setting and does not apply); body force at the
+        reference Gauss points, traction as on triangles (constant table, per-edge table, or -- when the traction
+        depends on points that move with free nodes -- autograd through ``t_force`` on the unfused edge path)."""
         if self._mode_flags(model):
             raise NotImplementedError("QUAD4 extension: grad_convention='physical' / deterministic are TRI3 switches")
-        _, Tconst = self._traction(model, None)
+        Bq = self._quad4_body(b_force)
+        no_edges = model.neumann_edges is None or model.N_edges == 0
         if self.quad4_planless:                                    # cross-check path: fp64 global atomics
+            if b_force is not None or t_force is not None:
+                raise NotImplementedError("QUAD4 planless cross-check kernel: default forces only")
+            _, Tconst = self._traction(model, None)
             edges = model._edges32 if model.N_edges else None
             return ops.Quad4EnergyFn.apply(model.coords, model.u_full, model._conn32, edges, self._mat, Tconst)
         plan = model.tile_plan(self.tile_elems)
-        return ops.Quad4PlanEnergyFn.apply(model.node_coords_free, model.u_free, model.node_coords_fixed.to(model.dtype),
-                                           model.u_fixed_rows(), plan, self._mat, Tconst)
+        args = (model.node_coords_free, model.u_free, model.node_coords_fixed.to(model.dtype), model.u_fixed_rows(), plan,
+                self._mat)
+        if no_edges:
+            return ops.Quad4PlanEnergyFn.apply(*args, [0.0] * 4, Bq, None, HFEM_FLAG_NO_EDGES)
+        if t_force is not None and model.node_coords_free.requires_grad and self._edge_nodes_free(model):
+            return ops.Quad4PlanEnergyFn.apply(*args, [0.0] * 4, Bq, None, HFEM_FLAG_NO_EDGES) - self.edge_energy(model, t_force)
+        T_edge, Tconst = self._traction(model, t_force)
+        return ops.Quad4PlanEnergyFn.apply(*args, Tconst, Bq, T_edge, 0)
 
     def value_and_grad_(self, model) -> torch.Tensor:
         """Autograd-free fast path: ONE launch writes the total potential's gradients straight into

@@ -458,7 +458,7 @@ class Quad4PlanEnergyFn(torch.autograd.Function):
     """Tiled QUAD4 energy + Neumann work (plan with nodes_per_elem = 4): one launch, loss + unit gradients."""
 
     @staticmethod
-    def forward(ctx, x_free, u_free, x_fixed, u_fixed, plan, mat, Tconst):
+    def forward(ctx, x_free, u_free, x_fixed, u_fixed, plan, mat, Tconst, Bq=None, T_edge=None, flags=0):
         dev = x_free.device
         xf, uf = _f64(x_free, "node_coords_free"), _f64(u_free, "u_free")
         xfix, ufix = _f64(x_fixed, "node_coords_fixed"), _f64(u_fixed, "u_fixed")
@@ -466,9 +466,12 @@ class Quad4PlanEnergyFn(torch.autograd.Function):
         loss = torch.empty((), dtype=F64, device=dev)
         gx = torch.empty_like(xf) if need_gx else None
         gu = torch.empty_like(uf) if need_gu else None
-        fl = (0 if need_gx else 1) | (0 if need_gu else 2)
-        check(_lib.lib().hfem_quad4_energy_plan(plan.handle, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix), _dvec(mat), None,
-                                                _dvec(Tconst), 0, -1, ptr(loss), ptr(gx), ptr(gu), fl, stream_ptr(dev)),
+        fl = int(flags) | (0 if need_gx else 1) | (0 if need_gu else 2)
+        te = _f64(T_edge, "T_edge")
+        check(_lib.lib().hfem_quad4_energy_plan_body(plan.handle, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix), _dvec(mat),
+                                                     None if Bq is None else _dvec(Bq), ptr(te),
+                                                     None if Tconst is None else _dvec(Tconst), 0, -1, ptr(loss), ptr(gx),
+                                                     ptr(gu), fl, stream_ptr(dev)),
               "hfem_quad4_energy_plan")
         ctx.unit, ctx.dtypes = (gx, gu), (x_free.dtype, u_free.dtype)
         return loss.to(x_free.dtype) if x_free.dtype != F64 else loss
@@ -479,4 +482,4 @@ class Quad4PlanEnergyFn(torch.autograd.Function):
         gx, gu = ctx.unit
         g64 = g.to(F64)
         return (None if gx is None else (gx * g64).to(ctx.dtypes[0]),
-                None if gu is None else (gu * g64).to(ctx.dtypes[1]), None, None, None, None, None)
+                None if gu is None else (gu * g64).to(ctx.dtypes[1])) + (None,) * 8

@@ -223,6 +223,14 @@ int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, const double *
                            const double *T_edge, const double Tconst[4], int32_t tile_begin,
                            int32_t tile_end, double *loss_out, double *gx_free, double *gu_free,
                            int32_t flags, void *stream);
+/* Same with a body force: Bq [4][2] = b at the 2x2 Gauss points in REFERENCE coordinates (the reference's triangle
+ * path hands b_force the reference points, src/loss.py:60,80 -- SURVEY F6), order (-,-) (+,-) (-,+) (+,+);
+ * e -= sum_q |detJ_q| u_h(xi_q).b_q.  NULL / all zero = hfem_quad4_energy_plan.                        */
+int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free, const double *x_fixed,
+                                const double *u_free, const double *u_fixed, const double mat[4],
+                                const double Bq[8], const double *T_edge, const double Tconst[4],
+                                int32_t tile_begin, int32_t tile_end, double *loss_out, double *gx_free,
+                                double *gu_free, int32_t flags, void *stream);
 /* Per-point forward/backward with the (x_ref, element_id) contract of src/models.py:316:
  * x_eval [M][2] in [-1,1]^2 -> u_h [M][2], detJ [M], grad_u [M][2][2]; backward ACCUMULATES gX,gU. */
 int hfem_quad4_eval_fwd(int device, const double *X, const double *U, const int32_t *conn4,

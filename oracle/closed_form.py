@@ -24,6 +24,8 @@ def lib():
         _lib = C.CDLL(_build.build())
         _lib.oracle_tri3_energy.restype = C.c_double
         _lib.oracle_tri3_energy.argtypes = [_dp, _dp, _ip, C.c_int64, _dp, C.c_double, _dp, _dp, _dp]
+        _lib.oracle_quad4_energy.restype = C.c_double
+        _lib.oracle_quad4_energy.argtypes = [_dp, _dp, _ip, C.c_int64, _dp, _dp, _dp, _dp]
         _lib.oracle_edge2_energy.restype = C.c_double
         _lib.oracle_edge2_energy.argtypes = [_dp, _dp, _ip, C.c_int64, _dp, _dp, _dp, _dp]
         _lib.oracle_tri3_eval.restype = None
@@ -69,6 +71,18 @@ def tri3_energy(X, U, conn, mat, W, Bk=None, grads=True):
     gU = np.zeros_like(U) if grads else None
     e = lib().oracle_tri3_energy(_d(X), _d(U), _i(conn), conn.shape[0], _d(_f64(mat)), float(W),
                                  _d(Bk), _d(gX), _d(gU))
+    return e, gX, gU
+
+
+def quad4_energy(X, U, conn4, mat, Bq=None, grads=True):
+    """QUAD4-iso extension (parity unpinned by the reference, SURVEY F11) -> (domain energy, gX, gU);
+    ``Bq [4,2]``: body force at the 2x2 Gauss points (reference coordinates, order (-,-) (+,-) (-,+) (+,+))."""
+    X, U = _f64(X), _f64(U)
+    conn4 = np.ascontiguousarray(conn4, dtype=np.int64)
+    Bq = None if Bq is None else _f64(Bq).reshape(8)
+    gX = np.zeros_like(X) if grads else None
+    gU = np.zeros_like(U) if grads else None
+    e = lib().oracle_quad4_energy(_d(X), _d(U), _i(conn4), conn4.shape[0], _d(_f64(mat)), _d(Bq), _d(gX), _d(gU))
     return e, gX, gU
 
 

@@ -82,6 +82,74 @@ double oracle_tri3_energy(const double *X, const double *U, const int64_t *conn,
     return total;
 }
 
+/* ---------------------------------------------------------------- QUAD4 -----
+ * PARITY UNPINNED BY THE REFERENCE: achraf-15/HiDeNN-FEM has no isoparametric quadrilateral.  This is
+ * the extension element as SURVEY section 8a specifies it, in the plain node-by-node D_N form (the kernels use a
+ * bilinear-coefficient form: an independent derivation), with the reference's triangle conventions:
+ * J[i][j] = sum_k x_k[i] D_N[j][k] (models.py:339), dN_dx = Jinv * D_N (models.py:351, F4), abs(detJ) (loss.py:84).
+ * conn4 [Ne][4] int64, local nodes CCW from (-1,-1); 2x2 Gauss (+-1/sqrt(3), weights 1) in the order
+ * (-,-) (+,-) (-,+) (+,+); Bq [4][2] = body force at those REFERENCE points (loss.py:80 passes reference
+ * coordinates, F6) or NULL.  Accumulates gX,gU [Nn][2] (caller zeroes; may be NULL) and returns
+ * sum_e sum_q |detJ_q| (psi_q - u_h(q).b_q).                                                                  */
+double oracle_quad4_energy(const double *X, const double *U, const int64_t *conn4, int64_t ne, const double *mat,
+                           const double *Bq, double *gX, double *gU)
+{
+    const double c11 = mat[0], c12 = mat[1], c22 = mat[2], c33 = mat[3];
+    const double gp = 0.57735026918962576451;
+    static const double XI[4] = {-1.0, 1.0, 1.0, -1.0}, ETA[4] = {-1.0, -1.0, 1.0, 1.0};
+    double total = 0.0;
+    for (int64_t e = 0; e < ne; ++e) {
+        int64_t n[4];
+        double x[4], y[4], ux[4], uy[4], gxx[4] = {0, 0, 0, 0}, gxy[4] = {0, 0, 0, 0}, gux[4] = {0, 0, 0, 0}, guy[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; ++k) {
+            n[k] = conn4[4 * e + k];
+            x[k] = X[2 * n[k]]; y[k] = X[2 * n[k] + 1]; ux[k] = U[2 * n[k]]; uy[k] = U[2 * n[k] + 1];
+        }
+        for (int q = 0; q < 4; ++q) {
+            const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp;
+            double N[4], D0[4], D1[4];
+            double a = 0, b = 0, c = 0, d = 0, g0x = 0, g0y = 0, g1x = 0, g1y = 0, uhx = 0, uhy = 0;
+            for (int k = 0; k < 4; ++k) {
+                N[k] = 0.25 * (1.0 + XI[k] * xi) * (1.0 + ETA[k] * eta);
+                D0[k] = 0.25 * XI[k] * (1.0 + ETA[k] * eta);
+                D1[k] = 0.25 * ETA[k] * (1.0 + XI[k] * xi);
+                a += x[k] * D0[k]; b += x[k] * D1[k]; c += y[k] * D0[k]; d += y[k] * D1[k];
+                g0x += ux[k] * D0[k]; g0y += uy[k] * D0[k]; g1x += ux[k] * D1[k]; g1y += uy[k] * D1[k];
+                uhx += N[k] * ux[k]; uhy += N[k] * uy[k];
+            }
+            const double det = a * d - b * c, sg = det < 0.0 ? -1.0 : 1.0, A = fabs(det);
+            const double h00 = (g0x * d - g1x * b) / det, h01 = (-g0x * c + g1x * a) / det;
+            const double h10 = (g0y * d - g1y * b) / det, h11 = (-g0y * c + g1y * a) / det;
+            const double gam = h01 + h10;
+            const double sxx = c11 * h00 + c12 * h11, syy = c12 * h00 + c22 * h11, sxy = c33 * gam;
+            const double psi = 0.5 * (h00 * sxx + h11 * syy + gam * sxy);
+            const double bx = Bq ? Bq[2 * q] : 0.0, by = Bq ? Bq[2 * q + 1] : 0.0;
+            const double dens = psi - (uhx * bx + uhy * by);
+            total += A * dens;
+            if (!gX) continue;
+            const double p00 = A * sxx, p01 = A * sxy, p10 = A * sxy, p11 = A * syy;
+            const double dg0x = (p00 * d - p01 * c) / det, dg0y = (p10 * d - p11 * c) / det;
+            const double dg1x = (-p00 * b + p01 * a) / det, dg1y = (-p10 * b + p11 * a) / det;
+            double da = (p01 * g1x + p11 * g1y) / det, db = -(p00 * g1x + p10 * g1y) / det;
+            double dc = -(p01 * g0x + p11 * g0y) / det, dd = (p00 * g0x + p10 * g0y) / det;
+            const double ddet = -(p00 * h00 + p01 * h01 + p10 * h10 + p11 * h11) / det + sg * dens;
+            da += ddet * d; dd += ddet * a; db -= ddet * c; dc -= ddet * b;
+            for (int k = 0; k < 4; ++k) {
+                gxx[k] += da * D0[k] + db * D1[k];
+                gxy[k] += dc * D0[k] + dd * D1[k];
+                gux[k] += dg0x * D0[k] + dg1x * D1[k] - A * N[k] * bx;
+                guy[k] += dg0y * D0[k] + dg1y * D1[k] - A * N[k] * by;
+            }
+        }
+        if (gX)
+            for (int k = 0; k < 4; ++k) {
+                gX[2 * n[k]] += gxx[k]; gX[2 * n[k] + 1] += gxy[k];
+                gU[2 * n[k]] += gux[k]; gU[2 * n[k] + 1] += guy[k];
+            }
+    }
+    return total;
+}
+
 /* ---------------------------------------------------------------- EDGE2 -----
  * edges [Ned][2] int64, index-sorted (i<j, mesh.py:130,255).  T [Ned][4] =
  * {Ti.x, Ti.y, Tj.x, Tj.y} with Ti = sum_q w_q (1-xi_q) t(x_q), Tj = sum_q w_q

@@ -32,17 +32,26 @@ def quad4_forward(coords, u_full, conn4, x_eval, elem_id):
     return u_h, detJ, grad_u
 
 
-def quad4_domain_energy(coords, u_full, conn4, C):
-    """sum_e sum_{2x2 Gauss} w |detJ| psi  (weights 1, points +-1/sqrt(3))."""
+def gauss_2x2(dtype=torch.float64):
+    """The 2x2 Gauss points in the order (-,-) (+,-) (-,+) (+,+) (weights 1)."""
+    g = 1.0 / torch.sqrt(torch.tensor(3.0, dtype=dtype))
+    return torch.stack([torch.stack([-g, -g]), torch.stack([g, -g]), torch.stack([-g, g]), torch.stack([g, g])])
+
+
+def quad4_domain_energy(coords, u_full, conn4, C, b_force=None):
+    """sum_e sum_{2x2 Gauss} w |detJ| (psi - b(xi_q).u_h)  (weights 1, points +-1/sqrt(3)); ``b_force`` receives
+    the REFERENCE points, as the reference's triangle path does (loss.py:60,80)."""
     dt = coords.dtype
     g = 1.0 / torch.sqrt(torch.tensor(3.0, dtype=dt))
     pts = torch.stack([torch.stack([-g, -g]), torch.stack([g, -g]), torch.stack([-g, g]), torch.stack([g, g])])
     ne = conn4.shape[0]
     x_eval = pts.unsqueeze(0).expand(ne, 4, 2).reshape(-1, 2)
     elem_id = torch.arange(ne).unsqueeze(1).repeat(1, 4).reshape(-1)
-    _, detJ, grad_u = quad4_forward(coords, u_full, conn4, x_eval, elem_id)
+    u_eval, detJ, grad_u = quad4_forward(coords, u_full, conn4, x_eval, elem_id)
     gx, gy = grad_u[:, 0, :], grad_u[:, 1, :]
     eps = torch.stack([gx[:, 0], gy[:, 1], 2 * (0.5 * (gx[:, 1] + gy[:, 0]))], dim=1)
     sig = eps @ C.T
     psi = 0.5 * torch.sum(eps * sig, dim=1)
+    if b_force is not None:
+        return torch.sum(detJ.abs() * psi) - torch.sum(detJ.abs() * torch.sum(b_force(x_eval) * u_eval, dim=1))
     return torch.sum(detJ.abs() * psi)

@@ -28,6 +28,61 @@ def test_quad4_oracle_sanity_on_rectilinear_cells():
     assert torch.allclose(u_h, xp @ A.T, atol=1e-12)
 
 
+def test_quad4_c_closed_form_matches_the_autograd_restatement():
+    """oracle/hfem_oracle.c:oracle_quad4_energy (node-by-node D_N form, hand backward) against oracle/quad4.py (autograd
+    through the op chain) with and without a body force -- two independent statements of the SURVEY section 8a spec.
+    PARITY UNPINNED BY THE REFERENCE (it has no QUAD4 element): these two are each other's only check."""
+    from oracle import quad4 as Q, ref_chain as R, closed_form as CF
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    from conftest import b_force_fn
+    c, cn, *_ = structured_quad_mesh(23, 17, jitter=0.3, seed=3, dtype=F64)
+    U = 1e-3 * torch.randn(c.shape, dtype=F64, generator=torch.Generator().manual_seed(1))
+    for bf in (None, b_force_fn):
+        X, Uu = c.clone().requires_grad_(True), U.clone().requires_grad_(True)
+        e = Q.quad4_domain_energy(X, Uu, cn, R.plane_stress_C(), bf)
+        e.backward()
+        Bq = None if bf is None else bf(Q.gauss_2x2()).numpy()
+        e2, gX, gU = CF.quad4_energy(c.numpy(), U.numpy(), cn.numpy(), CF.plane_stress(), Bq)
+        assert abs(e.item() - e2) <= 1e-13 * abs(e2)
+        assert np.abs(gX - X.grad.numpy()).max() <= 1e-12 * np.abs(gX).max()
+        assert np.abs(gU - Uu.grad.numpy()).max() <= 1e-12 * np.abs(gU).max()
+
+
+@pytest.mark.gpu
+def test_quad4_body_force_and_traction_function():
+    """The QUAD4 path takes a body force (at the reference Gauss points, as the triangle path does, F6) and a
+    position-dependent traction (per-edge table when the Neumann nodes are fixed, autograd through ``t_force`` when
+    they move) -- what EnergyLoss2D.__call__(model, b_force, t_force) offers for triangles (loss.py:80,106)."""
+    from oracle import quad4 as Q, ref_chain as R
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from conftest import b_force_fn, t_force_fn
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_quad_mesh(23, 17, jitter=0.25, seed=4, dtype=F64)
+    for fixed_boundary in (True, False):                   # False: the Neumann nodes are free -> autograd through t_force
+        bmask = geom if fixed_boundary else torch.zeros_like(geom)
+        torch.manual_seed(1)
+        m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=bmask, dirichlet_mask=bc, u_fixed=0.0,
+                                     neumann_edges=edges).to(d)
+        with torch.no_grad():
+            m.u_free.mul_(50.0)
+        lf = EnergyLoss2D(device=d, dtype=F64)
+        loss = lf(m, b_force=lambda x: b_force_fn(x.cpu()).to(d), t_force=lambda x: t_force_fn(x.cpu()).to(d))
+        loss.backward()
+        xf = m.node_coords_free.detach().cpu().clone().requires_grad_(True)
+        uf = m.u_free.detach().cpu().clone().requires_grad_(True)
+        X = R.assemble_coords(coords.shape[0], ~bmask, xf, bmask, coords[bmask])
+        U = R.assemble_u(coords.shape[0], ~bc, uf, bc, torch.tensor(0.0, dtype=F64))
+        ref = Q.quad4_domain_energy(X, U, conn, R.plane_stress_C(), b_force_fn) - \
+            R.edge_energy(X, U, edges, *R.interval_gauss(2), t_force=t_force_fn)
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 1e-12 * abs(ref.item()), fixed_boundary
+        gx, gu = m.node_coords_free.grad.cpu().numpy(), m.u_free.grad.cpu().numpy()
+        assert np.abs(gx - xf.grad.numpy()).max() <= 1e-10 * np.abs(xf.grad.numpy()).max()
+        assert np.abs(gu - uf.grad.numpy()).max() <= 1e-10 * np.abs(uf.grad.numpy()).max()
+
+
 @pytest.mark.gpu
 def test_quad4_kernels_match_the_autograd_oracle():
     from oracle import quad4 as Q, ref_chain as R
@@ -134,3 +189,12 @@ def test_quad4_one_million_elements_runs_and_matches_sampled_oracle():
     assert (m.u_free.grad - gu).abs().max() <= 1e-10 * gu.abs().max()
     st = m.tile_plan().stats
     assert st["n_elems"] == 10 ** 6 and st["lds_bytes"] <= 40 * 1024
+    # FULL comparison at 10^6 elements against the C closed form (oracle/hfem_oracle.c:oracle_quad4_energy -- parity
+    # unpinned by the reference: it has no QUAD4 element), loss and every gradient row, with the Neumann edge work
+    from oracle import closed_form as CF
+    Xn, Un = X.numpy(), U.numpy()
+    e_ref, gX_ref, gU_ref = CF.quad4_energy(Xn, Un, conn.numpy(), CF.plane_stress())
+    e_ref -= CF.edge2_energy(Xn, Un, edges.numpy(), Tconst=np.array([lf._ci * 1e5, 0.0, lf._cj * 1e5, 0.0]), gX=gX_ref, gU=gU_ref)
+    assert abs(loss.item() - e_ref) <= 1e-12 * abs(e_ref)
+    assert np.abs(gx.cpu().numpy() - gX_ref[~geom.numpy()]).max() <= 1e-10 * np.abs(gX_ref).max()
+    assert np.abs(gu.cpu().numpy() - gU_ref[~bc.numpy()]).max() <= 1e-10 * np.abs(gU_ref).max()

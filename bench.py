@@ -56,6 +56,7 @@ def parse():
                     "1-block launch after every energy kernel instead of inside the next launch")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed replays before each timed leg")
     ap.add_argument("--option", action="append", default=[], help="name=value for hfem_set_option (lab A/B runs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip config.extra (Q1M, T2M, cfg5 structured / Delaunay kernel timings)")
     ap.add_argument("--no-regimes", action="store_true", help="skip the extra cache-regime legs of the roofline block")
     ap.add_argument("--only-regime", default="", help="rocprof helper: run ONLY this roofline leg (replayed | "
                     "rewritten_inputs | rotating_sets) and exit")
@@ -425,6 +426,64 @@ def main():
                 r["rocprof_kernel_us"] = rocprof_us[name]
                 r["rocprof_frac"] = alg_bytes / (rocprof_us[name] * 1e-6) / 1e9 / HBM_PEAK_GBS
 
+    # ---- config.extra (N = 1): the other readings of "1 M quad elements" and BASELINE config 5, kernel only, each with
+    #      its own roofline figures (algorithmic bytes of ITS element type over ITS kernel's average launch time):
+    #        Q1M   10^6 QUAD4-iso elements (the extension element; parity unpinned by the reference)
+    #        T2M   the same 10^6 quads split in two: 2 x 10^6 TRI3 (reference-pinned element)
+    #        cfg5  4 x 10^6 TRI3, structured split with random diagonals + random element / node permutation
+    #        cfg5u 4.1 x 10^6 TRI3, genuinely unstructured: Delaunay of graded random points, plate with three holes
+    extras = []
+    if world == 1 and not a.no_extra and not only:
+        from hidenn_fem_amd.mesh import structured_quad_mesh, unstructured_tri_mesh
+
+        def extra(name, mesh, quad=False):
+            c_, cn_, g_, b_, _, e_ = mesh
+            torch.manual_seed(0)
+            m_ = PiecewiseLinearShapeNN2D(c_, cn_, boundary_mask=g_, dirichlet_mask=b_, u_fixed=0.0, neumann_edges=e_).to(dev)
+            lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64)
+            pl = m_.tile_plan(0)
+            x_, u_ = m_.node_coords_free.detach(), m_.u_free.detach()
+            xfx, ufx = m_.node_coords_fixed, m_.u_fixed_rows()
+            gx_, gu_ = torch.empty_like(x_), torch.empty_like(u_)
+            ls_ = torch.zeros((), dtype=f64, device=dev)
+            _, Tc_ = lf_._traction(m_, None)
+            Tcv = dv(Tc_)
+
+            def launch(i):
+                if quad:
+                    _lib.check(L.hfem_quad4_energy_plan(pl.handle, x_.data_ptr(), xfx.data_ptr(), u_.data_ptr(), ufx.data_ptr(),
+                                                        mat, None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(), gu_.data_ptr(),
+                                                        8, stream.cuda_stream))
+                else:
+                    _lib.check(L.hfem_tri3_energy_plan(pl.handle, x_.data_ptr(), xfx.data_ptr(), u_.data_ptr(), ufx.data_ptr(),
+                                                       mat, W, Bk, None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(),
+                                                       gu_.data_ptr(), 8, stream.cuda_stream))
+            us, _ = time_launches(launch)
+            ne_, nn_ = cn_.shape[0], c_.shape[0]
+            ab = (16 if quad else 12) * ne_ + 64 * nn_ + 8
+            st_ = pl.stats
+            extras.append(dict(name=name, element="QUAD4" if quad else "TRI3", elements=ne_, nodes=nn_, tiles=st_["n_tiles"],
+                               halo_elem_factor=st_["tile_elem_total"] / ne_, halo_node_factor=st_["tile_node_total"] / nn_,
+                               kernel_us=us, element_evals_per_s=ne_ / (us * 1e-6), alg_bytes_per_launch=ab,
+                               achieved=ab / (us * 1e-6) / 1e9, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS))
+            del m_, pl
+
+        keep = kreps
+        kreps = min(kreps, 60)
+        extra("Q1M: 10^6 QUAD4-iso (1001 x 1001 nodes), parity unpinned by the reference",
+              structured_quad_mesh(1001, 1001, length=2.0, height=2.0, jitter=0.2, seed=0, dtype=f64), quad=True)
+        extra("T2M: the same 10^6 quads split in two (2 x 10^6 TRI3)",
+              structured_tri_mesh(1001, 1001, length=2.0, height=2.0, jitter=0.2, seed=0, dtype=f64))
+        extra("cfg5: 4 x 10^6 TRI3, random diagonals, random element + node permutation",
+              structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=f64))
+        from hidenn_fem_amd.mesh import reorder_for_locality
+        extra("cfg5r: cfg5 after mesh.reorder_for_locality (Hilbert node renumbering, the host mesh pipeline's step)",
+              reorder_for_locality(structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True,
+                                                       dtype=f64))[0])
+        extra("cfg5u: genuinely unstructured (Delaunay, plate with three holes, graded), ~4.1 x 10^6 TRI3",
+              unstructured_tri_mesh(2_050_000, seed=2, dtype=f64))
+        kreps = keep
+
     out = None
     if rank == 0:
         cpu = None
@@ -456,6 +515,8 @@ def main():
                         loss=loss_gpu),
             roofline=roofline,
         )
+        if extras:
+            out["config"]["extra"] = extras
         if alt is not None:
             out["config"]["alt_exchange"] = alt
         if train is not None:

@@ -168,6 +168,52 @@ def structured_quad_mesh(nx: int, ny: int, length: float = 2.0, height: float = 
             torch.tensor(bc), torch.tensor(mn), torch.tensor(edges, dtype=torch.long))
 
 
+def _hilbert_keys(pts: np.ndarray, bits: int = 16) -> np.ndarray:
+    """Hilbert-curve position of every point (vectorised; one isotropic scale, as the tile planner uses)."""
+    lo = pts.min(axis=0)
+    span = max(float((pts.max(axis=0) - lo).max()), 1e-300)
+    q = np.clip(((pts - lo) * ((2 ** bits - 1) / span)).astype(np.int64), 0, 2 ** bits - 1)
+    x, y = q[:, 0].copy(), q[:, 1].copy()
+    d = np.zeros(len(pts), dtype=np.int64)
+    s_ = 1 << (bits - 1)
+    full = 2 ** bits - 1
+    while s_ > 0:
+        rx = ((x & s_) > 0).astype(np.int64)
+        ry = ((y & s_) > 0).astype(np.int64)
+        d += s_ * s_ * ((3 * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, full - x, x)
+        y = np.where(flip, full - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s_ >>= 1
+    return d
+
+
+def reorder_for_locality(mesh):
+    """Locality renumbering of a mesh 6-tuple ("locality reordering ... decides LDS-tile hit
+    rate"): nodes are renumbered along a Hilbert curve of their coordinates and the elements sorted along the curve
+    of their centroids, so that the nodes of a tile are neighbours in memory (a tile's 16-byte row gathers then share
+    cache lines instead of touching one line per row).  The energy and its gradients do not depend on the global
+    numbering (only on each element's LOCAL node order, which is kept -- SURVEY F4).  Works for TRI3 and QUAD4
+    connectivities.  Returns ``(mesh6_reordered, new_of_old)`` with ``new_of_old[n]`` = new id of old node ``n``:
+    ``coords_new[new_of_old] == coords_old``."""
+    coords, conn, geom, bc, mn, edges = mesh
+    pts = coords.detach().cpu().double().numpy()
+    order = np.argsort(_hilbert_keys(pts), kind="stable")            # old ids in new order
+    new_of_old = np.empty(len(pts), dtype=np.int64)
+    new_of_old[order] = np.arange(len(pts))
+    cn = new_of_old[conn.cpu().numpy()]
+    cen = pts[conn.cpu().numpy()].mean(axis=1)
+    cn = cn[np.argsort(_hilbert_keys(cen), kind="stable")]
+    ed = new_of_old[edges.cpu().numpy()] if edges is not None and edges.numel() else np.zeros((0, 2), dtype=np.int64)
+    if len(ed):
+        ed = np.unique(np.sort(ed, axis=1), axis=0)                   # index-sorted unique, the rule of mesh.py:125-134
+    idx = torch.from_numpy(order)
+    out = (coords[idx], torch.from_numpy(cn), geom[idx], bc[idx], mn[idx], torch.from_numpy(ed.astype(np.int64)))
+    return out, torch.from_numpy(new_of_old)
+
+
 def generate_mesh(
     length: float = 2.0,
     height: float = 1.0,

@@ -92,3 +92,34 @@ def test_tile_plan_on_unstructured_mesh(seed, tile_elems):
     # halo factors stay moderate on a graded mesh (the planner's locality curve works on centroids, not on a grid)
     assert st["tile_elem_total"] < 1.6 * conn.shape[0] and st["tile_node_total"] < 1.9 * nn
     plan.close()
+
+
+def test_reorder_for_locality_keeps_the_mesh_and_makes_tiles_contiguous():
+    """mesh.reorder_for_locality: a pure renumbering (same geometry, same local node order per element, same BC sets,
+    same energy by the C closed form), after which a tile's owned nodes are (nearly) one contiguous id range."""
+    from hidenn_fem_amd.mesh import reorder_for_locality, structured_tri_mesh
+    mesh = structured_tri_mesh(61, 47, jitter=0.3, seed=5, diagonal="random", permute=True, flip_fraction=0.2, dtype=torch.float64)
+    (c2, cn2, g2, b2, m2, e2), new_of_old = reorder_for_locality(mesh)
+    c, cn, g, b, m, e = mesh
+    assert torch.equal(c2[new_of_old], c) and torch.equal(g2[new_of_old], g) and torch.equal(b2[new_of_old], b)
+    # same elements with the same LOCAL order (as a multiset of coordinate triples in order)
+    key = lambda cc, co: np.sort(np.ascontiguousarray(cc.numpy()[co.numpy()].reshape(len(co), -1)).view([("", "f8")] * 6).ravel())
+    assert np.array_equal(key(c, cn), key(c2, cn2))
+    ed2 = e2.numpy()
+    assert (ed2[:, 0] < ed2[:, 1]).all() and m2.numpy()[ed2].all() and len(ed2) == len(e)
+    U = 1e-4 * np.random.default_rng(0).standard_normal(c.shape)
+    U2 = np.empty_like(U)
+    U2[new_of_old.numpy()] = U
+    mat = CF.plane_stress()
+    e_a, gXa, gUa = CF.tri3_energy(c.numpy(), U, cn.numpy(), mat, 0.25)
+    e_b, gXb, gUb = CF.tri3_energy(c2.numpy(), U2, cn2.numpy(), mat, 0.25)
+    assert abs(e_a - e_b) <= 1e-12 * abs(e_a)
+    assert np.abs(gXb[new_of_old.numpy()] - gXa).max() <= 1e-10 * np.abs(gXa).max()
+    # locality: span of owned node ids per tile
+    def spans(cc, co):
+        p = TilePlan(co, cc.shape[0], coords_hint=cc, tile_elems=600, device=None)
+        td, ns = p.export("tile_desc"), p.export("node_src")
+        out = [np.ptp(ns[no:no + nown, 0]) / max(nown, 1) for (_, _, no, _, nown, _, _, _) in td if nown > 8]
+        p.close()
+        return float(np.median(out))
+    assert spans(c2, cn2) < 6.0 < 20.0 < spans(c, cn)      # id span per owned node: ~3 after (tile + halo of neighbours), ~n_nodes/n_owned before

@@ -388,8 +388,7 @@ def main():
     # algorithmic bytes of ONE launch on this rank: its home elements and owned nodes
     ne_launch = int(td[lo:hi, 1].sum()) if world > 1 else ne      # (halo elements are not algorithmic work)
     if world > 1:
-        ep = plan.export("elem_pack")
-        ne_launch = int(sum(int(((ep[o:o + n] >> 30) & 1).sum()) for o, n in td[lo:hi, :2]))
+        ne_launch = int(sum(int(plan.tile_elements(t)[2].sum()) for t in range(lo, hi)))
     nn_launch = int(td[lo:hi, 4].sum())
     alg_bytes = 12 * ne_launch + 64 * nn_launch + 8
     achieved = alg_bytes / (k_us * 1e-6) / 1e9

@@ -58,6 +58,16 @@ struct HostPlan {
     // id ranges.  tile_chunks[t] = {e1, e2, po0 | po1<<8 | ph0<<16 | ph1<<24, 0}: po_k / ph_k = number of
     // 64-id pieces of the owned / halo id range that strips 0..k need.  Empty for the other element orders.
     std::vector<int32_t> tile_chunks;
+    // Paired element order (elem_order 5; contract of tri3_pair.hip): a slot holds element A = (n, b, c) and, when
+    // `hasB`, a second element B = (n, c, d) that shares A's corner-0 node and A's corner 2 as its corner 1 (two
+    // fan-adjacent elements around n -- e.g. the two triangles of a split quad).  The shared nodes' contributions are
+    // added in registers: 16 LDS atomics per pair instead of 24, 8 node reads instead of 12.  Records:
+    //   elem_pack[s]    = l_n | l_b<<10 | l_c<<20 | homeA<<30 | skip<<31
+    //   elem_pack_hi[s] = l_d | hasB<<10 | homeB<<11
+    // elem_gid[s] = A's element id, elem_gid_b[s] = B's (or -1).  Elements without a partner are slots with hasB = 0.
+    std::vector<int32_t> elem_gid_b;
+    bool paired = false;
+    int64_t n_pairs = 0;
     // compact copies of the inputs (the deterministic node-centric kernel walks the mesh itself, tri3_det.hip)
     std::vector<int32_t> conn32, x_src_g, u_src_g, edges32;
     int32_t max_chunk_elems = 0;       // longest strip (slots); 0 = not chunked

@@ -25,6 +25,13 @@ struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgr
 };
 
 
+struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
+    double2 *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows); must not alias the inputs
+    double2 *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows, updated in place
+    const double *bc = nullptr;                  // device {1 - b1^step, sqrt(1 - b2^step)} of this step (hfem_adam_prep)
+    double lr_x = 0, lr_u = 0, b1 = 0.9, b2 = 0.999, eps = 1e-8;
+};
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
 // L2).  Map block -> tile so that each XCD walks one contiguous run of the
 // Morton-ordered tiles: neighbouring tiles share halo nodes, which then hit the
@@ -90,6 +97,22 @@ int launch_tri3_stream(const hfem_plan *plan, int n_grid, int tile_begin, const 
                        const double *u_free, const double *u_fixed, const Tri3Consts &kc, const double *T_edge,
                        double4 tc, double *partials, double *gx_free, double *gu_free, int skip_edges, int store_policy,
                        const LagSum &lag, hipStream_t s, int ablate = 0);
+// tri3_pair.hip: paired-slot kernel on a paired plan (plan_elem_order 5, the default); 1 = launched, 0 = tile shape not held
+struct PairLaunch {
+    PlanDev pd;
+    int grid = 0, tile_begin = 0;
+    const void *x_free = nullptr, *x_fixed = nullptr, *u_free = nullptr, *u_fixed = nullptr;
+    Tri3Consts k;
+    const double4 *T_edge = nullptr;
+    double4 tc;
+    double *partials = nullptr;
+    void *gx = nullptr, *gu = nullptr;
+    int max_nodes = 0, max_owned = 0, skip_edges = 0;
+    size_t lds = 0;
+    hipStream_t s = nullptr;
+};
+int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
+                     const AdamFuse &af);
 // tri3_det.hip: fixed-order (bit-reproducible) energy + gradients; phys: the physical gradient convention
 int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed, const double *u_free,
                     const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,

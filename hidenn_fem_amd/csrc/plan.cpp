@@ -19,6 +19,8 @@
 // The local order of an element's three nodes is never changed (the reference
 // energy depends on it).
 #include <algorithm>
+#include <array>
+#include <unordered_map>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -164,6 +166,62 @@ void pack_bank_groups(const std::vector<int32_t> &elems, const int64_t *conn, in
         out.insert(out.end(), open[j].el.begin(), open[j].el.end());
         if ((pad_last || j + 1 < open.size()) && (int)open[j].el.size() < G) out.insert(out.end(), G - open[j].el.size(), -1);
     }
+}
+
+// Same packing for abstract slots with up to four local ids each (-1: none): returns the slot order (indices into
+// `items`, -1 = padding).  Used by the paired element order, whose slots carry the node ids (n, b, c, d).
+void pack_slot_groups(const std::vector<std::array<int32_t, 4>> &items, int32_t n_owned, std::vector<int32_t> &out) {
+    constexpr int G = 16;
+    struct Open { std::vector<int32_t> el; uint16_t used[4]; };
+    std::vector<int32_t> byc[5];
+    for (int32_t i = 0; i < (int32_t)items.size(); ++i) {
+        int owned = 0, have = 0;
+        for (int k = 0; k < 4; ++k) { have += items[i][k] >= 0; owned += items[i][k] >= 0 && items[i][k] < n_owned; }
+        (void)have;
+        byc[4 - owned].push_back(i);
+    }
+    std::vector<Open> open;
+    size_t first_open = 0;
+    for (int cls = 0; cls <= 4; ++cls)
+        for (int32_t i : byc[cls]) {
+            uint16_t bit[4];
+            for (int k = 0; k < 4; ++k) {
+                const int32_t l = items[i][k];
+                bit[k] = (l >= 0 && l < n_owned) ? (uint16_t)(1u << (l & 15)) : 0;
+            }
+            bool placed = false;
+            for (size_t j = first_open; j < open.size(); ++j) {
+                Open &g = open[j];
+                if ((int)g.el.size() >= G) continue;
+                if ((g.used[0] & bit[0]) | (g.used[1] & bit[1]) | (g.used[2] & bit[2]) | (g.used[3] & bit[3])) continue;
+                g.el.push_back(i);
+                for (int k = 0; k < 4; ++k) g.used[k] |= bit[k];
+                placed = true;
+                break;
+            }
+            if (!placed) {
+                Open g;
+                g.el.push_back(i);
+                for (int k = 0; k < 4; ++k) g.used[k] = bit[k];
+                open.push_back(std::move(g));
+            }
+            while (first_open < open.size() && (int)open[first_open].el.size() >= G) ++first_open;
+        }
+    // fullest first; the emptiest groups are dissolved into the holes of the fuller ones even where that costs a bank
+    // conflict (one extra LDS cycle on that group) -- cheaper than idle lanes.  Only the last group can be short.
+    std::stable_sort(open.begin(), open.end(), [](const Open &a, const Open &b) { return a.el.size() > b.el.size(); });
+    {
+        size_t lo = 0, hi = open.size();
+        while (lo < hi && (int)open[lo].el.size() >= G) ++lo;
+        while (lo + 1 < hi) {
+            Open &dst = open[lo], &srcg = open[hi - 1];
+            while ((int)dst.el.size() < G && !srcg.el.empty()) { dst.el.push_back(srcg.el.back()); srcg.el.pop_back(); }
+            if (srcg.el.empty()) --hi;
+            if ((int)dst.el.size() >= G) ++lo;
+        }
+        open.resize(hi);
+    }
+    for (size_t j = 0; j < open.size(); ++j) out.insert(out.end(), open[j].el.begin(), open[j].el.end());
 }
 
 // Order the elements of one tile so that the 64 lanes of a wave-instruction (64 consecutive
@@ -446,17 +504,91 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             chunk_rec[2] = po0 | (po1 << 8) | (ph0 << 16) | (ph1 << 24);
         } else {
             for (int32_t n : halo) lid[n] = nloc++;
-            order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
+            if (!(elem_order == 5 && npe == 3)) order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
         }
         nloc = d.n_owned + (int32_t)halo.size();
         if (elem_order == 4) P.tile_chunks.insert(P.tile_chunks.end(), chunk_rec, chunk_rec + 4);
 
         d.elem_off = (int32_t)P.elem_pack.size();
-        d.n_elem = (int32_t)telems.size();
         d.node_off = (int32_t)(P.node_src.size() / 2);
         d.n_node = nloc;
         d.edge_off = (int32_t)P.edge_pack.size();
         d.n_edge = (int32_t)(edg_ptr[t + 1] - edg_ptr[t]);
+        if (elem_order == 5 && npe == 3) {
+            // ---- paired slots.  B is the successor of A when A's corner 0 is B's corner 0 and A's corner 2 is B's corner 1
+            //      (the next element of the fan around n).  succ/pred are partial injective maps, so the candidate graph is
+            //      a set of paths and cycles; consecutive elements are paired greedily along each.
+            const int n = (int)telems.size();                   // telems: plain element ids here (order_tile_elements skipped)
+            std::unordered_map<uint64_t, int32_t> by_edge0;    // (c0, c1) -> index in telems
+            by_edge0.reserve((size_t)n * 2);
+            for (int i = 0; i < n; ++i) {
+                const int64_t e = telems[i];
+                by_edge0[((uint64_t)conn[3 * e] << 32) | (uint32_t)conn[3 * e + 1]] = i;
+            }
+            std::vector<int32_t> succ(n, -1), pred(n, -1);
+            for (int i = 0; i < n; ++i) {
+                const int64_t e = telems[i];
+                auto it = by_edge0.find(((uint64_t)conn[3 * e] << 32) | (uint32_t)conn[3 * e + 2]);   // B with (c0, c1) = (A.c0, A.c2)
+                if (it != by_edge0.end() && it->second != i && pred[it->second] < 0) { succ[i] = it->second; pred[it->second] = i; }
+            }
+            std::vector<char> used(n, 0);
+            std::vector<std::array<int32_t, 2>> slots;         // (A index, B index or -1)
+            slots.reserve(n);
+            for (int pass = 0; pass < 2; ++pass)               // pass 0: paths from their heads; pass 1: what is left (cycles)
+                for (int i = 0; i < n; ++i) {
+                    if (used[i] || (pass == 0 && pred[i] >= 0)) continue;
+                    int a = i;
+                    while (a >= 0 && !used[a]) {
+                        used[a] = 1;
+                        const int b = succ[a];
+                        if (b >= 0 && !used[b]) { used[b] = 1; slots.push_back({a, b}); a = succ[b]; }
+                        else { slots.push_back({a, -1}); a = -1; }
+                    }
+                }
+            // pairs first (curve order kept), then singles: waves are uniform in `hasB` except one
+            std::stable_sort(slots.begin(), slots.end(), [](const std::array<int32_t, 2> &x, const std::array<int32_t, 2> &y) { return (x[1] >= 0) > (y[1] >= 0); });
+            std::vector<std::array<int32_t, 4>> items(slots.size());
+            for (size_t s_ = 0; s_ < slots.size(); ++s_) {
+                const int64_t ea = telems[slots[s_][0]];
+                items[s_] = {lid[conn[3 * ea]], lid[conn[3 * ea + 1]], lid[conn[3 * ea + 2]],
+                             slots[s_][1] >= 0 ? lid[conn[3 * (int64_t)telems[slots[s_][1]] + 2]] : -1};
+            }
+            std::vector<int32_t> order_s;
+            // pack pairs and singles separately so the pairs stay in front
+            size_t n_pair = 0;
+            while (n_pair < slots.size() && slots[n_pair][1] >= 0) ++n_pair;
+            {
+                std::vector<std::array<int32_t, 4>> part(items.begin(), items.begin() + n_pair);
+                std::vector<int32_t> o;
+                pack_slot_groups(part, d.n_owned, o);
+                while (!o.empty() && (o.size() & 15)) o.push_back(-1);
+                order_s = o;
+                part.assign(items.begin() + n_pair, items.end());
+                o.clear();
+                pack_slot_groups(part, d.n_owned, o);
+                for (int32_t v : o) order_s.push_back(v < 0 ? -1 : v + (int32_t)n_pair);
+            }
+            d.n_elem = (int32_t)order_s.size();
+            for (int32_t si : order_s) {
+                if (si < 0) {
+                    P.elem_pack.push_back(kSkipBit);
+                    P.elem_pack_hi.push_back(0u);
+                    P.elem_gid.push_back(-1);
+                    P.elem_gid_b.push_back(-1);
+                    continue;
+                }
+                const int32_t ea = telems[slots[si][0]], eb = slots[si][1] >= 0 ? telems[slots[si][1]] : -1;
+                const std::array<int32_t, 4> &L = items[si];
+                P.elem_pack.push_back((uint32_t)L[0] | ((uint32_t)L[1] << kLocalBits) | ((uint32_t)L[2] << (2 * kLocalBits)) |
+                                      (home[ea] == t ? kHomeBit : 0u));
+                P.elem_pack_hi.push_back(eb >= 0 ? ((uint32_t)L[3] | (1u << 10) | (home[eb] == t ? (1u << 11) : 0u)) : 0u);
+                P.elem_gid.push_back(ea);
+                P.elem_gid_b.push_back(eb);
+                P.n_pairs += eb >= 0;
+            }
+            P.paired = true;
+        } else {
+        d.n_elem = (int32_t)telems.size();
         for (int32_t e : telems) {
             if (e < 0) {                                   // padding of a bank-conflict-free group
                 P.elem_pack.push_back(kSkipBit);
@@ -470,6 +602,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
                                   (home[e] == t ? kHomeBit : 0u));
             if (npe == 4) P.elem_pack_hi.push_back((uint32_t)lid[conn[npe * (int64_t)e + 3]]);
             P.elem_gid.push_back(e);
+        }
         }
         auto push_node = [&](int32_t n) {
             P.node_src.push_back(x_src ? x_src[n] : n);
@@ -524,6 +657,7 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
         const int rc = try_build(conn, npe, ne, nn, coords, x_src, u_src, edges, ned, T, node_cap, order, elem_order, chunk_cap, out);
         if (rc == 0 && npe == 4 && out.max_elems > kMaxQuadSlots) continue;   // QUAD4 kernel: <= 4 slots x 256 threads
+        if (rc == 0 && out.paired && out.max_elems > 6 * 256) continue;      // pair kernel: <= 6 slots x 256 threads
         if (rc == 0) {
             out.conn32.assign(conn, conn + npe * ne);
             out.edges32.assign(edges, edges + 2 * ned);

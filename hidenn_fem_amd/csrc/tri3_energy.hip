@@ -233,13 +233,6 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // SIMD (<= 64 VGPRs) so that four 512-thread workgroups (32 waves) are resident per CU -- the
 // residency the balanced tile plan is sized for.  The other instances keep the compiler's budget
 // (forcing 64 VGPRs on them spills).
-struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
-    double2 *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows); must not alias the inputs
-    double2 *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows, updated in place
-    const double *bc = nullptr;                  // device {1 - b1^step, sqrt(1 - b2^step)} of this step (hfem_adam_prep)
-    double lr_x = 0, lr_u = 0, b1 = 0.9, b2 = 0.999, eps = 1e-8;
-};
-
 // V2 = storage type of the parameter / gradient rows: double2, or float2 for fp32 models (the reference's default
 // dtype) -- rows are widened on load and rounded once on store, all arithmetic stays fp64.
 // CAPN / CAPO > 0: compile-time LDS array strides (nodes / owned nodes per tile, >= the plan's maxima): every LDS
@@ -702,7 +695,10 @@ struct Defaults {
                                             // L2 and does not evict the re-read inputs / plan arrays), 0 = plain
     std::atomic<int> tiled_fast{1};         // register-prefetched kernel (0: the generic loop kernel)
     std::atomic<int> fast_const_caps{1};    // default tile shape: instance with compile-time accumulator strides
-    std::atomic<int> plan_elem_order{3};    // 3: LDS-bank-aware 16-lane groups (plan.cpp); 4: the same inside three strips
+    std::atomic<int> plan_elem_order{-1};   // TRI3: -1 = auto (paired when >= 90 % of the elements find a partner, else 3; measured
+                                            // crossover), 5 = paired slots (two fan-adjacent elements per slot, tri3_pair.hip; the default),
+                                            // 3 = one element per slot in LDS-bank-aware 16-lane groups, 4 = the same inside three
+                                            // strips (lab), 0..2 legacy orders; QUAD4 plans always use 3
     std::atomic<int> plan_node_cap{-1};     // max distinct nodes among a tile's own elements; 0: cut by element count only;
                                             // -1 (auto): 557 when tile_elems is left to the library, else 0.  557 nodes keep
                                             // (n_node + n_owned) * 32 B <= 38.9 KB: four 512-thread workgroups per CU
@@ -939,9 +935,20 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     int32_t node_cap = g_def.plan_node_cap.load();
     if (node_cap < 0) node_cap = tile_elems <= 0 ? 557 : 0;
     if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
-    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap,
-                        g_def.plan_elem_order.load(), g_def.plan_chunk_cap.load(), p->host))
+    int order = g_def.plan_elem_order.load();
+    const bool auto_order = order < 0;
+    if (auto_order) order = nodes_per_elem == 3 ? 5 : 3;
+    if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, order,
+                        g_def.plan_chunk_cap.load(), p->host))
         return -1;
+    if (auto_order && p->host.paired && 2 * p->host.n_pairs * 10 < 9 * ne) {
+        // few fan-adjacent partners (local node orders are what they are -- they cannot be rotated): the
+        // one-element-per-slot order with the 512-thread kernel is faster there (profiles/r02: random diagonals 11.3 vs 12.1 us)
+        p->host = HostPlan();
+        if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, 3,
+                            g_def.plan_chunk_cap.load(), p->host))
+            return -1;
+    }
     const HostPlan &h = p->host;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
@@ -952,7 +959,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         int rc = 0;
         if (!rc) rc = hfem_upload(&raw->d_tiles, h.tiles.data(), h.tiles.size(), raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_elem_pack, h.elem_pack.data(), h.elem_pack.size(), raw->device_bytes);
-        if (!rc && h.npe == 4) rc = hfem_upload(&raw->d_elem_pack_hi, h.elem_pack_hi.data(), h.elem_pack_hi.size(), raw->device_bytes);
+        if (!rc && (h.npe == 4 || h.paired)) rc = hfem_upload(&raw->d_elem_pack_hi, h.elem_pack_hi.data(), h.elem_pack_hi.size(), raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
@@ -1002,6 +1009,7 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 5: src = h.elem_gid.data(); n = (int64_t)h.elem_gid.size(); break;
         case 7: src = h.elem_pack_hi.data(); n = (int64_t)h.elem_pack_hi.size(); break;
         case 8: src = h.tile_chunks.data(); n = (int64_t)h.tile_chunks.size(); break;
+        case 9: src = h.elem_gid_b.data(); n = (int64_t)h.elem_gid_b.size(); break;
         case 6: {   // lab build: device stamps, 16 x uint64 per tile, returned as 32 x int32 per tile
             n = (int64_t)h.tiles.size() * 32;
             if (buf) {
@@ -1046,8 +1054,8 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     bool hasb = false;
     for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
     const bool phys = (flags & HFEM_FLAG_PHYSICAL_GRAD) != 0;
-    const bool phys_fast = phys && !(flags & HFEM_FLAG_DETERMINISTIC) && plan->tune.tiled_block == 512 &&
-                           h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512;
+    const bool phys_fast = phys && !(flags & HFEM_FLAG_DETERMINISTIC) &&
+                           (h.paired || (plan->tune.tiled_block == 512 && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512));
     if ((flags & HFEM_FLAG_DETERMINISTIC) || (phys && !phys_fast)) {
         // fixed-order node-centric path (tri3_det.hip); also carries the physical convention for plan shapes the
         // tiled PHYS instance does not hold
@@ -1068,8 +1076,8 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     double *pbase = plan->d_partials + (size_t)wbank * nt;
     LagSum lag;
     if (lag_consume) {
-        HFEM_ARG_CHECK(plan->tune.tiled_fast && plan->tune.tiled_block == 512 && !hasb && !phys && plan->tune.store_policy == 16 &&
-                       h.max_nodes <= 1024 && h.max_elems <= 2048,
+        HFEM_ARG_CHECK(h.paired || (plan->tune.tiled_fast && plan->tune.tiled_block == 512 && !hasb && !phys && plan->tune.store_policy == 16 &&
+                       h.max_nodes <= 1024 && h.max_elems <= 2048),
                        "HFEM_FLAG_SUM_PREVIOUS: only the default (register-prefetched, 512-thread) kernel path implements it");
         lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
         lag.prev_n = plan->prev_n;
@@ -1090,7 +1098,18 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         A.stagger_cfg = g_fast_stagger_shift | ((g_fast_stagger_groups - 1) << 8);
         if (!phys) launched = launch_tri3_lab(plan, A, n, hasb, lag, &n_partials);
 #endif
-        if (!launched && phys_fast) {     // opt-in physical convention: one general instance of the register-prefetched kernel
+        if (!launched && h.paired) {      // paired plan (plan_elem_order 5, the default): its records are the pair kernel's
+            PairLaunch P;
+            P.grid = n + (lag.prev ? 1 : 0); P.tile_begin = (int)tile_begin;
+            P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
+            P.k = A.k; P.T_edge = A.T_edge; P.tc = tc; P.partials = A.partials; P.gx = A.gx; P.gu = A.gu;
+            P.skip_edges = A.skip_edges; P.s = s;
+            HFEM_ARG_CHECK(!(lag.prev && (hasb || phys)), "HFEM_FLAG_SUM_PREVIOUS: default forces and convention only");
+            const int rc_pair = launch_tri3_pair(plan, P, (hasb || phys) ? 1 : 0, hasb, phys, lag, AdamFuse{});
+            HFEM_ARG_CHECK(rc_pair == 1, "paired plan: tile shape outside the pair kernel's instances");
+            launched = true;
+        }
+        if (!launched && phys_fast && !h.paired) {     // opt-in physical convention: one general instance of the register-prefetched kernel
             launch_fast<512, 2, 4, true, 16, double2, 0, false, true>(A, n, AdamFuse{}, LagSum{});
             launched = true;
         }
@@ -1136,13 +1155,25 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     bool hasb = false;
     for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
     HFEM_ARG_CHECK(!hasb && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
-                   "fp32-storage path: needs a zero body force and tiles of <= 1024 nodes / 2048 element slots");
+                   "fp32-storage path: needs a zero body force and tiles of <= 1024 nodes / 2048 slots");
     if (int rc = use_device(plan->device)) return rc;
     PlanLock lock(plan);
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
     double *pbase = plan->d_partials + (size_t)plan->bank * nt + tile_begin;
-    if (n > 0) {
+    if (n > 0 && h.paired) {
+        PairLaunch P;
+        P.grid = n; P.tile_begin = (int)tile_begin;
+        P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
+        P.k = make_consts(mat, W, Bk); P.T_edge = (const double4 *)T_edge;
+        P.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+        P.partials = pbase;
+        P.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; P.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
+        P.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0; P.s = s;
+        HFEM_ARG_CHECK(launch_tri3_pair(plan, P, 2, false, false, LagSum{}, AdamFuse{}) == 1,
+                       "paired plan: tile shape outside the pair kernel's instances");
+        if (int rc = launch_status("hfem_tri3_energy_plan_f32")) return rc;
+    } else if (n > 0) {
         Tri3Launch A;
         A.pd = plan_dev(plan); A.tile_begin = (int)tile_begin;
         A.x_free = x_free; A.x_fixed = x_fixed; A.u_free = u_free; A.u_fixed = u_fixed;
@@ -1218,7 +1249,14 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
         A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
         A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
         const int grid = n + (lag_consume ? 1 : 0);
-        if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, double2, 0, true, false>(A, grid, af, lag);
+        if (h.paired) {
+            PairLaunch P;
+            P.grid = grid; P.tile_begin = 0;
+            P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
+            P.k = A.k; P.T_edge = A.T_edge; P.tc = A.tc; P.partials = pbase; P.skip_edges = A.skip_edges; P.s = s;
+            HFEM_ARG_CHECK(launch_tri3_pair(plan, P, 3, false, false, lag, af) == 1,
+                           "paired plan: tile shape outside the pair kernel's instances");
+        } else if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, double2, 0, true, false>(A, grid, af, lag);
         else launch_fast<512, 2, 4, false, 16, double2, 0, true, false>(A, grid, af, lag);
         if (int rc = launch_status("hfem_tri3_energy_adam_step")) return rc;
     }
@@ -1267,7 +1305,7 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "quad4_const_caps") {
         g_quad4_const_caps = value ? 1 : 0;
     } else if (n == "plan_elem_order") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 4, "plan_elem_order must be 0..4");
+        HFEM_ARG_CHECK(value >= -1 && value <= 5, "plan_elem_order must be -1 (auto) or 0..5");
         g_def.plan_elem_order = value;
     } else if (n == "plan_node_cap") {
         HFEM_ARG_CHECK(value >= -1 && value <= 1024, "plan_node_cap must be -1 (auto), 0 (off) or 1..1024");

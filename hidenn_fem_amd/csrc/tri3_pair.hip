@@ -1,0 +1,253 @@
+// Paired-slot TRI3 + EDGE2 energy kernel, gfx950 (MI355X): the tiled owner-computes pass of tri3_energy.hip with FEWER
+// LDS ATOMICS per element.
+//
+// Replaces EnergyLoss2D.__call__ + loss.backward() of the reference (/root/reference/src/loss.py:55-116 over
+// /root/reference/src/models.py:292-376) exactly as tri3_energy_fast_kernel does -- same closed forms (hfem_device.h),
+// same owner-computes tiling, same outputs -- on a PAIRED plan (plan_elem_order 5, plan.cpp): a slot holds element
+// A = (n, b, c) and, when the planner found one, the next element of the fan around n, B = (n, c, d) (A's corner 0 is B's
+// corner 0, A's corner 2 is B's corner 1: e.g. the two triangles of a split quad; each element keeps ITS OWN local node
+// order -- the reference energy depends on it).  The thread evaluates A, then B, and adds the contributions to
+// the two shared nodes in registers: a full pair costs 16 ds_add_f64 and 8 ds_read_b128 instead of 24 and 12.  The round-2
+// decomposition put the LDS atomics at 2.9 us of an 11 us launch, the largest single item.
+// Elements without a partner are slots with hasB = 0 (12 atomics, as before).
+// HBM-bound, no MFMA (2x2 / 2x3 contractions).  Algorithmic bytes per launch: 12 Ne + 64 Nn + 8.
+#include <hip/hip_runtime.h>
+
+#include "hfem_device.h"
+#include "hfem_plan_dev.h"
+
+namespace hfem {
+
+// BLOCK threads per tile; NPT >= ceil(max nodes / BLOCK), EPT >= ceil(max slots / BLOCK).  WPS = waves per SIMD the
+// register budget is sized for.  Measured best on T1M (round 2, profiles/r02): 256 threads, three slots per thread,
+// 86 VGPRs, four workgroups per CU -- 9.5 us against 11.2 us for the one-element-per-slot kernel at 512 threads.
+// CAPO > 0: compile-time stride of the four accumulator arrays.  LDS layout as tri3_energy_fast_kernel.
+// HASB: body-force table; PHYS: opt-in physical gradient convention (hfem_device.h); V2: row storage type (double2, or
+// float2 for fp32 models: widened on load, rounded once on store, fp64 arithmetic); ADAM: the write-out applies
+// torch.optim.Adam's update instead of storing the gradient (AdamFuse, hfem_tri3_energy_adam_step).
+template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
+          bool ADAM = false>
+__global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
+    PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
+    const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
+    const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
+    V2 *__restrict__ gx_free, V2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
+    LagSum lag, AdamFuse af) {
+    const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
+    extern __shared__ double2 lds[];
+    double2 *nd_xy = lds;
+    double2 *nd_uv = lds + cap_nodes;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
+
+    const int tid = threadIdx.x;
+    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0);
+    if (lag.prev && (int)blockIdx.x == n_launch) {      // HFEM_FLAG_SUM_PREVIOUS: reduce the previous launch's tile energies
+        double v = 0.0;
+        if (tid < 256)
+            for (int i = tid; i < lag.prev_n; i += 256) v += lag.prev[i];
+        const double tot = block_sum(v, red);
+        if (tid == 0) lag.out[0] = tot;
+        return;
+    }
+    const int slot = xcd_tile(blockIdx.x, n_launch);
+    const TileDesc d = pd.tiles[tile_begin + slot];
+    const int n_owned = d.n_owned;
+
+    // ---- all index loads first: row maps and slot records
+    int2 s[NPT];
+    uint32_t w0[EPT], w1[EPT];
+    const int2 *src = pd.node_src + d.node_off;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        s[j] = make_int2(0, 0);
+        if (l < d.n_node) s[j] = src[l];
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * BLOCK;
+        w0[j] = kSkipBit;
+        w1[j] = 0u;
+        if (i < d.n_elem) { w0[j] = pd.elem_pack[d.elem_off + i]; w1[j] = pd.elem_pack_hi[d.elem_off + i]; }
+    }
+    // ---- gather through the row maps into LDS, clear the accumulators
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        if (l < d.n_node) {
+            const V2 vx = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
+            const V2 vu = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
+            nd_xy[l] = make_double2((double)vx.x, (double)vx.y);
+            nd_uv[l] = make_double2((double)vu.x, (double)vu.y);
+        }
+        if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
+    }
+    __syncthreads();
+
+    auto add_row = [&](int l, const double2 gx, const double2 gu) {
+        unsafeAtomicAdd(&acc0[l], gx.x); unsafeAtomicAdd(&acc1[l], gx.y);
+        unsafeAtomicAdd(&acc2[l], gu.x); unsafeAtomicAdd(&acc3[l], gu.y);
+    };
+    // ---- slots: registers + LDS only
+    double e_loc = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t p = w0[j], q = w1[j];
+        if (!(p & kSkipBit)) {
+            const int ln = (int)(p & kLocalMask), lb = (int)((p >> kLocalBits) & kLocalMask),
+                      lc = (int)((p >> (2 * kLocalBits)) & kLocalMask);
+            const double2 Xn = nd_xy[ln], Un = nd_uv[ln], Xc = nd_xy[lc], Uc = nd_uv[lc];
+            double2 sxn, sun, sxc, suc;                 // running rows of the shared nodes n and c
+            {
+                double2 gx[3], gu[3];
+                const double e = tri3_element<true, HASB, PHYS>(Xn, nd_xy[lb], Xc, Un, nd_uv[lb], Uc, k, gx, gu);
+                if (p & kHomeBit) e_loc += e;
+                if (lb < n_owned) add_row(lb, gx[1], gu[1]);
+                sxn = gx[0]; sun = gu[0]; sxc = gx[2]; suc = gu[2];
+            }
+            if (q & (1u << 10)) {                       // B = (n, c, d)
+                const int ld = (int)(q & kLocalMask);
+                double2 gx[3], gu[3];
+                const double e = tri3_element<true, HASB, PHYS>(Xn, Xc, nd_xy[ld], Un, Uc, nd_uv[ld], k, gx, gu);
+                if (q & (1u << 11)) e_loc += e;
+                if (ld < n_owned) add_row(ld, gx[2], gu[2]);
+                sxn.x += gx[0].x; sxn.y += gx[0].y; sun.x += gu[0].x; sun.y += gu[0].y;
+                sxc.x += gx[1].x; sxc.y += gx[1].y; suc.x += gu[1].x; suc.y += gu[1].y;
+            }
+            if (ln < n_owned) add_row(ln, sxn, sun);
+            if (lc < n_owned) add_row(lc, sxc, suc);
+        }
+    }
+    const int n_edge = skip_edges ? 0 : d.n_edge;
+    for (int i = tid; i < n_edge; i += BLOCK) {          // boundary tiles only
+        const uint32_t p = pd.edge_pack[d.edge_off + i];
+        const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
+        const double4 tt = T_edge ? T_edge[pd.edge_gid[d.edge_off + i]] : Tconst;
+        double2 gx[2], gu[2];
+        const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
+        if (p & kHomeBit) e_loc -= wk;
+        if (l0 < n_owned) add_row(l0, gx[0], gu[0]);
+        if (l1 < n_owned) add_row(l1, gx[1], gu[1]);
+    }
+    {
+        const double w = wave_sum(e_loc);
+        if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
+    }
+    __syncthreads();
+
+    if (ADAM) {
+        // Fused optimiser step (hfem_tri3_energy_adam_step): the tile that owns a row holds its complete gradient (acc*) and
+        // its current value (nd_xy / nd_uv) in LDS, so it applies torch.optim.Adam's update here: m, v read-modify-written,
+        // the NEW row to the OTHER parameter buffer (tiles still gathering must see the old one: ping-pong); the gradient
+        // never goes to memory.  Arithmetic = optim.hip's adam_step_dev_kernel, operation for operation.
+        const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];
+        const double w1 = 1.0 - af.b1, w2 = 1.0 - af.b2;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int l = tid + j * BLOCK;
+            if (l < n_owned) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {              // c = 0: coordinates, 1: displacements
+                    const int row = c ? s[j].y : s[j].x;
+                    if (row < 0) continue;
+                    const double2 g = c ? make_double2(acc2[l], acc3[l]) : make_double2(acc0[l], acc1[l]);
+                    const double2 p = c ? nd_uv[l] : nd_xy[l];
+                    double2 *mp = (c ? af.mu : af.mx) + row, *vp = (c ? af.vu : af.vx) + row;
+                    const double2 m = *mp, v = *vp;
+                    const double ss = (c ? af.lr_u : af.lr_x) / bc1;
+                    double2 mn, vn, pn;
+                    mn.x = m.x + w1 * (g.x - m.x); mn.y = m.y + w1 * (g.y - m.y);
+                    vn.x = v.x * af.b2 + w2 * (g.x * g.x); vn.y = v.y * af.b2 + w2 * (g.y * g.y);
+                    pn.x = p.x - ss * (mn.x / (sqrt(vn.x) / sqrt_bc2 + af.eps));
+                    pn.y = p.y - ss * (mn.y / (sqrt(vn.y) / sqrt_bc2 + af.eps));
+                    *mp = mn; *vp = vn;
+                    (c ? af.u_out : af.x_out)[row] = pn;
+                }
+            }
+        }
+    } else {
+    // ---- every owned gradient row is written exactly once (write-through: the line leaves the XCD's L2)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr bool kWide = sizeof(V2) == 16;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
+    __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int l = tid + j * BLOCK;
+        if (l < n_owned) {
+            if (gx_free && s[j].x >= 0) {
+                V2 v;
+                v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, 16);
+            }
+            if (gu_free && s[j].y >= 0) {
+                V2 v;
+                v.x = acc2[l]; v.y = acc3[l];
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, 16);
+            }
+        }
+    }
+    }   // !ADAM
+    if (tid == 0) {                                     // fixed order: the tile energy is bit-reproducible
+        double tile_e = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
+        partials[slot] = tile_e;
+    }
+}
+
+template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM>
+static void launch_pair_inst(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
+    const size_t lds = CAPO > 0 ? (size_t)(A.max_nodes * 32 + CAPO * 32 + 128) : A.lds;
+    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM>), dim3(A.grid), dim3(BLK), lds, A.s,
+                       A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
+                       (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
+                       CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af);
+}
+
+// Launch on a paired plan: picks the instance that holds the plan's tile shape.  1 = launched, 0 = none does.
+// mode: 0 fp64 reference convention (zero body force), 1 general fp64 (body force and / or physical convention),
+//       2 fp32 rows, 3 fused Adam write-out.
+int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
+                     const AdamFuse &af) {
+    const HostPlan &h = plan->host;
+    if (!h.paired || !plan->d_elem_pack_hi) return 0;
+    A.pd = plan_dev(plan);
+    A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.lds = (size_t)plan->lds_bytes;
+    const bool cc = h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 38912;   // four workgroups per CU
+    const int npt = h.max_nodes <= 3 * 256 ? 3 : 4;
+    const int ept = (h.max_elems + 255) / 256;
+    if (h.max_nodes > 4 * 256 || ept > 6) return 0;
+#define HFEM_PAIR_EPT(NPT, CO, HB, PH, V, AD)                                                    \
+    switch (ept) {                                                                               \
+        case 1: case 2: case 3: launch_pair_inst<256, NPT, 3, CO, HB, PH, V, AD>(A, lag, af); return 1; \
+        case 4: launch_pair_inst<256, NPT, 4, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
+        case 5: launch_pair_inst<256, NPT, 5, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
+        default: launch_pair_inst<256, NPT, 6, CO, HB, PH, V, AD>(A, lag, af); return 1;          \
+    }
+    if (mode == 0) {
+        if (cc && npt == 3) HFEM_PAIR_EPT(3, 560, false, false, double2, false)
+        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, false)
+        HFEM_PAIR_EPT(4, 0, false, false, double2, false)
+    } else if (mode == 1) {
+        if (phys) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, true, double2, false) HFEM_PAIR_EPT(4, 0, true, true, double2, false) }
+        (void)hasb;
+        if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, double2, false)
+        HFEM_PAIR_EPT(4, 0, true, false, double2, false)
+    } else if (mode == 2) {
+        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, false)
+        HFEM_PAIR_EPT(4, 0, false, false, float2, false)
+    } else if (mode == 3) {
+        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, true)
+        HFEM_PAIR_EPT(4, 0, false, false, double2, true)
+    }
+#undef HFEM_PAIR_EPT
+    return 0;
+}
+
+}  // namespace hfem

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 
 EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
-              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8}
+              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8, "elem_gid_b": 9}
 
 
 def _np(a, dtype):
@@ -74,7 +74,7 @@ class TilePlan:
             rc = L.hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
                                        p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
         finally:
-            if prev_order is not None and prev_order >= 0:
+            if prev_order is not None:
                 L.hfem_set_option(b"plan_elem_order", prev_order)
         _lib.check(rc, "hfem_plan_create")
         st = _lib.PlanStats()
@@ -106,6 +106,43 @@ class TilePlan:
         elif name == "stamps":
             out = out.view(np.uint64).reshape(-1, 16)
         return out
+
+    # ---- format-independent view of the element records (tests, bench bookkeeping, the CPU tile evaluators)
+    def is_paired(self) -> bool:
+        """True for the paired element order (plan_elem_order 5, the default for TRI3): a slot holds element
+        A = (n, b, c) and optionally B = (n, c, d) -- ``elem_pack`` / ``elem_pack_hi`` as ``csrc/hfem_common.h`` says."""
+        return self.nodes_per_elem == 3 and self._export_len("elem_gid_b") > 0
+
+    def _export_len(self, name):
+        return int(_lib.lib().hfem_plan_export(self._h, EXPORT_IDS[name], None, 0))
+
+    def tile_elements(self, t: int):
+        """``(gid [m], loc [m, npe], home [m] bool)``: global id, tile-local node ids (in the element's own local order)
+        and the counted-here flag of every REAL element tile ``t`` evaluates, whatever the record format (padding records
+        dropped, pairs expanded)."""
+        c = getattr(self, "_dec", None)
+        if c is None:
+            c = self._dec = dict(td=self.export("tile_desc"), ep=self.export("elem_pack"), eg=self.export("elem_gid"))
+            if self.nodes_per_elem == 4 or self.is_paired():
+                c["hi"] = self.export("elem_pack_hi")
+            if self.is_paired():
+                c["egb"] = self.export("elem_gid_b")
+        eo, nel = int(c["td"][t, 0]), int(c["td"][t, 1])
+        w0 = c["ep"][eo:eo + nel]
+        real = (w0 >> 31) == 0
+        w0 = w0[real]
+        l0, l1, l2 = w0 & 1023, (w0 >> 10) & 1023, (w0 >> 20) & 1023
+        gid, home = c["eg"][eo:eo + nel][real], ((w0 >> 30) & 1).astype(bool)
+        if self.nodes_per_elem == 4:
+            return gid, np.stack([l0, l1, l2, c["hi"][eo:eo + nel][real] & 1023], axis=1).astype(np.int64), home
+        loc = np.stack([l0, l1, l2], axis=1).astype(np.int64)
+        if "egb" not in c:
+            return gid, loc, home
+        w1 = c["hi"][eo:eo + nel][real]
+        hb = ((w1 >> 10) & 1).astype(bool)
+        locb = np.stack([l0[hb], l2[hb], w1[hb] & 1023], axis=1).astype(np.int64)        # B = (n, c, d)
+        return (np.concatenate([gid, c["egb"][eo:eo + nel][real][hb]]), np.concatenate([loc, locb]),
+                np.concatenate([home, ((w1[hb] >> 11) & 1).astype(bool)]))
 
     def shard_range(self, rank: int, world: int):
         """Contiguous tile range of ``rank`` (tiles are Morton-ordered, so a range is a

@@ -41,11 +41,21 @@ def main():
     ap.add_argument("--prewarm", type=float, default=0.3)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--permute", action="store_true")
+    ap.add_argument("--diagonal", default="fixed", help="structured mesh: fixed | zigzag | random")
+    ap.add_argument("--mesh", default="structured", help="structured | cfg5 | cfg5r | delaunay (4 M-element BASELINE config 5 variants)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     f64 = torch.float64
-    kw = dict(diagonal="random", permute=True, jitter=0.3) if a.permute else dict(jitter=0.2)
-    coords, conn, geom, bc, mn, edges = structured_tri_mesh(a.nx, a.ny, seed=0, dtype=f64, **kw)
+    kw = dict(diagonal="random", permute=True, jitter=0.3) if a.permute else dict(jitter=0.2, diagonal=a.diagonal)
+    if a.mesh == "structured":
+        coords, conn, geom, bc, mn, edges = structured_tri_mesh(a.nx, a.ny, seed=0, dtype=f64, **kw)
+    elif a.mesh in ("cfg5", "cfg5r"):
+        from hidenn_fem_amd.mesh import reorder_for_locality
+        m6 = structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=f64)
+        coords, conn, geom, bc, mn, edges = reorder_for_locality(m6)[0] if a.mesh == "cfg5r" else m6
+    else:
+        from hidenn_fem_amd.mesh import unstructured_tri_mesh
+        coords, conn, geom, bc, mn, edges = unstructured_tri_mesh(2_050_000, seed=2, dtype=f64)
     torch.manual_seed(0)
     model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
                                      neumann_edges=edges).to(dev)

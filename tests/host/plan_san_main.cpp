@@ -49,6 +49,13 @@ int main(int argc, char **argv) {
                 for (int k = 0; k < 3; ++k)
                     if ((int)((pk >> (kLocalBits * k)) & kLocalMask) >= d.n_node) { fprintf(stderr, "local id out of range\n"); return 1; }
                 if (pk & kHomeBit) home[P.elem_gid[d.elem_off + i]]++;
+                if (P.paired) {
+                    const uint32_t hi = P.elem_pack_hi[d.elem_off + i];
+                    if ((hi >> 10) & 1u) {
+                        if ((int)(hi & kLocalMask) >= d.n_node) { fprintf(stderr, "local id out of range (B)\n"); return 1; }
+                        if ((hi >> 11) & 1u) home[P.elem_gid_b[d.elem_off + i]]++;
+                    }
+                }
             }
             for (int l = 0; l < d.n_owned; ++l) {
                 const int32_t src = P.node_src[2 * (size_t)(d.node_off + l)];

@@ -80,7 +80,7 @@ def test_product_library_carries_no_lab_code():
         assert L.hfem_get_option(knob) == -1
     assert b"lab knobs need libhidenn_hip_lab.so" in L.hfem_last_error()
     # product knobs: defaults that the NEXT plan captures; round-trip and restore
-    for knob, val in ((b"tiled_block", 256), (b"store_policy", 0), (b"plan_elem_order", 4)):
+    for knob, val in ((b"tiled_block", 256), (b"store_policy", 0), (b"plan_elem_order", 3)):
         old = L.hfem_get_option(knob)
         assert L.hfem_set_option(knob, val) == 0 and L.hfem_get_option(knob) == val
         assert L.hfem_set_option(knob, old) == 0

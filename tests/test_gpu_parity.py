@@ -568,3 +568,83 @@ def test_cfg3_structured_256x256_l2_projection_vs_reference_chain():
             # ~1e-16 * sqrt(N) * cancellation ~ 5e-10 of max|g|; 1e-8 is the stated tolerance for these two vectors
             assert_grad_close(m.increments_x.grad, ix.grad.numpy(), "cfg3 g increments_x", rtol=1e-8)
             assert_grad_close(m.increments_y.grad, iy.grad.numpy(), "cfg3 g increments_y", rtol=1e-8)
+
+
+@pytest.mark.parametrize("order", [3, 5])
+def test_golden_tri3_cases_in_both_element_orders(g_tri, order):
+    """The reference's golden TRI3 cases (all gauss orders, body force, traction function, flipped elements, permuted mesh)
+    through BOTH production element orders: 3 = one element per slot (tri3_energy_fast_kernel / generic loop kernel),
+    5 = paired slots (tri3_pair.hip: two fan-adjacent elements per slot, shared-node contributions added in registers).
+    The auto policy picks between them by pairing coverage; parity must not depend on the pick.  Also the fp32-row and
+    physical-convention instances of the pair kernel against the one-element-per-slot path."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = dev()
+    L = _lib.lib()
+    prev = L.hfem_get_option(b"plan_elem_order")
+    _lib.check(L.hfem_set_option(b"plan_elem_order", order))
+    try:
+        for case in g_tri.cases():
+            go, go1 = (int(v) for v in g_tri[case + "/gauss_order"])
+            b, t = tri_case_forces(case)
+            m = tri_model_from_golden(g_tri, case, d)
+            lf = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=go, gauss_order_1d=go1, device=d, dtype=F64)
+            assert m.tile_plan(lf.tile_elems).is_paired() == (order == 5)
+            loss = lf(m, b_force=(lambda x: b(x.cpu()).to(d)) if b else None, t_force=(lambda x: t(x.cpu()).to(d)) if t else None)
+            loss.backward()
+            want = g_tri[case + "/loss"].item()
+            assert abs(loss.item() - want) <= LOSS_RTOL * abs(want), (order, case)
+            assert_grad_close(m.u_free.grad, g_tri[case + "/g_u_free"], f"{case} gu (order {order})")
+            if m.node_coords_free.numel():
+                assert_grad_close(m.node_coords_free.grad, g_tri[case + "/g_coords_free"], f"{case} gx (order {order})")
+    finally:
+        L.hfem_set_option(b"plan_elem_order", prev)
+
+
+def test_pair_kernel_variants_match_the_single_slot_kernels():
+    """fp32 rows, physical convention, fused Adam and the lagged loss sum on a paired plan (a split-quad mesh: 98 % pairs)
+    against the same paths on a one-element-per-slot plan."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import EnergyAdamStep
+    d = dev()
+    L = _lib.lib()
+    prev = L.hfem_get_option(b"plan_elem_order")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 151, jitter=0.25, seed=8, flip_fraction=0.1, dtype=F64)
+    out = {}
+    try:
+        for order in (3, 5):
+            _lib.check(L.hfem_set_option(b"plan_elem_order", order))
+            res = {}
+            for tag, dt, conv in (("f64", F64, None), ("phys", F64, "physical"), ("f32", torch.float32, None)):
+                torch.manual_seed(4)
+                m = PiecewiseLinearShapeNN2D(coords.to(dt), conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.3,
+                                             neumann_edges=edges).to(d)
+                with torch.no_grad():
+                    m.u_free.mul_(50.0)
+                lf = EnergyLoss2D(device=d, dtype=dt, grad_convention=conv)
+                assert m.tile_plan(lf.tile_elems).is_paired() == (order == 5)
+                v = lf.value_and_grad_(m) if conv is None else None
+                if conv is not None:
+                    v = lf(m)
+                    v.backward()
+                res[tag] = (v.item(), m.node_coords_free.grad.double().cpu().numpy(), m.u_free.grad.double().cpu().numpy())
+            torch.manual_seed(4)
+            m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.3, neumann_edges=edges).to(d)
+            tr = EnergyAdamStep(m, EnergyLoss2D(device=d, dtype=F64), lr_x=1e-6, lr_u=1e-8)
+            losses = [tr.step().item() for _ in range(4)]
+            res["adam"] = (losses, m.node_coords_free.detach().cpu().numpy().copy(), m.u_free.detach().cpu().numpy().copy())
+            out[order] = res
+    finally:
+        L.hfem_set_option(b"plan_elem_order", prev)
+    for tag in ("f64", "phys", "f32"):
+        a, b = out[5][tag], out[3][tag]
+        rt = 1e-12 if tag != "f32" else 1e-6
+        assert abs(a[0] - b[0]) <= rt * abs(b[0]), tag
+        assert np.abs(a[1] - b[1]).max() <= (1e-11 if tag != "f32" else 2e-6) * np.abs(b[1]).max(), tag
+        assert np.abs(a[2] - b[2]).max() <= (1e-11 if tag != "f32" else 2e-6) * np.abs(b[2]).max(), tag
+    np.testing.assert_allclose(out[5]["adam"][0], out[3]["adam"][0], rtol=1e-12)
+    assert np.abs(out[5]["adam"][1] - out[3]["adam"][1]).max() <= 1e-12 * np.abs(out[3]["adam"][1]).max()
+    assert np.abs(out[5]["adam"][2] - out[3]["adam"][2]).max() <= 1e-10 * np.abs(out[3]["adam"][2]).max()

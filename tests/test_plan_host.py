@@ -22,6 +22,7 @@ def decode(plan):
 
 
 def check_invariants(conn, edges, nn, plan):
+    """Partition invariants of the owner-computes plan, whatever the element-record format (plan.tile_elements)."""
     a = decode(plan)
     td = a["td"]
     ne = conn.shape[0]
@@ -29,25 +30,20 @@ def check_invariants(conn, edges, nn, plan):
     home_count = np.zeros(ne, dtype=int)
     edge_home = np.zeros(edges.shape[0], dtype=int)
     owner = -np.ones(nn, dtype=int)
+    per_tile = []
     for t, (eo, nel, no, nno, nown, go, ned, _) in enumerate(td):
         assert 0 <= nown <= nno <= 1024
         gids = a["ns"][no:no + nno, 0]                       # identity maps: x_src == global id
         assert len(np.unique(gids)) == nno
         owned_count[gids[:nown]] += 1
         owner[gids[:nown]] = t
-        real = (a["ep"][eo:eo + nel] & SKIP) == 0          # padding records of bank-aware groups
-        assert (a["eg"][eo:eo + nel][~real] == -1).all()
-        pk = a["ep"][eo:eo + nel][real]
-        loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1)
-        if a["hi"] is not None:                              # QUAD4 plans: 4th local node in the second word
-            loc = np.concatenate([loc, (a["hi"][eo:eo + nel][real] & MASK)[:, None]], axis=1)
-        nel = int(real.sum())
+        eg, loc, home = plan.tile_elements(t)
+        per_tile.append(eg)
         assert loc.max(initial=0) < max(nno, 1)
-        eg = a["eg"][eo:eo + a["td"][t][1]][real]
         # the local node ORDER of every element is preserved (reference energy depends on it, F4)
         assert np.array_equal(gids[loc], conn[eg])
-        home_count[eg[(pk & HOME) != 0]] += 1
-        assert len(np.unique(eg)) == nel
+        home_count[eg[home]] += 1
+        assert len(np.unique(eg)) == len(eg)
         gpk = a["gp"][go:go + ned]
         gl = np.stack([gpk & MASK, (gpk >> 10) & MASK], axis=1)
         geid = a["gg"][go:go + ned]
@@ -59,28 +55,25 @@ def check_invariants(conn, edges, nn, plan):
     assert (edge_home == 1).all(), "every edge is counted by exactly one tile"
     # completeness: a tile holds every element / edge that touches one of its owned nodes
     for t, (eo, nel, no, nno, nown, go, ned, _) in enumerate(td):
-        eg = set(a["eg"][eo:eo + nel].tolist()) - {-1}
         need = np.nonzero((owner[conn] == t).any(axis=1))[0]
-        assert set(need.tolist()) <= eg
+        assert set(need.tolist()) <= set(per_tile[t].tolist())
         if edges.shape[0]:
             gneed = np.nonzero((owner[edges] == t).any(axis=1))[0]
             assert set(gneed.tolist()) <= set(a["gg"][go:go + ned].tolist())
+    a["plan"] = plan
     return a
 
 
 def emulate(a, X, U, mat, W, Bk, Tc):
-    """What tri3_energy_tiled_kernel computes, tile by tile, with the oracle as the per-element math."""
+    """What the tiled kernels compute, tile by tile, with the oracle as the per-element math."""
     nn = X.shape[0]
     gX, gU = np.full((nn, 2), np.nan), np.full((nn, 2), np.nan)
     loss = 0.0
-    for (eo, nel, no, nno, nown, go, ned, _) in a["td"]:
+    for t, (eo, nel, no, nno, nown, go, ned, _) in enumerate(a["td"]):
         gids = a["ns"][no:no + nno, 0]
-        pk = a["ep"][eo:eo + nel]
-        pk = pk[(pk & SKIP) == 0]
-        loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1).astype(np.int64)
+        _, loc, home = a["plan"].tile_elements(t)
         Xl, Ul = X[gids], U[gids]
         _, gxl, gul = CF.tri3_energy(Xl, Ul, loc, mat, W, Bk)
-        home = (pk & HOME) != 0
         e_home, _, _ = CF.tri3_energy(Xl, Ul, loc[home], mat, W, Bk, grads=False)
         loss += e_home
         if ned:
@@ -264,12 +257,15 @@ def test_planner_under_address_and_ub_sanitizers(tmp_path):
     c, cn, geom, bc, mn, ed = structured_tri_mesh(81, 61, jitter=0.3, seed=2, diagonal="random", permute=True,
                                                   flip_fraction=0.3, dtype=torch.float64)
     maps = (row_maps((~geom).numpy()), row_maps((~bc).numpy()))
-    for order in (0, 1, 2, 3, 4):
+    for order in (0, 1, 2, 3, 4, 5):
         files.append(write(f"perm_o{order}.bin", cn.numpy(), c.numpy(), ed.numpy(), tile_elems=700, order=order, maps=maps))
     files.append(write("auto_cap.bin", cn.numpy(), c.numpy(), ed.numpy(), tile_elems=1200, node_cap=557, order=4, maps=maps))
     cu, cnu, _, _, _, edu = unstructured_tri_mesh(6000, seed=4, dtype=torch.float64)
     files.append(write("delaunay_retry.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=4096, order=3))
     files.append(write("delaunay_chunked.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=900, order=4))
+    files.append(write("delaunay_paired.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=1200, node_cap=557, order=5))
+    cf, cnf, _, _, _, edf = structured_tri_mesh(121, 81, jitter=0.2, seed=1, dtype=torch.float64)
+    files.append(write("fixed_paired.bin", cnf.numpy(), cf.numpy(), edf.numpy(), tile_elems=1200, node_cap=557, order=5))
     cq, cnq, _, _, _, edq = structured_quad_mesh(41, 37, jitter=0.2, seed=1, dtype=torch.float64)
     files.append(write("quad4.bin", cnq.numpy(), cq.numpy(), edq.numpy(), npe=4, tile_elems=500))
     files.append(write("one_element.bin", [[0, 1, 2]], [[0, 0], [1, 0], [0, 1]], np.zeros((0, 2))))
@@ -280,3 +276,41 @@ def test_planner_under_address_and_ub_sanitizers(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count(": ok ") == len(files), r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_paired_element_order_records_and_auto_policy():
+    """plan_elem_order 5 (csrc/plan.cpp; contract of tri3_pair.hip): a slot holds A = (n, b, c) and, when found, the
+    next element of the fan around n, B = (n, c, d) -- each in ITS OWN local node order.  Invariants and the
+    numpy emulation hold for it on structured, flipped, permuted and Delaunay meshes; the auto policy takes it when
+    >= 90 % of the elements find a partner and the one-element-per-slot order otherwise."""
+    from hidenn_fem_amd.mesh import unstructured_tri_mesh
+    cases = {
+        "fixed": structured_tri_mesh(61, 41, jitter=0.25, seed=2, dtype=torch.float64),
+        "flipped": structured_tri_mesh(40, 37, jitter=0.25, seed=5, flip_fraction=0.5, dtype=torch.float64),
+        "permuted": structured_tri_mesh(33, 21, jitter=0.3, seed=3, diagonal="random", permute=True, dtype=torch.float64),
+        "delaunay": unstructured_tri_mesh(5000, seed=6, dtype=torch.float64),
+    }
+    mat, W, Tc = CF.plane_stress(), 0.25, np.array([2e5, 0.0, 0.0, 0.0])
+    for name, (coords, conn, geom, bc, mn, edges) in cases.items():
+        X, cn, ed = coords.numpy(), conn.numpy(), edges.numpy()
+        plan = TilePlan(cn, X.shape[0], coords_hint=X, edges=ed, tile_elems=300, elem_order=5)
+        assert plan.is_paired()
+        a = check_invariants(cn, ed, X.shape[0], plan)
+        # record format: B shares A's corner 0 and has A's corner 2 as its corner 1
+        w0, w1, ga, gb = plan.export("elem_pack"), plan.export("elem_pack_hi"), plan.export("elem_gid"), plan.export("elem_gid_b")
+        has_b = ((w1 >> 10) & 1).astype(bool) & ((w0 >> 31) == 0)
+        assert (gb[~has_b] == -1).all()
+        assert np.array_equal(cn[ga[has_b], 0], cn[gb[has_b], 0]) and np.array_equal(cn[ga[has_b], 2], cn[gb[has_b], 1])
+        if name == "fixed":
+            assert has_b.sum() * 2 > 0.9 * cn.shape[0]                   # a split-quad mesh pairs (almost) everything
+        U = 1e-4 * np.random.default_rng(1).standard_normal(X.shape)
+        e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, cn, mat, W)
+        e_ref -= CF.edge2_energy(X, U, ed, Tconst=Tc, gX=gX_ref, gU=gU_ref)
+        loss, gX, gU = emulate(a, X, U, mat, W, None, Tc)
+        assert abs(loss - e_ref) <= 1e-12 * abs(e_ref), name
+        assert np.abs(gX - gX_ref).max() <= 1e-10 * np.abs(gX_ref).max() and np.abs(gU - gU_ref).max() <= 1e-10 * np.abs(gU_ref).max()
+        plan.close()
+        auto = TilePlan(cn, X.shape[0], coords_hint=X, edges=ed, tile_elems=300)
+        assert auto.is_paired() == (name == "fixed"), name
+        check_invariants(cn, ed, X.shape[0], auto)
+        auto.close()

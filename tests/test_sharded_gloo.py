@@ -21,7 +21,7 @@ MASK, HOME = 1023, 1 << 30
 def oracle_tile_evaluator(plan, model):
     """(lo, hi, loss_v, gx_v, gu_v) -> fills the views like hfem_tri3_energy_plan does for tiles [lo, hi)."""
     from oracle import closed_form as CF
-    td, ep, ns = plan.export("tile_desc"), plan.export("elem_pack"), plan.export("node_src")
+    td, ns = plan.export("tile_desc"), plan.export("node_src")
     gp = plan.export("edge_pack")
     mat, W = CF.plane_stress(), 0.25
     Tc = np.array([2e5, 0.0, 0.0, 0.0])
@@ -30,15 +30,13 @@ def oracle_tile_evaluator(plan, model):
         xf, uf = model.node_coords_free.detach().numpy(), model.u_free.detach().numpy()
         xfix, ufix = model.node_coords_fixed.numpy(), model.u_fixed_rows().numpy()
         total = 0.0
-        for (eo, nel, no, nno, nown, go, ned, _) in td[lo:hi]:
+        for t, (eo, nel, no, nno, nown, go, ned, _) in enumerate(td[lo:hi], start=lo):
             src = ns[no:no + nno]
             X = np.where((src[:, 0] >= 0)[:, None], xf[np.maximum(src[:, 0], 0)], xfix[np.maximum(~src[:, 0], 0)] if len(xfix) else 0.0)
             U = np.where((src[:, 1] >= 0)[:, None], uf[np.maximum(src[:, 1], 0)], ufix[np.maximum(~src[:, 1], 0)] if len(ufix) else 0.0)
-            pk = ep[eo:eo + nel]
-            pk = pk[(pk >> 31) == 0]                    # padding records carry no element
-            loc = np.stack([pk & MASK, (pk >> 10) & MASK, (pk >> 20) & MASK], axis=1).astype(np.int64)
+            _, loc, home = plan.tile_elements(t)           # whatever the record format (padding dropped, pairs expanded)
             _, gxl, gul = CF.tri3_energy(X, U, loc, mat, W)
-            total += CF.tri3_energy(X, U, loc[(pk & HOME) != 0], mat, W, grads=False)[0]
+            total += CF.tri3_energy(X, U, loc[home], mat, W, grads=False)[0]
             if ned:
                 q = gp[go:go + ned]
                 gl = np.stack([q & MASK, (q >> 10) & MASK], axis=1).astype(np.int64)

@@ -20,8 +20,9 @@ owned rows inside, so the exchanged rows change every step) and `config.alt_exch
 a dense sum all-reduce of the packed [gX|gU|loss] buffer.
 
 One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel
-(tri3_energy_fast_kernel): algorithmic bytes (12 Ne + 64 Nn + 8) over its
-average back-to-back launch time measured with HIP events on the launch stream.
+(tri3_energy_pair_kernel on the paired tile plan a split-quad mesh gets; tri3_energy_fast_kernel otherwise): algorithmic
+bytes (12 Ne + 64 Nn + 8) over its average back-to-back launch time measured with HIP events on the
+launch stream.
 ``cpu_baseline`` times the oracle's op-for-op PyTorch restatement of the reference chain on the
 host cores, on the same workload (bounded number of evaluations).
 """
@@ -408,7 +409,7 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="tri3_energy_fast_kernel", kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
+                    traffic=traffic, kernel="tri3_energy_pair_kernel" if plan.is_paired() else "tri3_energy_fast_kernel", kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
                     alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
     for name, r in regimes.items():
         r["achieved"] = alg_bytes / (r["kernel_us"] * 1e-6) / 1e9
@@ -502,7 +503,8 @@ def main():
                                  f"(structured quads split in 2), {nn} nodes, gauss_order=4, r-adaptivity on, "
                                  f"Neumann edges {edges.shape[0]}, fwd+bwd (loss + dX + dU)",
                         elements=ne, nodes=nn, elements_per_gpu=ne // world, tiles=st["n_tiles"],
-                        tile_elems=st["tile_elems"], halo_elem_factor=st["tile_elem_total"] / max(ne, 1),
+                        tile_elems=st["tile_elems"], element_order="paired slots" if plan.is_paired() else "one element per slot",
+                        halo_elem_factor=sum(len(plan.tile_elements(t)[0]) for t in range(st["n_tiles"])) / max(ne, 1),
                         lds_bytes=st["lds_bytes"], launch="hipgraph" if graph is not None else "eager",
                         loss_sum=("by an extra workgroup of the next launch (HFEM_FLAG_SUM_PREVIOUS) + one trailing "
                                   "1-block launch" if lagged else "1-block launch after every energy kernel"),

@@ -23,7 +23,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
     python3 - "$OUT/pmc_${c}_$r/p_counter_collection.csv" "$c" "$r" >> "$OUT/pmc_summary.txt" <<'PY'
 import csv, sys
 vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1]))
-        if "tri3_energy_fast_kernel" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]]
+        if "tri3_energy_" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]]
 print(sys.argv[2], sys.argv[3], "launches", len(vals), "mean", sum(vals) / max(len(vals), 1))
 PY
     rm -rf "$OUT/pmc_${c}_$r"

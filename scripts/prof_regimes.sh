@@ -14,7 +14,7 @@ for r in replayed rewritten_inputs rotating_sets; do
   rm -rf "$OUT/$r"
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o p -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-regimes > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench.log"
+    python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-regimes --no-extra > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench.log"
 cp "$OUT/bench/p_kernel_stats.csv" "$OUT/kernel_stats_bench_py.csv"; rm -rf "$OUT/bench"
 for c in FETCH_SIZE WRITE_SIZE; do
   for r in replayed rotating_sets; do

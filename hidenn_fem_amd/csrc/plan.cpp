@@ -6,8 +6,9 @@
 // /root/reference/src/models.py:292-305.  Output is the tile plan the fused
 // energy kernel walks (layout: hfem_common.h, DESIGN.md "Data layout").
 //
-//  1. elements are sorted along a Morton curve of their centroids and cut into
-//     tiles of `tile_elems` consecutive elements (the tile's HOME elements);
+//  1. elements are sorted along a Hilbert curve of their centroids (Morton: plan_curve 0) and cut
+//     into tiles of consecutive elements (the tile's HOME elements), sized by element count or by
+//     an owned-node cap;
 //  2. a node is OWNED by the lowest-numbered tile among its adjacent elements'
 //     home tiles (nodes without elements go to extra element-less tiles);
 //  3. a tile evaluates home elements + HALO elements (other tiles' elements that
@@ -16,8 +17,12 @@
 //  4. a Neumann edge is evaluated by the owner tiles of its two nodes; its work
 //     is counted by the owner of its first node.
 //
+//  5. inside a tile the element records are laid out for the kernel that walks them: bank-aware
+//     16-lane groups (order 3), or PAIRED slots (order 5): A = (n,b,c) + B = (n,c,d), two elements
+//     that share the directed edge (first node, last node of A) = (first, second node of B).
+//
 // The local order of an element's three nodes is never changed (the reference
-// energy depends on it).
+// energy depends on it): pairing only chooses WHICH elements share a slot.
 #include <algorithm>
 #include <array>
 #include <unordered_map>

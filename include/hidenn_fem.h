@@ -64,11 +64,18 @@ int hfem_edge2_energy_atomic(int device, const double *X, const double *U,
                              double *gU, void *stream);
 
 /* Planned variant -- the fast path.  A plan is an owner-computes tiling of the
- * mesh (host-side preprocessing, once per mesh): elements are Morton-sorted and
- * cut into tiles; every node is owned by exactly one tile; a tile evaluates its
- * home elements plus the halo elements that touch its owned nodes, with node
- * data staged in LDS and gradients accumulated in LDS, so each gradient row is
- * written exactly once with a plain store (no global atomics, no zero fill).
+ * mesh (host-side preprocessing, once per mesh): elements are sorted along a
+ * Hilbert curve of their centroids and cut into tiles; every node is owned by
+ * exactly one tile; a tile evaluates its home elements plus the halo elements
+ * that touch its owned nodes, with node data staged in LDS and gradients
+ * accumulated in LDS, so each gradient row is written exactly once with a plain
+ * store (no global atomics, no zero fill).  TRI3 plans whose elements pair up
+ * along shared fan edges (>= 90 % of them: structured splits, Delaunay meshes)
+ * store two elements per slot, A = (n,b,c) and B = (n,c,d), each in its own
+ * local node order, and run the paired-slot kernel (16 instead of 24 LDS
+ * atomics per pair); other meshes keep one element per slot.  The choice is
+ * made at plan creation ("plan_elem_order" -1 = auto) and is invisible in the
+ * results up to fp64 summation order.
  *
  * It also fuses the free/fixed parameter assembly of src/models.py:292-305:
  *   x_src[n] >= 0 -> coords of node n = x_free[x_src[n]]   (node_coords_free row)
@@ -102,8 +109,10 @@ int hfem_plan_destroy(hfem_plan *plan);
 int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
 /* Copy a host-side plan array out (for tests).  which: 0 tile_desc [n_tiles][8]
  * i32, 1 elem_pack u32, 2 node_src [.][2] i32, 3 edge_pack u32, 4 edge_gid i32,
- * 5 elem_gid i32 (global element id of every tile element; -1 = padding), 6 lab stamps,
- * 7 elem_pack_hi u32 (QUAD4 plans: 4th local node of every slot).
+ * 5 elem_gid i32 (global element id of every slot's element A; -1 = padding), 6 lab stamps
+ * (lab build only), 7 elem_pack_hi u32 (QUAD4 plans: 4th local node of every slot; paired TRI3
+ * plans: node d + presence/home bits of element B), 8 tile_chunks (chunked lab order), 9 elem_gid_b
+ * i32 (paired plans: global id of every slot's element B; -1 = none).
  * Returns the element count, or <0.  buf may be NULL to query the size.       */
 int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t cap_elems);
 
@@ -166,8 +175,13 @@ int hfem_adam_prep(int device, int64_t *step_dev, double beta1, double beta2, do
  * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
 int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, double *loss_out, void *stream);
 
-/* Process-wide tuning knobs of the tiled kernel: "tiled_block" (threads per tile: 256, 512,
- * 1024) and "tiled_ablate" (lab-only ablation bits, 0 in production; see tri3_energy.hip).
+/* Process-wide DEFAULTS (atomics) that hfem_plan_create captures into the plan it builds; changing one
+ * never affects an existing plan, and launches on different plans may run from different threads (a plan
+ * serialises its own launches with a mutex).  Product knobs: "tiled_block" (threads per tile of the
+ * one-element-per-slot kernels: 256, 512, 1024), "store_policy", "tiled_fast", "fast_const_caps",
+ * "quad4_const_caps", "plan_elem_order" (-1 auto, 3 one element per slot, 5 paired slots), "plan_node_cap",
+ * "plan_chunk_cap", "plan_curve" (0 Morton, 1 Hilbert).  The ablation / stamp / pipeline knobs exist only in
+ * the lab build (libhidenn_hip_lab.so, hfem_get_option("lab_build") == 1); the product library rejects them.
  * hfem_get_option returns the value or -1.                                     */
 int hfem_set_option(const char *name, int value);
 int hfem_get_option(const char *name);

@@ -28,6 +28,8 @@ constexpr int kMaxLocal = 1 << kLocalBits;
 constexpr uint32_t kLocalMask = kMaxLocal - 1;
 constexpr uint32_t kHomeBit = 1u << 30;   // element/edge energy is counted by this tile
 constexpr uint32_t kSkipBit = 1u << 31;   // padding record: the lane has no element
+constexpr int32_t kNodeTailPad = 1024;    // records after the last tile's stride (unguarded loads of up to 4 x 256 lanes)
+constexpr int32_t kElemTailPad = 1536;    // slot records after the last tile's stride (6 x 256 lanes)
 constexpr int32_t kMaxQuadSlots = 1024;   // element slots per tile the tiled QUAD4 kernel can hold in registers
 
 // tile_desc[t] = 8 x int32
@@ -36,7 +38,7 @@ struct TileDesc {
     int32_t node_off, n_node;     // into node_src; owned nodes first
     int32_t n_owned;
     int32_t edge_off, n_edge;     // into edge_pack / edge_gid
-    int32_t pad;
+    int32_t pad;                  // paired plans: column stride of the tile's slot array (slot j of thread t at j*stride + t)
 };
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 8 x int32");
 
@@ -48,7 +50,12 @@ struct HostPlan {
     std::vector<uint32_t> elem_pack;   // l0 | l1<<10 | l2<<20 | home<<30 | skip<<31
     std::vector<uint32_t> elem_pack_hi;  // QUAD4 only: l3 of the same slot
     std::vector<int32_t> elem_gid;     // global element id (tests / debugging)
-    std::vector<int32_t> node_src;     // [.][2] = {x_src, u_src} of each local node
+    std::vector<int32_t> node_src;     // [.][2] = {x_src, u_src} of each local node; tile t's records start at t * node_stride,
+                                       // padded to the stride with its last record, kNodeTailPad more after the last tile
+    int32_t node_stride = 0, elem_stride = 0;   // elem_pack / elem_pack_hi / elem_gid(_b): tile t's slots start at t * elem_stride (skip-padded)
+    int64_t elem_records = 0;          // real slots (padding not counted)
+    int32_t col_stride = 0;            // paired plans: columns of every tile's slot array (= tile_desc.pad of every tile)
+    int64_t node_records = 0;          // sum of n_node (the padding not counted)
     std::vector<uint32_t> edge_pack;   // li | lj<<10 | home<<30
     std::vector<int32_t> edge_gid;     // global edge id (row of the traction table)
     int32_t max_nodes = 0, max_owned = 0, max_elems = 0, max_edges = 0;
@@ -66,8 +73,12 @@ struct HostPlan {
     //   elem_pack_hi[s] = l_d | hasB<<10 | homeB<<11
     // elem_gid[s] = A's element id, elem_gid_b[s] = B's (or -1).  Elements without a partner are slots with hasB = 0.
     std::vector<int32_t> elem_gid_b;
+    // Strip order (elem_order 6): as 5, plus CHAINED slots: bit 12 of elem_pack_hi[s] says that the slot one column-stride
+    // further (same thread, next row; tile_desc.pad = stride) holds the pair with n' = b and d' = c; the thread carries this
+    // slot's rows of b and c in registers into that slot's rows of n and d instead of adding them to LDS.
     bool paired = false;
-    int64_t n_pairs = 0;
+    int64_t n_pairs = 0, n_chained = 0;
+    int32_t max_rows = 0;              // paired plans: slots per thread (rows of the widest tile's slot array)
     // compact copies of the inputs (the deterministic node-centric kernel walks the mesh itself, tri3_det.hip)
     std::vector<int32_t> conn32, x_src_g, u_src_g, edges32;
     int32_t max_chunk_elems = 0;       // longest strip (slots); 0 = not chunked

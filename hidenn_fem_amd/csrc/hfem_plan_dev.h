@@ -16,6 +16,8 @@ struct PlanDev {
     const int32_t *edge_gid;
     const uint32_t *elem_pack_hi;   // QUAD4 plans only: 4th local node id of every slot
     const int4 *tile_chunks;        // chunked plans only (HostPlan::tile_chunks)
+    int node_stride;                // tile t's node_src records start at t * node_stride (HostPlan::node_stride)
+    int elem_stride;                // tile t's slot records start at t * elem_stride
 };
 
 struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
@@ -83,7 +85,7 @@ struct hfem_plan {
 
 namespace hfem {
 inline PlanDev plan_dev(const hfem_plan *p) {
-    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi, p->d_tile_chunks};
+    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi, p->d_tile_chunks, p->host.node_stride, p->host.elem_stride};
 }
 inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6]) {
     Tri3Consts k;
@@ -108,6 +110,9 @@ struct PairLaunch {
     double *partials = nullptr;
     void *gx = nullptr, *gu = nullptr;
     int max_nodes = 0, max_owned = 0, skip_edges = 0;
+    int chain = -1;               // -1: by the plan (chained records -> carrying slot loop); lab: 0 / 1 forces
+    int lab_bits = 0;             // lab build: ablation bits (tri3_pair.hip)
+    int col_stride = 256;         // columns of every tile's slot array (HostPlan::col_stride)
     size_t lds = 0;
     hipStream_t s = nullptr;
 };

@@ -229,6 +229,63 @@ void pack_slot_groups(const std::vector<std::array<int32_t, 4>> &items, int32_t 
     for (size_t j = 0; j < open.size(); ++j) out.insert(out.end(), open[j].el.begin(), open[j].el.end());
 }
 
+// Same packing for COLUMNS of the strip order (elem_order 6): a column is what one thread walks, up to kMaxRows slots
+// with up to four flushed local ids each (-1: no atomic at that row / position).  A 16-lane group is conflict-free iff,
+// for every (row, position), the flushed owned ids are distinct mod 16.  Items are taken in the given order (the caller
+// sorts them by shape, so waves stay uniform in their chain pattern); returns the column order, -1 = empty column.
+constexpr int kMaxRows = 6;
+void pack_column_groups(const std::vector<std::array<int32_t, 4 * kMaxRows>> &cols, int32_t n_owned, std::vector<int32_t> &out) {
+    // No padding: exactly ceil(n / 16) groups, all open from the start; a column goes to the EARLIEST group where it adds
+    // the fewest bank clashes (zero when possible).  With the caller's order (shape, then first node id: columns that
+    // start on consecutive nodes follow one another and have consecutive local ids at every row / position) runs of 16
+    // columns stacked along the node numbering are conflict-free in all their instructions at once.
+    constexpr int G = 16, M = 4 * kMaxRows;
+    const int n = (int)cols.size();
+    const int ng = (n + G - 1) / G;
+    struct Grp { std::vector<int32_t> el; uint16_t used[M]; };
+    std::vector<Grp> grp(ng);
+    for (auto &g : grp) std::fill(g.used, g.used + M, (uint16_t)0);
+    int first_open = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        uint16_t bit[M];
+        for (int k = 0; k < M; ++k) {
+            const int32_t l = cols[i][k];
+            bit[k] = (l >= 0 && l < n_owned) ? (uint16_t)(1u << (l & 15)) : 0;
+        }
+        int best = -1, best_cost = 1 << 30;
+        for (int j = first_open; j < ng && best_cost > 0; ++j) {
+            if ((int)grp[j].el.size() >= G) continue;
+            int cost = 0;
+            for (int k = 0; k < M; ++k) cost += (grp[j].used[k] & bit[k]) != 0;
+            if (cost < best_cost) { best_cost = cost; best = j; }
+        }
+        Grp &g = grp[best];
+        g.el.push_back(i);
+        for (int k = 0; k < M; ++k) g.used[k] |= bit[k];
+        while (first_open < ng && (int)grp[first_open].el.size() >= G) ++first_open;
+    }
+    // only the last group may be short: move the tail of the last full-enough groups forward
+    for (int j = 0; j < ng; ++j) out.insert(out.end(), grp[j].el.begin(), grp[j].el.end());
+    // groups are emitted in order; a short group in the middle would shift the 16-lane alignment of the following ones,
+    // so short groups are topped up from the very end of the list
+    {
+        std::vector<int32_t> res;
+        res.reserve(out.size());
+        std::vector<std::vector<int32_t>> gs(ng);
+        for (int j = 0; j < ng; ++j) gs[j] = grp[j].el;
+        int hi = ng - 1;
+        for (int j = 0; j < ng; ++j) {
+            while ((int)gs[j].size() < G && hi > j) {
+                if (gs[hi].empty()) { --hi; continue; }
+                gs[j].push_back(gs[hi].back());
+                gs[hi].pop_back();
+            }
+        }
+        for (int j = 0; j < ng; ++j) res.insert(res.end(), gs[j].begin(), gs[j].end());
+        out.swap(res);
+    }
+}
+
 // Order the elements of one tile so that the 64 lanes of a wave-instruction (64 consecutive
 // positions) do not add into the same LDS accumulator: same-address ds_add_f64 lanes serialise.
 //   mode 0: keep Morton order (neighbouring lanes share nodes: worst for atomics)
@@ -509,7 +566,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             chunk_rec[2] = po0 | (po1 << 8) | (ph0 << 16) | (ph1 << 24);
         } else {
             for (int32_t n : halo) lid[n] = nloc++;
-            if (!(elem_order == 5 && npe == 3)) order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
+            if (!(elem_order >= 5 && npe == 3)) order_tile_elements(telems, conn, npe, lid, d.n_owned, elem_order);
         }
         nloc = d.n_owned + (int32_t)halo.size();
         if (elem_order == 4) P.tile_chunks.insert(P.tile_chunks.end(), chunk_rec, chunk_rec + 4);
@@ -519,7 +576,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
         d.n_node = nloc;
         d.edge_off = (int32_t)P.edge_pack.size();
         d.n_edge = (int32_t)(edg_ptr[t + 1] - edg_ptr[t]);
-        if (elem_order == 5 && npe == 3) {
+        if (elem_order >= 5 && npe == 3) {
             // ---- paired slots.  B is the successor of A when A's corner 0 is B's corner 0 and A's corner 2 is B's corner 1
             //      (the next element of the fan around n).  succ/pred are partial injective maps, so the candidate graph is
             //      a set of paths and cycles; consecutive elements are paired greedily along each.
@@ -559,9 +616,104 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
                              slots[s_][1] >= 0 ? lid[conn[3 * (int64_t)telems[slots[s_][1]] + 2]] : -1};
             }
             std::vector<int32_t> order_s;
-            // pack pairs and singles separately so the pairs stay in front
+            std::vector<char> chain(slots.size(), 0);           // slot's b, c rows are carried into the next slot of its column
             size_t n_pair = 0;
             while (n_pair < slots.size() && slots[n_pair][1] >= 0) ++n_pair;
+            d.pad = 256;                                        // column stride of the slot array (slot j of thread t at j*stride + t)
+            if (elem_order == 6) {
+                // ---- strips: pair Q follows pair P in a strip when Q.n = P.b and Q.d = P.c (the next split quad along a
+                //      row): the thread that walks the strip keeps P's rows of b and c in registers and adds them to Q's
+                //      rows of n and d -- a strip of L pairs flushes 2L + 2 node rows instead of 4L.  Strips are cut to at
+                //      most H slots (the rows of a column) and bin-packed into <= 256 columns.
+                const int S = (int)slots.size();
+                const int H = std::min(kMaxRows, std::max(1, (S + 255) / 256));   // rows per column: as few as 256 threads allow
+                if (S > 256 * kMaxRows) return 1;
+                auto gnode = [&](int si, int k) -> int64_t {    // global node id of slot position k (n, b, c, d)
+                    return k < 3 ? conn[3 * (int64_t)telems[slots[si][0]] + k] : conn[3 * (int64_t)telems[slots[si][1]] + 2];
+                };
+                std::unordered_map<uint64_t, int32_t> by_nd;
+                by_nd.reserve(n_pair * 2);
+                for (size_t si = 0; si < n_pair; ++si) by_nd[((uint64_t)gnode((int)si, 0) << 32) | (uint32_t)gnode((int)si, 3)] = (int32_t)si;
+                std::vector<int32_t> nxt(n_pair, -1), prv(n_pair, -1);
+                for (size_t si = 0; si < n_pair; ++si) {
+                    auto it = by_nd.find(((uint64_t)gnode((int)si, 1) << 32) | (uint32_t)gnode((int)si, 2));
+                    if (it != by_nd.end() && it->second != (int32_t)si && prv[it->second] < 0) { nxt[si] = it->second; prv[it->second] = (int32_t)si; }
+                }
+                std::vector<std::vector<int32_t>> strips, columns;
+                {
+                    const int L = H;
+                    strips.clear();
+                    std::vector<char> seen(n_pair, 0);
+                    for (int pass = 0; pass < 2; ++pass)
+                        for (size_t si = 0; si < n_pair; ++si) {
+                            if (seen[si] || (pass == 0 && prv[si] >= 0)) continue;
+                            int32_t a = (int32_t)si;
+                            while (a >= 0 && !seen[a]) {
+                                strips.emplace_back();
+                                while (a >= 0 && !seen[a] && (int)strips.back().size() < L) { seen[a] = 1; strips.back().push_back(a); a = nxt[a]; }
+                            }
+                        }
+                    std::stable_sort(strips.begin(), strips.end(), [](const std::vector<int32_t> &x, const std::vector<int32_t> &y) { return x.size() > y.size(); });
+                    for (size_t si = n_pair; si < slots.size(); ++si) strips.push_back({(int32_t)si});   // singles last
+                    // best-fit decreasing into exactly ceil(S / H) columns of H rows (fewest wave-rows); a strip that fits no
+                    // single column is cut where the roomiest column ends (the cut slot just flushes its b and c)
+                    const int ncol = (S + H - 1) / H;
+                    columns.assign(ncol, {});
+                    std::vector<std::vector<int32_t>> with_room(H + 1);      // column indices by free rows
+                    for (int ci = ncol - 1; ci >= 0; --ci) with_room[H].push_back(ci);
+                    for (size_t k = 0; k < strips.size(); ++k) {
+                        std::vector<int32_t> st = strips[k];
+                        while (!st.empty()) {
+                            const int len = (int)st.size();
+                            int r = len;
+                            while (r <= H && with_room[r].empty()) ++r;
+                            int take = len;
+                            if (r > H) {                                     // no column holds it whole: fill the roomiest
+                                r = len - 1;
+                                while (r > 0 && with_room[r].empty()) --r;
+                                take = r;
+                            }
+                            if (r <= 0) return -1;                           // cannot happen: ncol * H >= S
+                            const int32_t ci = with_room[r].back();
+                            with_room[r].pop_back();
+                            columns[ci].insert(columns[ci].end(), st.begin(), st.begin() + take);
+                            for (int q = 0; q + 1 < take; ++q) chain[st[q]] = 1;
+                            if (r - take > 0) with_room[r - take].push_back(ci);
+                            st.erase(st.begin(), st.begin() + take);
+                        }
+                    }
+                    while (!columns.empty() && columns.back().empty()) columns.pop_back();
+                }
+                if (columns.size() > 256) return 1;
+                // shape order (chain pattern as a number, long strips first), then bank-aware groups of 16 columns
+                auto shape = [&](const std::vector<int32_t> &c) { uint32_t v = 0; for (int32_t si : c) v = v * 4 + (chain[si] ? 3u : (slots[si][1] >= 0 ? 2u : 1u)); for (size_t q = c.size(); q < (size_t)kMaxRows; ++q) v *= 4; return v; };
+                std::stable_sort(columns.begin(), columns.end(), [&](const std::vector<int32_t> &x, const std::vector<int32_t> &y) {
+                    const uint32_t sx = shape(x), sy = shape(y);
+                    return sx != sy ? sx > sy : gnode(x[0], 0) < gnode(y[0], 0);
+                });
+                std::vector<std::array<int32_t, 4 * kMaxRows>> citems(columns.size());
+                int rows_used = 0;
+                for (size_t ci = 0; ci < columns.size(); ++ci) {
+                    citems[ci].fill(-1);
+                    rows_used = std::max(rows_used, (int)columns[ci].size());
+                    for (size_t r = 0; r < columns[ci].size(); ++r) {
+                        const int32_t si = columns[ci][r];
+                        citems[ci][4 * r + 0] = items[si][0];
+                        citems[ci][4 * r + 3] = items[si][3];
+                        if (!chain[si]) { citems[ci][4 * r + 1] = items[si][1]; citems[ci][4 * r + 2] = items[si][2]; }
+                    }
+                }
+                std::vector<int32_t> corder;
+                pack_column_groups(citems, d.n_owned, corder);
+                const int stride = (int)((corder.size() + 15) / 16 * 16);
+                d.pad = stride;
+                order_s.assign((size_t)rows_used * stride, -1);
+                for (size_t t_ = 0; t_ < corder.size(); ++t_)
+                    for (size_t r = 0; r < columns[corder[t_]].size(); ++r) order_s[r * stride + t_] = columns[corder[t_]][r];
+                while (!order_s.empty() && order_s.back() < 0) order_s.pop_back();
+                P.max_rows = std::max(P.max_rows, rows_used);
+            } else {
+            // pack pairs and singles separately so the pairs stay in front
             {
                 std::vector<std::array<int32_t, 4>> part(items.begin(), items.begin() + n_pair);
                 std::vector<int32_t> o;
@@ -572,6 +724,8 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
                 o.clear();
                 pack_slot_groups(part, d.n_owned, o);
                 for (int32_t v : o) order_s.push_back(v < 0 ? -1 : v + (int32_t)n_pair);
+            }
+            P.max_rows = std::max(P.max_rows, ((int)order_s.size() + 255) / 256);
             }
             d.n_elem = (int32_t)order_s.size();
             for (int32_t si : order_s) {
@@ -586,10 +740,11 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
                 const std::array<int32_t, 4> &L = items[si];
                 P.elem_pack.push_back((uint32_t)L[0] | ((uint32_t)L[1] << kLocalBits) | ((uint32_t)L[2] << (2 * kLocalBits)) |
                                       (home[ea] == t ? kHomeBit : 0u));
-                P.elem_pack_hi.push_back(eb >= 0 ? ((uint32_t)L[3] | (1u << 10) | (home[eb] == t ? (1u << 11) : 0u)) : 0u);
+                P.elem_pack_hi.push_back(eb >= 0 ? ((uint32_t)L[3] | (1u << 10) | (home[eb] == t ? (1u << 11) : 0u) | (chain[si] ? (1u << 12) : 0u)) : 0u);
                 P.elem_gid.push_back(ea);
                 P.elem_gid_b.push_back(eb);
                 P.n_pairs += eb >= 0;
+                P.n_chained += chain[si];
             }
             P.paired = true;
         } else {
@@ -627,6 +782,77 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
         P.max_elems = std::max(P.max_elems, d.n_elem);
         P.max_edges = std::max(P.max_edges, d.n_edge);
     }
+    // ---- uniform node stride: tile t's row-map records start at t * node_stride, so a kernel can load them from its
+    //      tile index alone, in parallel with the descriptor (one dependent memory round trip less: desc -> maps -> rows
+    //      becomes {desc, maps} -> rows).  Padding repeats the tile's last record (a valid row pair: loads through it are
+    //      harmless); kNodeTailPad more records follow the last tile so that lanes past a tile's stride stay inside the array.
+    {
+        const int32_t stride = (P.max_nodes + 15) / 16 * 16;
+        if ((int64_t)nt * stride + kNodeTailPad > (int64_t)std::numeric_limits<int32_t>::max()) {
+            set_error("plan: tile arrays exceed int32 offsets");
+            return -1;
+        }
+        std::vector<int32_t> ns((size_t)2 * ((size_t)nt * stride + kNodeTailPad));
+        int32_t lastx = 0, lastu = 0;                       // running "last valid record" (tiles without nodes repeat it)
+        for (int32_t t = 0; t < nt; ++t) {
+            TileDesc &d = P.tiles[t];
+            const int32_t *srcp = P.node_src.data() + 2 * (size_t)d.node_off;
+            int32_t *dst = ns.data() + 2 * (size_t)t * stride;
+            std::memcpy(dst, srcp, sizeof(int32_t) * 2 * (size_t)d.n_node);
+            if (d.n_node > 0) { lastx = srcp[2 * (d.n_node - 1)]; lastu = srcp[2 * (d.n_node - 1) + 1]; }
+            else if (t == 0 && nt > 1 && P.tiles[1].n_node > 0) { lastx = P.node_src[2 * (size_t)P.tiles[1].node_off]; lastu = P.node_src[2 * (size_t)P.tiles[1].node_off + 1]; }
+            for (int32_t l = d.n_node; l < stride; ++l) { dst[2 * l] = lastx; dst[2 * l + 1] = lastu; }
+            d.node_off = t * stride;
+        }
+        for (size_t l = (size_t)nt * stride; l < (size_t)nt * stride + kNodeTailPad; ++l) { ns[2 * l] = lastx; ns[2 * l + 1] = lastu; }
+        P.node_records = (int64_t)P.node_src.size() / 2;
+        P.node_src.swap(ns);
+        P.node_stride = stride;
+    }
+    // ---- uniform slot stride, same reason: tile t's element records start at t * elem_stride; padding = skip records,
+    //      kElemTailPad more after the last tile (unguarded loads of up to 6 x 256 lanes from a tile's start)
+    {
+        // paired plans: one column stride for the whole plan (the widest tile's), so that a thread's row-j record sits at
+        // j * col_stride + t whatever the tile
+        int32_t cs = 0;
+        if (P.paired) {
+            for (int32_t t = 0; t < nt; ++t) cs = std::max(cs, P.tiles[t].pad);
+            P.max_elems = 0;
+            for (int32_t t = 0; t < nt; ++t) {
+                const TileDesc &d = P.tiles[t];
+                const int32_t ne_new = d.n_elem > 0 ? ((d.n_elem - 1) / d.pad) * cs + (d.n_elem - 1) % d.pad + 1 : 0;
+                P.max_elems = std::max(P.max_elems, ne_new);
+            }
+            P.col_stride = cs;
+        }
+        const int64_t stride = (P.max_elems + 15) / 16 * 16;
+        const size_t total = (size_t)nt * stride + kElemTailPad;
+        if (total > (size_t)std::numeric_limits<int32_t>::max()) { set_error("plan: tile arrays exceed int32 offsets"); return -1; }
+        const bool hi = !P.elem_pack_hi.empty(), gb = !P.elem_gid_b.empty();
+        std::vector<uint32_t> ep(total, kSkipBit), eh(hi ? total : 0, 0u);
+        std::vector<int32_t> eg(total, -1), egb(gb ? total : 0, -1);
+        int64_t real = 0;
+        for (int32_t t = 0; t < nt; ++t) {
+            TileDesc &d = P.tiles[t];
+            const size_t so = (size_t)d.elem_off, dn = (size_t)t * stride, n = (size_t)d.n_elem;
+            int32_t n_new = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const size_t k = cs > 0 ? (i / d.pad) * cs + i % d.pad : i;      // row-major re-stride
+                ep[dn + k] = P.elem_pack[so + i];
+                eg[dn + k] = P.elem_gid[so + i];
+                if (hi) eh[dn + k] = P.elem_pack_hi[so + i];
+                if (gb) egb[dn + k] = P.elem_gid_b[so + i];
+                n_new = (int32_t)k + 1;
+            }
+            real += d.n_elem;
+            d.elem_off = (int32_t)dn;
+            d.n_elem = n_new;
+            if (cs > 0) d.pad = cs;
+        }
+        P.elem_pack.swap(ep); P.elem_gid.swap(eg); P.elem_pack_hi.swap(eh); P.elem_gid_b.swap(egb);
+        P.elem_stride = (int32_t)stride;
+        P.elem_records = real;
+    }
     if (P.elem_pack.size() > (size_t)std::numeric_limits<int32_t>::max() ||
         P.node_src.size() / 2 > (size_t)std::numeric_limits<int32_t>::max()) {
         set_error("plan: tile arrays exceed int32 offsets");
@@ -662,7 +888,7 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
         const int rc = try_build(conn, npe, ne, nn, coords, x_src, u_src, edges, ned, T, node_cap, order, elem_order, chunk_cap, out);
         if (rc == 0 && npe == 4 && out.max_elems > kMaxQuadSlots) continue;   // QUAD4 kernel: <= 4 slots x 256 threads
-        if (rc == 0 && out.paired && out.max_elems > 6 * 256) continue;      // pair kernel: <= 6 slots x 256 threads
+        if (rc == 0 && out.paired && out.max_rows > kMaxRows) continue;      // pair kernel: <= 6 slots per thread
         if (rc == 0) {
             out.conn32.assign(conn, conn + npe * ne);
             out.edges32.assign(edges, edges + 2 * ned);

@@ -711,6 +711,7 @@ int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
 int g_tiled_pipe = 0;      // k > 0: persistent pipelined kernel, k workgroups per CU
 int g_tri3_stream = 0;     // chunked plans take the streamed kernel (tri3_stream.hip)
 int g_stream_ablate = 0;
+int g_pair_chain = -1, g_pair_ablate = 0;   // pair kernel: force the slot loop (0 plain, 1 carrying), ablation bits
 #endif
 
 hfem_plan::Tune current_tune() {
@@ -985,8 +986,8 @@ extern "C" int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out) 
     out->n_elems = h.ne; out->n_nodes = h.nn; out->n_edges = h.ned;
     out->n_tiles = (int32_t)h.tiles.size();
     out->tile_elems = h.tile_elems;
-    out->tile_elem_total = (int64_t)h.elem_pack.size();
-    out->tile_node_total = (int64_t)h.node_src.size() / 2;
+    out->tile_elem_total = h.elem_records;
+    out->tile_node_total = h.node_records;
     out->max_tile_nodes = h.max_nodes; out->max_tile_owned = h.max_owned;
     out->max_tile_elems = h.max_elems; out->max_tile_edges = h.max_edges;
     out->device_bytes = plan->device_bytes;
@@ -1104,6 +1105,9 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
             P.k = A.k; P.T_edge = A.T_edge; P.tc = tc; P.partials = A.partials; P.gx = A.gx; P.gu = A.gu;
             P.skip_edges = A.skip_edges; P.s = s;
+#ifdef HFEM_LAB
+            P.chain = g_pair_chain; P.lab_bits = g_pair_ablate;
+#endif
             HFEM_ARG_CHECK(!(lag.prev && (hasb || phys)), "HFEM_FLAG_SUM_PREVIOUS: default forces and convention only");
             const int rc_pair = launch_tri3_pair(plan, P, (hasb || phys) ? 1 : 0, hasb, phys, lag, AdamFuse{});
             HFEM_ARG_CHECK(rc_pair == 1, "paired plan: tile shape outside the pair kernel's instances");
@@ -1305,7 +1309,7 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "quad4_const_caps") {
         g_quad4_const_caps = value ? 1 : 0;
     } else if (n == "plan_elem_order") {
-        HFEM_ARG_CHECK(value >= -1 && value <= 5, "plan_elem_order must be -1 (auto) or 0..5");
+        HFEM_ARG_CHECK(value >= -1 && value <= 6, "plan_elem_order must be -1 (auto) or 0..6");
         g_def.plan_elem_order = value;
     } else if (n == "plan_node_cap") {
         HFEM_ARG_CHECK(value >= -1 && value <= 1024, "plan_node_cap must be -1 (auto), 0 (off) or 1..1024");
@@ -1340,6 +1344,10 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_tri3_stream = value ? 1 : 0;
     } else if (n == "stream_ablate") {
         g_stream_ablate = value;
+    } else if (n == "pair_chain") {
+        g_pair_chain = value;
+    } else if (n == "pair_ablate") {
+        g_pair_ablate = value;
     } else if (n == "quad4_stagger") {
         HFEM_ARG_CHECK(value >= -1 && value <= 100000, "quad4_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
         g_quad4_stagger = value;
@@ -1389,6 +1397,8 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "tiled_pipe") return g_tiled_pipe;
     if (n == "tri3_stream") return g_tri3_stream;
     if (n == "stream_ablate") return g_stream_ablate;
+    if (n == "pair_chain") return g_pair_chain;
+    if (n == "pair_ablate") return g_pair_ablate;
     if (n == "quad4_stagger") return g_quad4_stagger;
     if (n == "quad4_pipe") return g_quad4_pipe;
     if (n == "quad4_ablate") return g_quad4_ablate;

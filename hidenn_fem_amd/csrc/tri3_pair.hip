@@ -18,6 +18,12 @@
 
 namespace hfem {
 
+#ifdef HFEM_LAB
+#define HFEM_PAIR_LAB(bit) (lab_bits & (bit))          /* ablations: 1 no atomics, 2 no slot phase, 4 no write-out, 8 no gather loads, 16 return at once, 32 return after the row-map loads, 64 after the record loads, 128 after the first barrier, 256 no tile-energy store */
+#else
+#define HFEM_PAIR_LAB(bit) false
+#endif
+
 // BLOCK threads per tile; NPT >= ceil(max nodes / BLOCK), EPT >= ceil(max slots / BLOCK).  WPS = waves per SIMD the
 // register budget is sized for.  Measured best on T1M (round 2, profiles/r02): 256 threads, three slots per thread,
 // 86 VGPRs, four workgroups per CU -- 9.5 us against 11.2 us for the one-element-per-slot kernel at 512 threads.
@@ -26,13 +32,13 @@ namespace hfem {
 // float2 for fp32 models: widened on load, rounded once on store, fp64 arithmetic); ADAM: the write-out applies
 // torch.optim.Adam's update instead of storing the gradient (AdamFuse, hfem_tri3_energy_adam_step).
 template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
-          bool ADAM = false>
+          bool ADAM = false, bool CHAIN = false>
 __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
     const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     V2 *__restrict__ gx_free, V2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    LagSum lag, AdamFuse af) {
+    LagSum lag, AdamFuse af, int col_stride, int lab_bits) {
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
@@ -51,47 +57,85 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         if (tid == 0) lag.out[0] = tot;
         return;
     }
+    if (HFEM_PAIR_LAB(16)) return;                      // lab: dispatch cost of this grid shape alone
     const int slot = xcd_tile(blockIdx.x, n_launch);
-    const TileDesc d = pd.tiles[tile_begin + slot];
-    const int n_owned = d.n_owned;
-
-    // ---- all index loads first: row maps and slot records
+    // ---- row maps first, from the tile index alone (uniform node stride, plan.cpp): these loads and the descriptor's are in
+    //      flight together.  Unguarded: lanes past n_node read padding / the next tile's records -- valid rows, never stored.
     int2 s[NPT];
-    uint32_t w0[EPT], w1[EPT];
-    const int2 *src = pd.node_src + d.node_off;
+    const int2 *src = pd.node_src + (size_t)(tile_begin + slot) * pd.node_stride;
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int l = tid + j * BLOCK;
-        s[j] = make_int2(0, 0);
-        if (l < d.n_node) s[j] = src[l];
+    for (int j = 0; j < NPT; ++j) s[j] = src[tid + j * BLOCK];
+    const TileDesc d = pd.tiles[tile_begin + slot];     // scalar loads, in flight with the row maps
+    if (HFEM_PAIR_LAB(32)) {                            // lab: + one round of index loads
+        int acc = d.n_node;
+        for (int j = 0; j < NPT; ++j) acc += s[j].x;
+        if (acc == 0x7fffffff) partials[slot] = 1.0;
+        return;
     }
+    // ---- slot records, from the tile index alone as well (uniform slot stride; column stride `col_stride` is the plan's):
+    //      thread t walks column t, row j at j * col_stride + t.  Unguarded; what lies past n_elem is masked below.
+    uint32_t w0[EPT], w1[EPT];
+    const size_t rec0 = (size_t)(tile_begin + slot) * pd.elem_stride;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int i = tid + j * BLOCK;
-        w0[j] = kSkipBit;
-        w1[j] = 0u;
-        if (i < d.n_elem) { w0[j] = pd.elem_pack[d.elem_off + i]; w1[j] = pd.elem_pack_hi[d.elem_off + i]; }
+        w0[j] = pd.elem_pack[rec0 + tid + j * col_stride];
+        w1[j] = pd.elem_pack_hi[rec0 + tid + j * col_stride];
     }
-    // ---- gather through the row maps into LDS, clear the accumulators
+    // ---- gather through the row maps: issued before anything that needs the descriptor (program order = vmcnt order)
+    V2 vx[NPT], vu[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const V2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
+        const V2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
+        if (HFEM_PAIR_LAB(8)) { vx[j].x = vx[j].y = (decltype(vx[j].x))(0.001 * tid); vu[j] = vx[j]; continue; }
+        vx[j] = *px;
+        vu[j] = *pu;
+    }
+    const int n_owned = d.n_owned;
+    // boundary tiles: their Neumann-edge records now, not after the slot loop (a late dependent load on the critical path)
+    const int n_edge = skip_edges ? 0 : d.n_edge;
+    uint32_t edge_rec = 0u;
+    int edge_id = 0;
+    if (tid < n_edge) {
+        edge_rec = pd.edge_pack[d.edge_off + tid];
+        if (T_edge) edge_id = pd.edge_gid[d.edge_off + tid];
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (!(tid < col_stride && tid + j * col_stride < d.n_elem)) { w0[j] = kSkipBit; w1[j] = 0u; }
+    if (HFEM_PAIR_LAB(64)) {                            // lab: + the slot-record loads (second dependent round)
+        uint32_t acc = 0;
+        for (int j = 0; j < EPT; ++j) acc += w0[j] ^ w1[j];
+        for (int j = 0; j < NPT; ++j) acc += (uint32_t)s[j].x;
+        if (acc == 0x7fffffffu) partials[slot] = 1.0;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
         if (l < d.n_node) {
-            const V2 vx = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
-            const V2 vu = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
-            nd_xy[l] = make_double2((double)vx.x, (double)vx.y);
-            nd_uv[l] = make_double2((double)vu.x, (double)vu.y);
+            nd_xy[l] = make_double2((double)vx[j].x, (double)vx[j].y);
+            nd_uv[l] = make_double2((double)vu[j].x, (double)vu[j].y);
         }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     __syncthreads();
+    if (HFEM_PAIR_LAB(128)) {                           // lab: + LDS fill and the first barrier
+        uint32_t acc = 0;
+        for (int j = 0; j < EPT; ++j) acc += w0[j] ^ w1[j];
+        if (acc == 0x7fffffffu || nd_xy[tid].x == 1.2345) partials[slot] = 1.0;
+        return;
+    }
 
     auto add_row = [&](int l, const double2 gx, const double2 gu) {
+        if (HFEM_PAIR_LAB(1)) return;
         unsafeAtomicAdd(&acc0[l], gx.x); unsafeAtomicAdd(&acc1[l], gx.y);
         unsafeAtomicAdd(&acc2[l], gu.x); unsafeAtomicAdd(&acc3[l], gu.y);
     };
-    // ---- slots: registers + LDS only
     double e_loc = 0.0;
+    if (HFEM_PAIR_LAB(2)) {
+    } else if (!CHAIN) {
+    // ---- slots: registers + LDS only
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const uint32_t p = w0[j], q = w1[j];
@@ -120,11 +164,63 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
             if (lc < n_owned) add_row(lc, sxc, suc);
         }
     }
-    const int n_edge = skip_edges ? 0 : d.n_edge;
+    } else {
+    // ---- slots: registers + LDS only.  A CHAINED slot (strip order, plan.cpp) hands its rows of b and c -- and the node
+    //      values -- to the next slot of the column, whose n and d they are: 8 instead of 16 atomics, 4 instead of 8 reads.
+    double2 kxb, kub, kxc, kuc;                         // carried rows
+    double2 pXb, pUb, pXc, pUc;                         // carried node values
+    bool chained = false;
+    constexpr bool kCarryVals = false;                  // also carry the node VALUES (saves 4 LDS reads per chained slot; +16 VGPRs: spills)
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t p = w0[j], q = w1[j];
+        if (!(p & kSkipBit)) {
+            const int ln = (int)(p & kLocalMask), lb = (int)((p >> kLocalBits) & kLocalMask),
+                      lc = (int)((p >> (2 * kLocalBits)) & kLocalMask);
+            double2 Xn, Un;
+            if (kCarryVals && j > 0 && chained) { Xn = pXb; Un = pUb; } else { Xn = nd_xy[ln]; Un = nd_uv[ln]; }
+            const double2 Xc = nd_xy[lc], Uc = nd_uv[lc];
+            double2 sxn = make_double2(0.0, 0.0), sun = sxn, sxc = sxn, suc = sxn;   // running rows of the shared nodes n and c
+            if (q & (1u << 10)) {                       // B = (n, c, d) first: the carried rows and node values die here
+                const int ld = (int)(q & kLocalMask);
+                double2 Xd, Ud;
+                if (kCarryVals && j > 0 && chained) { Xd = pXc; Ud = pUc; } else { Xd = nd_xy[ld]; Ud = nd_uv[ld]; }
+                double2 gx[3], gu[3];
+                const double e = tri3_element<true, HASB, PHYS>(Xn, Xc, Xd, Un, Uc, Ud, k, gx, gu);
+                if (q & (1u << 11)) e_loc += e;
+                if (j > 0 && chained) {
+                    gx[0].x += kxb.x; gx[0].y += kxb.y; gu[0].x += kub.x; gu[0].y += kub.y;
+                    gx[2].x += kxc.x; gx[2].y += kxc.y; gu[2].x += kuc.x; gu[2].y += kuc.y;
+                }
+                if (ld < n_owned) add_row(ld, gx[2], gu[2]);
+                sxn = gx[0]; sun = gu[0]; sxc = gx[1]; suc = gu[1];
+            }
+            {
+                const double2 Xb = nd_xy[lb], Ub = nd_uv[lb];
+                double2 gx[3], gu[3];
+                const double e = tri3_element<true, HASB, PHYS>(Xn, Xb, Xc, Un, Ub, Uc, k, gx, gu);
+                if (p & kHomeBit) e_loc += e;
+                sxn.x += gx[0].x; sxn.y += gx[0].y; sun.x += gu[0].x; sun.y += gu[0].y;
+                sxc.x += gx[2].x; sxc.y += gx[2].y; suc.x += gu[2].x; suc.y += gu[2].y;
+                if (ln < n_owned) add_row(ln, sxn, sun);
+                chained = (q & (1u << 12)) != 0;
+                if (j + 1 < EPT && chained) {
+                    kxb = gx[1]; kub = gu[1]; kxc = sxc; kuc = suc;
+                    if (kCarryVals) { pXb = Xb; pUb = Ub; pXc = Xc; pUc = Uc; }
+                } else {
+                    if (lb < n_owned) add_row(lb, gx[1], gu[1]);
+                    if (lc < n_owned) add_row(lc, sxc, suc);
+                }
+            }
+        } else {
+            chained = false;
+        }
+    }
+    }   // CHAIN
     for (int i = tid; i < n_edge; i += BLOCK) {          // boundary tiles only
-        const uint32_t p = pd.edge_pack[d.edge_off + i];
+        const uint32_t p = i == tid ? edge_rec : pd.edge_pack[d.edge_off + i];
         const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
-        const double4 tt = T_edge ? T_edge[pd.edge_gid[d.edge_off + i]] : Tconst;
+        const double4 tt = T_edge ? T_edge[i == tid ? edge_id : pd.edge_gid[d.edge_off + i]] : Tconst;
         double2 gx[2], gu[2];
         const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
         if (p & kHomeBit) e_loc -= wk;
@@ -135,6 +231,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         const double w = wave_sum(e_loc);
         if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
     }
+    // every load has long returned; saying so keeps the compiler from guarding each write-out store with a vmcnt(0) of its
+    // own (gfx9 counts stores in vmcnt: the stores would wait for one another -- seen in the ISA of the carrying slot loop)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     if (ADAM) {
@@ -177,7 +276,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
-        if (l < n_owned) {
+        if (l < n_owned && !HFEM_PAIR_LAB(4)) {
             if (gx_free && s[j].x >= 0) {
                 V2 v;
                 v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
@@ -197,17 +296,22 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         double tile_e = 0.0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
-        partials[slot] = tile_e;
+        if (!HFEM_PAIR_LAB(256) || tile_e == 1.2345) partials[slot] = tile_e;
     }
 }
 
-template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM>
-static void launch_pair_inst(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
+template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM, bool CHAIN>
+static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
     const size_t lds = CAPO > 0 ? (size_t)(A.max_nodes * 32 + CAPO * 32 + 128) : A.lds;
-    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM>), dim3(A.grid), dim3(BLK), lds, A.s,
+    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN>), dim3(A.grid), dim3(BLK), lds, A.s,
                        A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
                        (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
-                       CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af);
+                       CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride, A.lab_bits);
+}
+template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM>
+static void launch_pair_inst(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
+    if (A.chain) launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, true>(A, lag, af);
+    else launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, false>(A, lag, af);
 }
 
 // Launch on a paired plan: picks the instance that holds the plan's tile shape.  1 = launched, 0 = none does.
@@ -219,10 +323,12 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     if (!h.paired || !plan->d_elem_pack_hi) return 0;
     A.pd = plan_dev(plan);
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.lds = (size_t)plan->lds_bytes;
+    A.col_stride = h.col_stride;
+    if (A.chain < 0) A.chain = h.n_chained > 0 ? 1 : 0;   // chained records need the carrying slot loop
     const bool cc = h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 38912;   // four workgroups per CU
     const int npt = h.max_nodes <= 3 * 256 ? 3 : 4;
-    const int ept = (h.max_elems + 255) / 256;
-    if (h.max_nodes > 4 * 256 || ept > 6) return 0;
+    const int ept = h.max_rows;                          // slots per thread
+    if (h.max_nodes > 4 * 256 || ept > 6 || ept < 1) return 0;
 #define HFEM_PAIR_EPT(NPT, CO, HB, PH, V, AD)                                                    \
     switch (ept) {                                                                               \
         case 1: case 2: case 3: launch_pair_inst<256, NPT, 3, CO, HB, PH, V, AD>(A, lag, af); return 1; \

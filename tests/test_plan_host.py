@@ -266,6 +266,9 @@ def test_planner_under_address_and_ub_sanitizers(tmp_path):
     files.append(write("delaunay_paired.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=1200, node_cap=557, order=5))
     cf, cnf, _, _, _, edf = structured_tri_mesh(121, 81, jitter=0.2, seed=1, dtype=torch.float64)
     files.append(write("fixed_paired.bin", cnf.numpy(), cf.numpy(), edf.numpy(), tile_elems=1200, node_cap=557, order=5))
+    files.append(write("fixed_strips.bin", cnf.numpy(), cf.numpy(), edf.numpy(), tile_elems=1200, node_cap=557, order=6))
+    files.append(write("delaunay_strips.bin", cnu.numpy(), cu.numpy(), edu.numpy(), tile_elems=1200, node_cap=557, order=6))
+    files.append(write("perm_strips_big.bin", cn.numpy(), c.numpy(), ed.numpy(), tile_elems=1400, order=6, maps=maps))
     cq, cnq, _, _, _, edq = structured_quad_mesh(41, 37, jitter=0.2, seed=1, dtype=torch.float64)
     files.append(write("quad4.bin", cnq.numpy(), cq.numpy(), edq.numpy(), npe=4, tile_elems=500))
     files.append(write("one_element.bin", [[0, 1, 2]], [[0, 0], [1, 0], [0, 1]], np.zeros((0, 2))))
@@ -314,3 +317,51 @@ def test_paired_element_order_records_and_auto_policy():
         assert auto.is_paired() == (name == "fixed"), name
         check_invariants(cn, ed, X.shape[0], auto)
         auto.close()
+
+
+def test_strip_element_order_chains():
+    """plan_elem_order 6 (csrc/plan.cpp; tri3_pair.hip's chained slots): thread t of a tile walks column t of the tile's
+    slot array (row j at j*stride + t, stride = tile_desc[7]); a slot with the chain bit hands its rows of b and c to the
+    next slot of the column, which must be a full pair with n' = b and d' = c.  The invariants and the numpy emulation
+    (format-independent) hold; on a fixed-diagonal split mesh most pairs are chained."""
+    from hidenn_fem_amd.mesh import unstructured_tri_mesh
+    cases = {
+        "fixed": structured_tri_mesh(61, 41, jitter=0.25, seed=2, dtype=torch.float64),
+        "zigzag": structured_tri_mesh(40, 37, jitter=0.25, seed=5, diagonal="zigzag", dtype=torch.float64),
+        "flipped": structured_tri_mesh(40, 37, jitter=0.25, seed=5, flip_fraction=0.3, dtype=torch.float64),
+        "delaunay": unstructured_tri_mesh(5000, seed=6, dtype=torch.float64),
+    }
+    mat, W, Tc = CF.plane_stress(), 0.25, np.array([2e5, 0.0, 0.0, 0.0])
+    for name, (coords, conn, geom, bc, mn, edges) in cases.items():
+        X, cn, ed = coords.numpy(), conn.numpy(), edges.numpy()
+        for tile in (300, 1100):
+            plan = TilePlan(cn, X.shape[0], coords_hint=X, edges=ed, tile_elems=tile, elem_order=6)
+            assert plan.is_paired()
+            a = check_invariants(cn, ed, X.shape[0], plan)
+            desc = plan.export("tile_desc").reshape(-1, 8)
+            w0, w1 = plan.export("elem_pack"), plan.export("elem_pack_hi")
+            n_chain = n_pair = 0
+            for t in range(desc.shape[0]):
+                eo, nel, stride = int(desc[t, 0]), int(desc[t, 1]), int(desc[t, 7])
+                assert 0 < stride <= 256 and stride % 16 == 0 or nel == 0
+                assert nel <= 6 * stride
+                p, q = w0[eo:eo + nel], w1[eo:eo + nel]
+                real = (p >> 31) == 0
+                n_pair += int((real & (((q >> 10) & 1) == 1)).sum())
+                ch = np.nonzero(real & (((q >> 12) & 1) == 1))[0]
+                n_chain += ch.size
+                nxt = ch + stride
+                assert (nxt < nel).all()                                   # the successor exists, ...
+                assert ((p[nxt] >> 31) == 0).all() and (((q[nxt] >> 10) & 1) == 1).all()      # ... is a full pair ...
+                assert (((q[ch] >> 10) & 1) == 1).all()
+                assert np.array_equal(p[nxt] & 1023, (p[ch] >> 10) & 1023)                     # ... with n' = b
+                assert np.array_equal(q[nxt] & 1023, (p[ch] >> 20) & 1023)                     # ... and d' = c
+            if name == "fixed" and tile == 1100:                           # three slots per thread: chains of up to three pairs
+                assert n_chain > 0.45 * n_pair, (n_chain, n_pair)
+            U = 1e-4 * np.random.default_rng(1).standard_normal(X.shape)
+            e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, cn, mat, W)
+            e_ref -= CF.edge2_energy(X, U, ed, Tconst=Tc, gX=gX_ref, gU=gU_ref)
+            loss, gX, gU = emulate(a, X, U, mat, W, None, Tc)
+            assert abs(loss - e_ref) <= 1e-12 * abs(e_ref), name
+            assert np.abs(gX - gX_ref).max() <= 1e-10 * np.abs(gX_ref).max() and np.abs(gU - gU_ref).max() <= 1e-10 * np.abs(gU_ref).max()
+            plan.close()

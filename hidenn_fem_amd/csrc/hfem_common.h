@@ -28,8 +28,8 @@ constexpr int kMaxLocal = 1 << kLocalBits;
 constexpr uint32_t kLocalMask = kMaxLocal - 1;
 constexpr uint32_t kHomeBit = 1u << 30;   // element/edge energy is counted by this tile
 constexpr uint32_t kSkipBit = 1u << 31;   // padding record: the lane has no element
-constexpr int32_t kNodeTailPad = 1024;    // records after the last tile's stride (unguarded loads of up to 4 x 256 lanes)
-constexpr int32_t kElemTailPad = 1536;    // slot records after the last tile's stride (6 x 256 lanes)
+constexpr int32_t kNodeTailPad = 2048;    // records after the last tile's stride (unguarded loads of up to NPT x BLOCK lanes from a tile's start)
+constexpr int32_t kElemTailPad = 4096;    // slot records after the last tile's stride (EPT x BLOCK lanes)
 constexpr int32_t kMaxQuadSlots = 1024;   // element slots per tile the tiled QUAD4 kernel can hold in registers
 
 // tile_desc[t] = 8 x int32

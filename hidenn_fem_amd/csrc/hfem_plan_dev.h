@@ -76,7 +76,7 @@ struct hfem_plan {
     int prev_begin = 0, prev_n = 0;           // partial range of the most recent HFEM_FLAG_NO_LOSS_SUM launch
     void *prev_stream = nullptr;              // ... and the stream it went to
     // tuning options captured at creation (hfem_set_option only changes the defaults of LATER plans)
-    struct Tune { int tiled_block = 512, store_policy = 16, tiled_fast = 1, fast_const_caps = 1; } tune;
+    struct Tune { int tiled_block = 512, store_policy = 16, tiled_fast = 1, fast_const_caps = 1, pair_tiles_per_wg = 1, pair_pipe_wps = 4; } tune;
     unsigned long long *d_stamps = nullptr;   // lab build only: [n_tiles][16] s_memrealtime stamps (NULL otherwise)
     int64_t device_bytes = 0;
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
@@ -118,6 +118,8 @@ struct PairLaunch {
 };
 int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
                      const AdamFuse &af);
+// tri3_pair_pipe.hip: the same pass with tpw tiles per workgroup, software-pipelined; 1 = launched, 0 = no instance
+int launch_tri3_pair_pipe(const hfem_plan *plan, PairLaunch A, int n_tiles, int tpw, const LagSum &lag);
 // tri3_det.hip: fixed-order (bit-reproducible) energy + gradients; phys: the physical gradient convention
 int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed, const double *u_free,
                     const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,

@@ -336,33 +336,38 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
         while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
     }
 #endif
+    // ---- row maps and element records from the tile index alone (uniform node / slot strides, plan.cpp), in flight together
+    //      with the descriptor; unguarded loads (padding = valid rows / skip records), then the gather, issued back to back
+    int2 s[NPT];
+    uint32_t pk[EPT], pk3[EPT];
+    const int2 *src = pd.node_src + (size_t)(tile_begin + slot) * pd.node_stride;
+    const size_t rec0 = (size_t)(tile_begin + slot) * pd.elem_stride;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];      // lanes past the stride repeat its last record
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const size_t i = rec0 + min(tid + j * BLOCK, pd.elem_stride - 1);
+        pk[j] = pd.elem_pack[i];
+        pk3[j] = pd.elem_pack_hi[i];
+    }
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
     if ((ABL & 4) && threadIdx.x == 0 && n_owned >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-
-    int2 s[NPT];
-    uint32_t pk[EPT], pk3[EPT];
-    const int2 *src = pd.node_src + d.node_off;
+    double2 vx[NPT], vu[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const double2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
+        const double2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
+        vx[j] = *px;
+        vu[j] = *pu;
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (tid + j * BLOCK >= d.n_elem) { pk[j] = kSkipBit; pk3[j] = 0u; }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
-        s[j] = make_int2(0, 0);
-        if (l < d.n_node) s[j] = src[l];
-    }
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const int i = tid + j * BLOCK;
-        pk[j] = kSkipBit;
-        pk3[j] = 0u;
-        if (i < d.n_elem) { pk[j] = pd.elem_pack[d.elem_off + i]; pk3[j] = pd.elem_pack_hi[d.elem_off + i]; }
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int l = tid + j * BLOCK;
-        if (l < d.n_node) {
-            nd_xy[l] = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
-            nd_uv[l] = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
-        }
+        if (l < d.n_node) { nd_xy[l] = vx[j]; nd_uv[l] = vu[j]; }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     HFEM_QSTAMP(2)
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
         if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
     }
     HFEM_QSTAMP(4)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): all loads returned long ago; keeps per-store vmcnt waits out of the write-out
     __syncthreads();
     HFEM_QSTAMP(5)
 

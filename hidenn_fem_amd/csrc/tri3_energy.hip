@@ -282,34 +282,32 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
     }
 #endif
+    // ---- row maps and element records from the tile index alone (uniform node / slot strides, plan.cpp), in flight together
+    //      with the descriptor; unguarded loads (padding = valid rows / skip records), then the gather, all issued back to back.
+    //      Round-2 ISA reading: guarded loads are basic blocks of their own and made desc -> maps -> rows three dependent trips.
+    int2 s[NPT];
+    uint32_t pk[EPT];
+    const int2 *src = pd.node_src + (size_t)(tile_begin + slot) * pd.node_stride;
+    const uint32_t *ep = pd.elem_pack + (size_t)(tile_begin + slot) * pd.elem_stride;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];      // lanes past the stride repeat its last record
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) pk[j] = ep[min(tid + j * BLOCK, pd.elem_stride - 1)];
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
     if (STAMP && threadIdx.x == 0 && n_owned >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-
-    // ---- all index loads first: row maps and element records
-    int2 s[NPT];
-    uint32_t pk[EPT];
-    const int2 *src = pd.node_src + d.node_off;
-    const uint32_t *ep = pd.elem_pack + d.elem_off;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (tid + j * BLOCK >= d.n_elem) pk[j] = kSkipBit;
+    // ---- gather (unguarded loads: the compiler batches as many as the register budget of the instance allows) into LDS,
+    //      clear the accumulators
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
-        s[j] = make_int2(0, 0);
-        if (l < d.n_node) s[j] = src[l];
-    }
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const int i = tid + j * BLOCK;
-        pk[j] = kSkipBit;
-        if (i < d.n_elem) pk[j] = ep[i];
-    }
-    // ---- gather through the row maps into LDS, clear the accumulators
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int l = tid + j * BLOCK;
+        const V2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
+        const V2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
+        const V2 vx = *px, vu = *pu;
         if (l < d.n_node) {
-            const V2 vx = s[j].x >= 0 ? x_free[s[j].x] : x_fixed[~s[j].x];
-            const V2 vu = s[j].y >= 0 ? u_free[s[j].y] : u_fixed[~s[j].y];
             nd_xy[l] = make_double2((double)vx.x, (double)vx.y);
             nd_uv[l] = make_double2((double)vu.x, (double)vu.y);
         }
@@ -368,6 +366,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
     }
     HFEM_FSTAMP(4)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): all loads returned long ago; keeps per-store vmcnt waits out of the write-out
     __syncthreads();
     HFEM_FSTAMP(5)
 
@@ -695,6 +694,8 @@ struct Defaults {
                                             // L2 and does not evict the re-read inputs / plan arrays), 0 = plain
     std::atomic<int> tiled_fast{1};         // register-prefetched kernel (0: the generic loop kernel)
     std::atomic<int> fast_const_caps{1};    // default tile shape: instance with compile-time accumulator strides
+    std::atomic<int> pair_pipe_wps{4};      // pipelined kernel: register budget sized for this many waves per SIMD (3 or 4)
+    std::atomic<int> pair_tiles_per_wg{1};  // paired plans: > 1 = software-pipelined kernel, that many tiles per workgroup
     std::atomic<int> plan_elem_order{-1};   // TRI3: -1 = auto (paired when >= 90 % of the elements find a partner, else 3; measured
                                             // crossover), 5 = paired slots (two fan-adjacent elements per slot, tri3_pair.hip; the default),
                                             // 3 = one element per slot in LDS-bank-aware 16-lane groups, 4 = the same inside three
@@ -720,6 +721,8 @@ hfem_plan::Tune current_tune() {
     t.store_policy = g_def.store_policy.load();
     t.tiled_fast = g_def.tiled_fast.load();
     t.fast_const_caps = g_def.fast_const_caps.load();
+    t.pair_tiles_per_wg = g_def.pair_tiles_per_wg.load();
+    t.pair_pipe_wps = g_def.pair_pipe_wps.load();
     return t;
 }
 
@@ -1109,7 +1112,15 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             P.chain = g_pair_chain; P.lab_bits = g_pair_ablate;
 #endif
             HFEM_ARG_CHECK(!(lag.prev && (hasb || phys)), "HFEM_FLAG_SUM_PREVIOUS: default forces and convention only");
-            const int rc_pair = launch_tri3_pair(plan, P, (hasb || phys) ? 1 : 0, hasb, phys, lag, AdamFuse{});
+            int rc_pair = 0;
+#ifdef HFEM_LAB
+            if (plan->tune.pair_tiles_per_wg > 1 && !hasb && !phys) {
+                P.grid = 0;
+                rc_pair = launch_tri3_pair_pipe(plan, P, n, plan->tune.pair_tiles_per_wg, lag);
+                P.grid = n + (lag.prev ? 1 : 0);
+            }
+#endif
+            if (!rc_pair) rc_pair = launch_tri3_pair(plan, P, (hasb || phys) ? 1 : 0, hasb, phys, lag, AdamFuse{});
             HFEM_ARG_CHECK(rc_pair == 1, "paired plan: tile shape outside the pair kernel's instances");
             launched = true;
         }
@@ -1344,6 +1355,12 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_tri3_stream = value ? 1 : 0;
     } else if (n == "stream_ablate") {
         g_stream_ablate = value;
+    } else if (n == "pair_pipe_wps") {
+        HFEM_ARG_CHECK(value == 3 || value == 4, "pair_pipe_wps must be 3 or 4");
+        g_def.pair_pipe_wps = value;
+    } else if (n == "pair_tiles_per_wg") {
+        HFEM_ARG_CHECK(value >= 1 && value <= 16, "pair_tiles_per_wg must be 1..16");
+        g_def.pair_tiles_per_wg = value;
     } else if (n == "pair_chain") {
         g_pair_chain = value;
     } else if (n == "pair_ablate") {
@@ -1378,6 +1395,8 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "store_policy") return g_def.store_policy.load();
     if (n == "tiled_fast") return g_def.tiled_fast.load();
     if (n == "fast_const_caps") return g_def.fast_const_caps.load();
+    if (n == "pair_tiles_per_wg") return g_def.pair_tiles_per_wg.load();
+    if (n == "pair_pipe_wps") return g_def.pair_pipe_wps.load();
     if (n == "quad4_const_caps") return g_quad4_const_caps;
     if (n == "plan_elem_order") return g_def.plan_elem_order.load();
     if (n == "plan_node_cap") return g_def.plan_node_cap.load();

@@ -19,7 +19,7 @@
 namespace hfem {
 
 #ifdef HFEM_LAB
-#define HFEM_PAIR_LAB(bit) (lab_bits & (bit))          /* ablations: 1 no atomics, 2 no slot phase, 4 no write-out, 8 no gather loads, 16 return at once, 32 return after the row-map loads, 64 after the record loads, 128 after the first barrier, 256 no tile-energy store */
+#define HFEM_PAIR_LAB(bit) (lab_bits & (bit))          /* ablations: 1 no atomics, 2 no slot phase, 4 no write-out, 8 no gather loads, 16 return at once, 32 return after the row-map loads, 64 after the record loads, 128 after the first barrier, 256 no tile-energy store, 512 no edges, 1024 no record loads, 2048 no LDS fill */
 #else
 #define HFEM_PAIR_LAB(bit) false
 #endif
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     int2 s[NPT];
     const int2 *src = pd.node_src + (size_t)(tile_begin + slot) * pd.node_stride;
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) s[j] = src[tid + j * BLOCK];
+    for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];      // lanes past the stride repeat its last record
     const TileDesc d = pd.tiles[tile_begin + slot];     // scalar loads, in flight with the row maps
     if (HFEM_PAIR_LAB(32)) {                            // lab: + one round of index loads
         int acc = d.n_node;
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     const size_t rec0 = (size_t)(tile_begin + slot) * pd.elem_stride;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        w0[j] = pd.elem_pack[rec0 + tid + j * col_stride];
-        w1[j] = pd.elem_pack_hi[rec0 + tid + j * col_stride];
+        if (HFEM_PAIR_LAB(1024)) { w0[j] = kSkipBit | tid; w1[j] = 0u; continue; }
+        const size_t i = rec0 + min(tid + j * col_stride, pd.elem_stride - 1);
+        w0[j] = pd.elem_pack[i];
+        w1[j] = pd.elem_pack_hi[i];
     }
     // ---- gather through the row maps: issued before anything that needs the descriptor (program order = vmcnt order)
     V2 vx[NPT], vu[NPT];
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     }
     const int n_owned = d.n_owned;
     // boundary tiles: their Neumann-edge records now, not after the slot loop (a late dependent load on the critical path)
-    const int n_edge = skip_edges ? 0 : d.n_edge;
+    const int n_edge = (skip_edges || HFEM_PAIR_LAB(512)) ? 0 : d.n_edge;
     uint32_t edge_rec = 0u;
     int edge_id = 0;
     if (tid < n_edge) {
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
+        if (HFEM_PAIR_LAB(2048)) continue;
         if (l < d.n_node) {
             nd_xy[l] = make_double2((double)vx[j].x, (double)vx[j].y);
             nd_uv[l] = make_double2((double)vu[j].x, (double)vu[j].y);

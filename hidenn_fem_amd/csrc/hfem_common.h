@@ -92,5 +92,6 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
                     HostPlan &out);
 
 void set_plan_curve(int c);   // 0 Morton, 1 Hilbert (default)
+void set_plan_snap(int percent);   // tile cuts snap back to coarse curve-cell boundaries by up to this share of a tile (0 off)
 
 }  // namespace hfem

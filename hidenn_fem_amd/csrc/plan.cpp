@@ -67,10 +67,18 @@ inline uint32_t hilbert16(uint32_t x, uint32_t y) {
 
 static int g_curve = 1;   // 0 Morton, 1 Hilbert
 void set_locality_curve(int c) { g_curve = c; }
+// Tile cuts snap to coarse cells of the locality curve: when the node cap ends a tile, the cut moves back (by at most
+// g_snap percent of the tile) to the boundary between the two consecutive elements whose curve codes differ in the highest
+// bit -- the edge of the coarsest curve cell in reach.  Tiles become unions of whole cells (straight, axis-aligned sides)
+// instead of ending mid-cell on a staircase: fewer halo elements and nodes per tile.  0 = off.
+static int g_snap = 0;
+void set_tile_snap(int percent) { g_snap = percent < 0 ? 0 : (percent > 50 ? 50 : percent); }
+static thread_local std::vector<uint32_t> g_codes;   // curve code of every element, in sorted order (empty: no coordinates)
 
 void morton_order(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *xy,
                   std::vector<int32_t> &order) {
     order.resize(ne);
+    g_codes.clear();
     if (!xy || ne == 0) {
         std::iota(order.begin(), order.end(), 0);
         return;
@@ -104,7 +112,8 @@ void morton_order(const int64_t *conn, int npe, int64_t ne, int64_t nn, const do
         keys[e] = (code << 32) | (uint64_t)(uint32_t)e;   // ties: element id (stable)
     }
     std::sort(keys.begin(), keys.end());
-    for (int64_t p = 0; p < ne; ++p) order[p] = (int32_t)(keys[p] & 0xFFFFFFFFu);
+    g_codes.resize(ne);
+    for (int64_t p = 0; p < ne; ++p) { order[p] = (int32_t)(keys[p] & 0xFFFFFFFFu); g_codes[p] = (uint32_t)(keys[p] >> 32); }
 }
 
 constexpr int kOrphanTileNodes = 512;
@@ -379,10 +388,21 @@ void cut_tiles(const int64_t *conn, int npe, int64_t ne, int64_t nn, const std::
         for (int k = 0; k < npe; ++k)
             if (stamp[conn[npe * e + k]] != tile) ++fresh;
         if (p > start && (p - start >= T || distinct + fresh > node_cap)) {
-            bounds.push_back(p);
+            int64_t cut = p;
+            if (g_snap > 0 && (int64_t)g_codes.size() == ne) {
+                const int64_t lo = std::max(start + 1, p - ((p - start) * g_snap) / 100);
+                int best_lvl = -1;                                       // curve level of the boundary (two code bits per level)
+                for (int64_t q = p; q >= lo; --q) {                      // the latest position wins ties: biggest tile
+                    const uint32_t x = g_codes[q - 1] ^ g_codes[q];
+                    const int lvl = x ? (31 - __builtin_clz(x)) / 2 : -1;
+                    if (lvl > best_lvl) { best_lvl = lvl; cut = q; }
+                }
+            }
+            bounds.push_back(cut);
             ++tile;
-            start = p;
+            start = cut;
             distinct = 0;
+            if (cut != p) { p = cut - 1; continue; }                     // re-walk [cut, p) as part of the new tile
         }
         for (int k = 0; k < npe; ++k) {
             int32_t &st = stamp[conn[npe * e + k]];
@@ -864,6 +884,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
 }  // namespace
 
 void set_plan_curve(int c) { set_locality_curve(c); }
+void set_plan_snap(int percent) { set_tile_snap(percent); }
 
 int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,

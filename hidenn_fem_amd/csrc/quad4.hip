@@ -353,21 +353,22 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     const TileDesc d = pd.tiles[tile_begin + slot];
     const int n_owned = d.n_owned;
     if ((ABL & 4) && threadIdx.x == 0 && n_owned >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    double2 vx[NPT], vu[NPT];
+    double vxx[NPT], vxy[NPT], vux[NPT], vuy[NPT];      // plain doubles (double2 arrays end up in scratch)
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const double2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
         const double2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
-        vx[j] = *px;
-        vu[j] = *pu;
+        const double2 tx = *px, tu = *pu;
+        vxx[j] = tx.x; vxy[j] = tx.y; vux[j] = tu.x; vuy[j] = tu.y;
     }
+    __builtin_amdgcn_sched_barrier(0);                  // all gather loads are issued before the first is waited for
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
         if (tid + j * BLOCK >= d.n_elem) { pk[j] = kSkipBit; pk3[j] = 0u; }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
-        if (l < d.n_node) { nd_xy[l] = vx[j]; nd_uv[l] = vu[j]; }
+        if (l < d.n_node) { nd_xy[l] = make_double2(vxx[j], vxy[j]); nd_uv[l] = make_double2(vux[j], vuy[j]); }
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     HFEM_QSTAMP(2)

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         vx[j] = *px;
         vu[j] = *pu;
     }
+    __builtin_amdgcn_sched_barrier(0);                  // all gather loads are issued before the first is waited for
     const int n_owned = d.n_owned;
     // boundary tiles: their Neumann-edge records now, not after the slot loop (a late dependent load on the critical path)
     const int n_edge = (skip_edges || HFEM_PAIR_LAB(512)) ? 0 : d.n_edge;

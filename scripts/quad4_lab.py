@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--ccaps", default="1", help="compile-time accumulator stride instance (1) or runtime strides (0)")
     ap.add_argument("--pipes", default="0", help="persistent pipelined kernel: workgroups per CU (0 = off)")
     ap.add_argument("--ablate", default="0", help="lab bits: 1 no element math, 2 no LDS atomics")
+    ap.add_argument("--snaps", default="0", help="plan_snap values (tile cuts snap to coarse curve cells, percent of a tile)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     f64 = torch.float64
@@ -90,8 +91,9 @@ def main():
     us = time_graph(planless, a.reps)
     print(json.dumps(dict(kernel="quad4_atomic(planless, no zero fill)", us=round(us, 2),
                           alg_TBps=round(alg / us * 1e-6, 3))), flush=True)
-    for T, cap in [(int(t), int(c)) for t in a.tiles.split(",") for c in a.caps.split(",")]:
+    for T, cap, snap in [(int(t), int(c), int(sn)) for t in a.tiles.split(",") for c in a.caps.split(",") for sn in a.snaps.split(",")]:
         _lib.check(L.hfem_set_option(b"plan_node_cap", cap))
+        _lib.check(L.hfem_set_option(b"plan_snap", snap))
         plan = TilePlan(m.connectivity, m.Nnodes, coords_hint=m.initial_node_coords, x_src=m._x_src, u_src=m._u_src,
                         edges=m.neumann_edges, tile_elems=T, device=dev, nodes_per_elem=4)
 
@@ -125,7 +127,7 @@ def main():
               _lib.check(L.hfem_set_option(b"quad4_stagger", 0))
               _lib.check(L.hfem_set_option(b"quad4_pipe", 0))
               st = plan.stats
-              print(json.dumps(dict(kernel="quad4_tiled", ablate=abl, stagger=stg, shift=sh, groups=grp, pipe=pipe, ccaps=cc, check=chk if abl == 0 else "", tile_elems=T, cap=cap, us=round(us, 2),
+              print(json.dumps(dict(kernel="quad4_tiled", ablate=abl, stagger=stg, shift=sh, groups=grp, pipe=pipe, ccaps=cc, check=chk if abl == 0 else "", tile_elems=T, cap=cap, snap=snap, us=round(us, 2),
                                     alg_TBps=round(alg / us * 1e-6, 3), frac=round(alg / us * 1e-6 / 8.0, 3),
                                     n_tiles=st["n_tiles"], lds=st["lds_bytes"], slots=st["tile_elem_total"],
                                     max_nodes=st["max_tile_nodes"], max_elems=st["max_tile_elems"])), flush=True)

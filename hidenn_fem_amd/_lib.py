@@ -101,6 +101,13 @@ PROTOTYPES = {
     "hfem_rectq4_mse": (C.c_int, [C.c_int, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 
+# float-row twins of the 1D / structured entry points (same argument lists; every array pointer is float* except the
+# fp64 scratch of the *_ws forms)
+_F32_TWINS = ["hfem_grid_param_fwd", "hfem_grid_param_bwd", "hfem_grid_param_fwd_ws", "hfem_grid_param_bwd_ws",
+              "hfem_line2_eval_fwd", "hfem_line2_eval_bwd", "hfem_bar_energy", "hfem_line2_mse", "hfem_rectq4_eval_fwd",
+              "hfem_rectq4_eval_bwd", "hfem_rectq4_mse"]
+PROTOTYPES.update({name + "_f32": PROTOTYPES[name] for name in _F32_TWINS})
+
 _lib = None
 
 

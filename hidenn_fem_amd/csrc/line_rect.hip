@@ -42,36 +42,38 @@ __device__ __forceinline__ double block_scan(double v, double *buf, bool suffix)
 }
 
 // p[n] -> grid[n+1]; one workgroup of kScan threads, each owning a contiguous chunk.
-__global__ __launch_bounds__(kScan) void grid_param_fwd_kernel(const double *__restrict__ p, int64_t n,
+template <typename T>
+__global__ __launch_bounds__(kScan) void grid_param_fwd_kernel(const T *__restrict__ p, int64_t n,
                                                               double x0, double xN,
                                                               const uint8_t *__restrict__ mask,
-                                                              const double *__restrict__ initial,
-                                                              double *__restrict__ grid) {
+                                                              const T *__restrict__ initial,
+                                                              T *__restrict__ grid) {
     __shared__ double buf[kScan];
     const int tid = threadIdx.x;
     const int64_t chunk = (n + kScan - 1) / kScan;
     const int64_t k0 = tid * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
     double s = 0.0;
-    for (int64_t k = k0; k < k1; ++k) s += softplus_clamped(p[k]);
+    for (int64_t k = k0; k < k1; ++k) s += softplus_clamped((double)p[k]);
     const double incl = block_scan(s, buf, false);
     const double S = buf[kScan - 1];
     double run = incl - s;
     for (int64_t k = k0; k < k1; ++k) {
-        run += softplus_clamped(p[k]);
+        run += softplus_clamped((double)p[k]);
         const double cum = (k == n - 1) ? S : run;              // cum[-1]/cum[-1] == 1 exactly
         double g = x0 + (xN - x0) * cum / S;                    // models.py:52
-        if (mask && mask[k + 1]) g = initial[k + 1];            // models.py:165-166
-        grid[k + 1] = g;
+        if (mask && mask[k + 1]) g = (double)initial[k + 1];    // models.py:165-166
+        grid[k + 1] = (T)g;
     }
-    if (tid == 0) grid[0] = (mask && mask[0]) ? initial[0] : x0;
+    if (tid == 0) grid[0] = (mask && mask[0]) ? initial[0] : (T)x0;
 }
 
 // ggrid[n+1] -> gp[n]
-__global__ __launch_bounds__(kScan) void grid_param_bwd_kernel(const double *__restrict__ p, int64_t n,
+template <typename T>
+__global__ __launch_bounds__(kScan) void grid_param_bwd_kernel(const T *__restrict__ p, int64_t n,
                                                               double x0, double xN,
                                                               const uint8_t *__restrict__ mask,
-                                                              const double *__restrict__ ggrid,
-                                                              double *__restrict__ gp) {
+                                                              const T *__restrict__ ggrid,
+                                                              T *__restrict__ gp) {
     __shared__ double buf[kScan];
     __shared__ double red[kScan / 64];
     __shared__ double dot_s;
@@ -80,15 +82,15 @@ __global__ __launch_bounds__(kScan) void grid_param_bwd_kernel(const double *__r
     const int64_t k0 = tid * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
     const double L = xN - x0;
     double s = 0.0;
-    for (int64_t k = k0; k < k1; ++k) s += softplus_clamped(p[k]);
+    for (int64_t k = k0; k < k1; ++k) s += softplus_clamped((double)p[k]);
     const double incl = block_scan(s, buf, false);
     const double S = buf[kScan - 1];
     __syncthreads();
     // dot = sum_k gx_k cum_k (masked rows carry no gradient)
     double run = incl - s, dot = 0.0;
     for (int64_t k = k0; k < k1; ++k) {
-        run += softplus_clamped(p[k]);
-        const double g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+        run += softplus_clamped((double)p[k]);
+        const double g = (mask && mask[k + 1]) ? 0.0 : (double)ggrid[k + 1];
         dot += g * ((k == n - 1) ? S : run);
     }
     const double dtot = block_sum(dot, red);
@@ -98,15 +100,15 @@ __global__ __launch_bounds__(kScan) void grid_param_bwd_kernel(const double *__r
     // gcum_k = L g_k / S  (last: minus corr); ginc = suffix sum of gcum
     double loc = 0.0;
     for (int64_t k = k0; k < k1; ++k) {
-        const double g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+        const double g = (mask && mask[k + 1]) ? 0.0 : (double)ggrid[k + 1];
         loc += L * g / S - (k == n - 1 ? corr : 0.0);
     }
     const double suf = block_scan(loc, buf, true);   // sum over chunks >= tid
     double acc = suf - loc;                           // chunks strictly after this one
     for (int64_t k = k1 - 1; k >= k0; --k) {
-        const double g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+        const double g = (mask && mask[k + 1]) ? 0.0 : (double)ggrid[k + 1];
         acc += L * g / S - (k == n - 1 ? corr : 0.0);
-        gp[k] = acc * softplus_clamped_grad(p[k]);
+        gp[k] = (T)(acc * softplus_clamped_grad((double)p[k]));
     }
 }
 
@@ -132,14 +134,15 @@ __device__ __forceinline__ double gp_block_scan(double v, double *buf, bool suff
 }
 
 // F1: cumloc[k] = inclusive prefix of softplus within the block; bsum[b] = block total
-__global__ __launch_bounds__(kGpThreads) void gp_fwd_local_kernel(const double *__restrict__ p, int64_t n,
+template <typename T>
+__global__ __launch_bounds__(kGpThreads) void gp_fwd_local_kernel(const T *__restrict__ p, int64_t n,
                                                                   double *__restrict__ cum, double *__restrict__ bsum) {
     __shared__ double buf[kGpThreads];
     const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
     double v[kGpPer], run = 0.0;
 #pragma unroll
     for (int j = 0; j < kGpPer; ++j) {
-        v[j] = (k0 + j < n) ? softplus_clamped(p[k0 + j]) : 0.0;
+        v[j] = (k0 + j < n) ? softplus_clamped((double)p[k0 + j]) : 0.0;
         run += v[j];
         v[j] = run;
     }
@@ -172,12 +175,13 @@ __global__ __launch_bounds__(kScan) void gp_block_offsets_kernel(double *__restr
 }
 
 // F3: cum += block offset (last entry := S exactly), grid
+template <typename T>
 __global__ __launch_bounds__(kGpThreads) void gp_fwd_final_kernel(int64_t n, double x0, double xN,
                                                                   const uint8_t *__restrict__ mask,
-                                                                  const double *__restrict__ initial,
+                                                                  const T *__restrict__ initial,
                                                                   const double *__restrict__ boff,
                                                                   const double *__restrict__ scal, double *__restrict__ cum,
-                                                                  double *__restrict__ grid) {
+                                                                  T *__restrict__ grid) {
     const double S = scal[0], off = boff[blockIdx.x];
     const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
 #pragma unroll
@@ -187,16 +191,17 @@ __global__ __launch_bounds__(kGpThreads) void gp_fwd_final_kernel(int64_t n, dou
             const double c = (k == n - 1) ? S : off + cum[k];       // cum[-1]/cum[-1] == 1 exactly
             cum[k] = c;
             double g = x0 + (xN - x0) * c / S;                      // models.py:52
-            if (mask && mask[k + 1]) g = initial[k + 1];            // models.py:165-166
-            grid[k + 1] = g;
+            if (mask && mask[k + 1]) g = (double)initial[k + 1];    // models.py:165-166
+            grid[k + 1] = (T)g;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) grid[0] = (mask && mask[0]) ? initial[0] : x0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) grid[0] = (mask && mask[0]) ? initial[0] : (T)x0;
 }
 
 // B1: a_k = L g_k / S; sufloc[k] = inclusive suffix of a within the block; asum[b]; dsum[b] = sum g_k cum_k
+template <typename T>
 __global__ __launch_bounds__(kGpThreads) void gp_bwd_local_kernel(int64_t n, double L, const uint8_t *__restrict__ mask,
-                                                                  const double *__restrict__ ggrid,
+                                                                  const T *__restrict__ ggrid,
                                                                   const double *__restrict__ cum, double *__restrict__ suf,
                                                                   double *__restrict__ asum, double *__restrict__ dsum) {
     __shared__ double buf[kGpThreads];
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(kGpThreads) void gp_bwd_local_kernel(int64_t n, dou
         const int64_t k = k0 + j;
         double g = 0.0;
         if (k < n) {
-            g = (mask && mask[k + 1]) ? 0.0 : ggrid[k + 1];
+            g = (mask && mask[k + 1]) ? 0.0 : (double)ggrid[k + 1];
             dot += g * cum[k];
         }
         run += L * g / S;
@@ -227,26 +232,28 @@ __global__ __launch_bounds__(kGpThreads) void gp_bwd_local_kernel(int64_t n, dou
 }
 
 // B3: gp[k] = (suffix over later blocks + local suffix - corr) * softplus'(p[k])
-__global__ __launch_bounds__(kGpThreads) void gp_bwd_final_kernel(const double *__restrict__ p, int64_t n, double L,
+template <typename T>
+__global__ __launch_bounds__(kGpThreads) void gp_bwd_final_kernel(const T *__restrict__ p, int64_t n, double L,
                                                                   const double *__restrict__ cum,
                                                                   const double *__restrict__ suf,
                                                                   const double *__restrict__ aoff,
-                                                                  const double *__restrict__ scal, double *__restrict__ gp) {
+                                                                  const double *__restrict__ scal, T *__restrict__ gp) {
     const double S = cum[n - 1], corr = L * scal[1] / (S * S), off = aoff[blockIdx.x];
     const int64_t k0 = (int64_t)blockIdx.x * kGpChunk + (int64_t)threadIdx.x * kGpPer;
 #pragma unroll
     for (int j = 0; j < kGpPer; ++j) {
         const int64_t k = k0 + j;
-        if (k < n) gp[k] = (off + suf[k] - corr) * softplus_clamped_grad(p[k]);
+        if (k < n) gp[k] = (T)((off + suf[k] - corr) * softplus_clamped_grad((double)p[k]));
     }
 }
 
 // searchsorted(grid, x, right=False) - 1, clamp(0, n-2)      models.py:73-74
-__device__ __forceinline__ int find_elem(const double *__restrict__ grid, int n, double x) {
+template <typename T>
+__device__ __forceinline__ int find_elem(const T *__restrict__ grid, int n, double x) {
     int lo = 0, hi = n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (grid[mid] < x) lo = mid + 1; else hi = mid;
+        if ((double)grid[mid] < x) lo = mid + 1; else hi = mid;
     }
     int e = lo - 1;
     e = e < 0 ? 0 : e;
@@ -257,10 +264,13 @@ struct Hat {   // one axis of the hat-function pair, models.py:84-85
     int e;
     double N1, N2, h, raw, ui, uj;
 };
-__device__ __forceinline__ Hat hat_eval(const double *__restrict__ grid, int n, double x) {
+// T = row type of the caller's arrays (double, or float for the reference's default dtype: widened on load, rounded once on
+// store / atomic add, fp64 arithmetic in between -- as the TRI3 fp32-row kernel does)
+template <typename T>
+__device__ __forceinline__ Hat hat_eval(const T *__restrict__ grid, int n, double x) {
     Hat t;
     t.e = find_elem(grid, n, x);
-    const double xi = grid[t.e], xj = grid[t.e + 1];
+    const double xi = (double)grid[t.e], xj = (double)grid[t.e + 1];
     t.raw = xj - xi;
     t.h = t.raw < 1e-10 ? 1e-10 : t.raw;        // .clamp(self.epsilon)
     t.N1 = (xj - x) / t.h;
@@ -268,128 +278,130 @@ __device__ __forceinline__ Hat hat_eval(const double *__restrict__ grid, int n, 
     return t;
 }
 // accumulate d/dgrid of one axis given dL/dN1, dL/dN2
+template <typename T>
 __device__ __forceinline__ void hat_grid_grad(const Hat &t, double gN1, double gN2, double extra_gh,
-                                              double *__restrict__ ggrid) {
+                                              T *__restrict__ ggrid) {
     const double gh = t.raw < 1e-10 ? 0.0 : (extra_gh - (gN1 * t.N1 + gN2 * t.N2) / t.h);
-    unsafeAtomicAdd(&ggrid[t.e + 1], gN1 / t.h + gh);
-    unsafeAtomicAdd(&ggrid[t.e], -gN2 / t.h - gh);
+    unsafeAtomicAdd(&ggrid[t.e + 1], (T)(gN1 / t.h + gh));
+    unsafeAtomicAdd(&ggrid[t.e], (T)(-gN2 / t.h - gh));
 }
 
-__global__ __launch_bounds__(kBlockL) void line2_eval_fwd_kernel(const double *__restrict__ grid,
-                                                                const double *__restrict__ u, int n,
-                                                                const double *__restrict__ x_eval, int64_t m,
-                                                                double *__restrict__ pred,
-                                                                double *__restrict__ dudx) {
+template <typename T>
+__global__ __launch_bounds__(kBlockL) void line2_eval_fwd_kernel(const T *__restrict__ grid, const T *__restrict__ u, int n,
+                                                                const T *__restrict__ x_eval, int64_t m,
+                                                                T *__restrict__ pred, T *__restrict__ dudx) {
     const int64_t stride = (int64_t)gridDim.x * kBlockL;
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
-        const Hat t = hat_eval(grid, n, x_eval[q]);
-        const double ui = u[t.e], uj = u[t.e + 1];
-        if (pred) pred[q] = ui * t.N1 + uj * t.N2;               // models.py:88
-        if (dudx) dudx[q] = (uj - ui) / t.h;
+        const Hat t = hat_eval(grid, n, (double)x_eval[q]);
+        const double ui = (double)u[t.e], uj = (double)u[t.e + 1];
+        if (pred) pred[q] = (T)(ui * t.N1 + uj * t.N2);          // models.py:88
+        if (dudx) dudx[q] = (T)((uj - ui) / t.h);
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(kBlockL) void line2_eval_bwd_kernel(
-    const double *__restrict__ grid, const double *__restrict__ u, int n, const double *__restrict__ x_eval,
-    int64_t m, const double *__restrict__ cot, const double *__restrict__ cot_d, double *__restrict__ ggrid,
-    double *__restrict__ gu, double *__restrict__ gx_eval) {
+    const T *__restrict__ grid, const T *__restrict__ u, int n, const T *__restrict__ x_eval,
+    int64_t m, const T *__restrict__ cot, const T *__restrict__ cot_d, T *__restrict__ ggrid,
+    T *__restrict__ gu, T *__restrict__ gx_eval) {
     const int64_t stride = (int64_t)gridDim.x * kBlockL;
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
-        const Hat t = hat_eval(grid, n, x_eval[q]);
-        const double ui = u[t.e], uj = u[t.e + 1];
-        const double g = cot ? cot[q] : 0.0, gd = cot_d ? cot_d[q] : 0.0;
+        const Hat t = hat_eval(grid, n, (double)x_eval[q]);
+        const double ui = (double)u[t.e], uj = (double)u[t.e + 1];
+        const double g = cot ? (double)cot[q] : 0.0, gd = cot_d ? (double)cot_d[q] : 0.0;
         const double du = (uj - ui) / t.h;
         if (gu) {
-            unsafeAtomicAdd(&gu[t.e], g * t.N1 - gd / t.h);
-            unsafeAtomicAdd(&gu[t.e + 1], g * t.N2 + gd / t.h);
+            unsafeAtomicAdd(&gu[t.e], (T)(g * t.N1 - gd / t.h));
+            unsafeAtomicAdd(&gu[t.e + 1], (T)(g * t.N2 + gd / t.h));
         }
         if (ggrid) hat_grid_grad(t, g * ui, g * uj, -gd * du / t.h, ggrid);
-        if (gx_eval) gx_eval[q] = g * du;
+        if (gx_eval) gx_eval[q] = (T)(g * du);
     }
 }
 
 // examples/example3.py:27-70 with detached xq,wq (F8): loss += sum wq (E/2 du^2 - b u)
-__global__ __launch_bounds__(kBlockL) void bar_energy_kernel(const double *__restrict__ grid,
-                                                            const double *__restrict__ u, int n,
-                                                            const double *__restrict__ xq,
-                                                            const double *__restrict__ wq,
-                                                            const double *__restrict__ bq, int64_t npts,
-                                                            double E, double *__restrict__ loss,
-                                                            double *__restrict__ ggrid,
-                                                            double *__restrict__ gu) {
+template <typename T>
+__global__ __launch_bounds__(kBlockL) void bar_energy_kernel(const T *__restrict__ grid, const T *__restrict__ u, int n,
+                                                            const T *__restrict__ xq, const T *__restrict__ wq,
+                                                            const T *__restrict__ bq, int64_t npts, double E,
+                                                            T *__restrict__ loss, T *__restrict__ ggrid,
+                                                            T *__restrict__ gu) {
     __shared__ double red[kBlockL / 64];
     double loc = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kBlockL;
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < npts; q += stride) {
-        const Hat t = hat_eval(grid, n, xq[q]);
-        const double ui = u[t.e], uj = u[t.e + 1], w = wq[q], b = bq[q];
+        const Hat t = hat_eval(grid, n, (double)xq[q]);
+        const double ui = (double)u[t.e], uj = (double)u[t.e + 1], w = (double)wq[q], b = (double)bq[q];
         const double uu = ui * t.N1 + uj * t.N2, du = (uj - ui) / t.h;
         loc += w * (0.5 * E * du * du - b * uu);
         const double gdu = w * E * du, guq = -w * b;
         if (gu) {
-            unsafeAtomicAdd(&gu[t.e], guq * t.N1 - gdu / t.h);
-            unsafeAtomicAdd(&gu[t.e + 1], guq * t.N2 + gdu / t.h);
+            unsafeAtomicAdd(&gu[t.e], (T)(guq * t.N1 - gdu / t.h));
+            unsafeAtomicAdd(&gu[t.e + 1], (T)(guq * t.N2 + gdu / t.h));
         }
         if (ggrid) hat_grid_grad(t, guq * ui, guq * uj, -gdu * du / t.h, ggrid);
     }
     const double tot = block_sum(loc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss, tot);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (T)tot);
 }
 
 // examples/example1.py:38: loss += mean((pred - target)^2) and its backward
-__global__ __launch_bounds__(kBlockL) void line2_mse_kernel(const double *__restrict__ grid,
-                                                           const double *__restrict__ u, int n,
-                                                           const double *__restrict__ x_eval,
-                                                           const double *__restrict__ target, int64_t m,
-                                                           double *__restrict__ loss,
-                                                           double *__restrict__ ggrid,
-                                                           double *__restrict__ gu) {
+template <typename T>
+__global__ __launch_bounds__(kBlockL) void line2_mse_kernel(const T *__restrict__ grid, const T *__restrict__ u, int n,
+                                                           const T *__restrict__ x_eval, const T *__restrict__ target,
+                                                           int64_t m, T *__restrict__ loss, T *__restrict__ ggrid,
+                                                           T *__restrict__ gu) {
     __shared__ double red[kBlockL / 64];
     double loc = 0.0;
     const double invm = 1.0 / (double)m;
     const int64_t stride = (int64_t)gridDim.x * kBlockL;
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
-        const Hat t = hat_eval(grid, n, x_eval[q]);
-        const double ui = u[t.e], uj = u[t.e + 1];
-        const double diff = ui * t.N1 + uj * t.N2 - target[q];
+        const Hat t = hat_eval(grid, n, (double)x_eval[q]);
+        const double ui = (double)u[t.e], uj = (double)u[t.e + 1];
+        const double diff = ui * t.N1 + uj * t.N2 - (double)target[q];
         loc += diff * diff;
         const double g = 2.0 * diff * invm;
         if (gu) {
-            unsafeAtomicAdd(&gu[t.e], g * t.N1);
-            unsafeAtomicAdd(&gu[t.e + 1], g * t.N2);
+            unsafeAtomicAdd(&gu[t.e], (T)(g * t.N1));
+            unsafeAtomicAdd(&gu[t.e + 1], (T)(g * t.N2));
         }
         if (ggrid) hat_grid_grad(t, g * ui, g * uj, 0.0, ggrid);
     }
     const double tot = block_sum(loc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss, tot * invm);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (T)(tot * invm));
 }
 
 // ---- RECT-Q4 ---------------------------------------------------------------
+template <typename T> struct Row2;                 // [.][2] rows of the caller's dtype
+template <> struct Row2<double> { typedef double2 type; };
+template <> struct Row2<float> { typedef float2 type; };
+
 struct Q4 {
     Hat x, y;
     double u00, u10, u01, u11;
 };
-__device__ __forceinline__ Q4 q4_eval(const double *__restrict__ gx, int nx, const double *__restrict__ gy,
-                                      int ny, const double *__restrict__ u, double2 pt) {
+template <typename T>
+__device__ __forceinline__ Q4 q4_eval(const T *__restrict__ gx, int nx, const T *__restrict__ gy, int ny,
+                                      const T *__restrict__ u, double px, double py) {
     Q4 c;
-    c.x = hat_eval(gx, nx, pt.x);
-    c.y = hat_eval(gy, ny, pt.y);
+    c.x = hat_eval(gx, nx, px);
+    c.y = hat_eval(gy, ny, py);
     const int64_t b = (int64_t)c.x.e * ny + c.y.e;
-    c.u00 = u[b]; c.u01 = u[b + 1]; c.u10 = u[b + ny]; c.u11 = u[b + ny + 1];   // models.py:197-200
+    c.u00 = (double)u[b]; c.u01 = (double)u[b + 1]; c.u10 = (double)u[b + ny]; c.u11 = (double)u[b + ny + 1];   // models.py:197-200
     return c;
 }
 __device__ __forceinline__ double q4_value(const Q4 &c) {   // models.py:210
     return c.x.N1 * c.y.N1 * c.u00 + c.x.N2 * c.y.N1 * c.u10 + c.x.N1 * c.y.N2 * c.u01 + c.x.N2 * c.y.N2 * c.u11;
 }
-__device__ __forceinline__ void q4_backward(const Q4 &c, double g, int ny, double *__restrict__ ggx,
-                                            double *__restrict__ ggy, double *__restrict__ gu,
-                                            double2 *gpt) {
+template <typename T>
+__device__ __forceinline__ void q4_backward(const Q4 &c, double g, int ny, T *__restrict__ ggx, T *__restrict__ ggy,
+                                            T *__restrict__ gu, double2 *gpt) {
     if (gu) {
         const int64_t b = (int64_t)c.x.e * ny + c.y.e;
-        unsafeAtomicAdd(&gu[b], g * c.x.N1 * c.y.N1);
-        unsafeAtomicAdd(&gu[b + ny], g * c.x.N2 * c.y.N1);
-        unsafeAtomicAdd(&gu[b + 1], g * c.x.N1 * c.y.N2);
-        unsafeAtomicAdd(&gu[b + ny + 1], g * c.x.N2 * c.y.N2);
+        unsafeAtomicAdd(&gu[b], (T)(g * c.x.N1 * c.y.N1));
+        unsafeAtomicAdd(&gu[b + ny], (T)(g * c.x.N2 * c.y.N1));
+        unsafeAtomicAdd(&gu[b + 1], (T)(g * c.x.N1 * c.y.N2));
+        unsafeAtomicAdd(&gu[b + ny + 1], (T)(g * c.x.N2 * c.y.N2));
     }
     const double gN1x = g * (c.y.N1 * c.u00 + c.y.N2 * c.u01), gN2x = g * (c.y.N1 * c.u10 + c.y.N2 * c.u11);
     const double gN1y = g * (c.x.N1 * c.u00 + c.x.N2 * c.u10), gN2y = g * (c.x.N1 * c.u01 + c.x.N2 * c.u11);
@@ -398,45 +410,55 @@ __device__ __forceinline__ void q4_backward(const Q4 &c, double g, int ny, doubl
     if (gpt) *gpt = make_double2((gN2x - gN1x) / c.x.h, (gN2y - gN1y) / c.y.h);
 }
 
-__global__ __launch_bounds__(kBlockL) void rectq4_eval_fwd_kernel(const double *__restrict__ gx, int nx,
-                                                                 const double *__restrict__ gy, int ny,
-                                                                 const double *__restrict__ u,
-                                                                 const double2 *__restrict__ x_eval, int64_t m,
-                                                                 double *__restrict__ pred) {
-    const int64_t stride = (int64_t)gridDim.x * kBlockL;
-    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride)
-        pred[q] = q4_value(q4_eval(gx, nx, gy, ny, u, x_eval[q]));
-}
-
-__global__ __launch_bounds__(kBlockL) void rectq4_eval_bwd_kernel(
-    const double *__restrict__ gx, int nx, const double *__restrict__ gy, int ny, const double *__restrict__ u,
-    const double2 *__restrict__ x_eval, int64_t m, const double *__restrict__ cot, double *__restrict__ ggx,
-    double *__restrict__ ggy, double *__restrict__ gu, double2 *__restrict__ gx_eval) {
+template <typename T>
+__global__ __launch_bounds__(kBlockL) void rectq4_eval_fwd_kernel(const T *__restrict__ gx, int nx, const T *__restrict__ gy,
+                                                                 int ny, const T *__restrict__ u,
+                                                                 const typename Row2<T>::type *__restrict__ x_eval,
+                                                                 int64_t m, T *__restrict__ pred) {
     const int64_t stride = (int64_t)gridDim.x * kBlockL;
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
-        const Q4 c = q4_eval(gx, nx, gy, ny, u, x_eval[q]);
-        double2 gpt;
-        q4_backward(c, cot[q], ny, ggx, ggy, gu, gx_eval ? &gpt : nullptr);
-        if (gx_eval) gx_eval[q] = gpt;
+        const typename Row2<T>::type pt = x_eval[q];
+        pred[q] = (T)q4_value(q4_eval(gx, nx, gy, ny, u, (double)pt.x, (double)pt.y));
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(kBlockL) void rectq4_eval_bwd_kernel(
+    const T *__restrict__ gx, int nx, const T *__restrict__ gy, int ny, const T *__restrict__ u,
+    const typename Row2<T>::type *__restrict__ x_eval, int64_t m, const T *__restrict__ cot, T *__restrict__ ggx,
+    T *__restrict__ ggy, T *__restrict__ gu, typename Row2<T>::type *__restrict__ gx_eval) {
+    const int64_t stride = (int64_t)gridDim.x * kBlockL;
+    for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
+        const typename Row2<T>::type pt = x_eval[q];
+        const Q4 c = q4_eval(gx, nx, gy, ny, u, (double)pt.x, (double)pt.y);
+        double2 gpt;
+        q4_backward(c, (double)cot[q], ny, ggx, ggy, gu, gx_eval ? &gpt : nullptr);
+        if (gx_eval) {
+            typename Row2<T>::type o;
+            o.x = (T)gpt.x; o.y = (T)gpt.y;
+            gx_eval[q] = o;
+        }
+    }
+}
+
+template <typename T>
 __global__ __launch_bounds__(kBlockL) void rectq4_mse_kernel(
-    const double *__restrict__ gx, int nx, const double *__restrict__ gy, int ny, const double *__restrict__ u,
-    const double2 *__restrict__ x_eval, const double *__restrict__ target, int64_t m, double *__restrict__ loss,
-    double *__restrict__ ggx, double *__restrict__ ggy, double *__restrict__ gu) {
+    const T *__restrict__ gx, int nx, const T *__restrict__ gy, int ny, const T *__restrict__ u,
+    const typename Row2<T>::type *__restrict__ x_eval, const T *__restrict__ target, int64_t m, T *__restrict__ loss,
+    T *__restrict__ ggx, T *__restrict__ ggy, T *__restrict__ gu) {
     __shared__ double red[kBlockL / 64];
     double loc = 0.0;
     const double invm = 1.0 / (double)m;
     const int64_t stride = (int64_t)gridDim.x * kBlockL;
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
-        const Q4 c = q4_eval(gx, nx, gy, ny, u, x_eval[q]);
-        const double diff = q4_value(c) - target[q];
+        const typename Row2<T>::type pt = x_eval[q];
+        const Q4 c = q4_eval(gx, nx, gy, ny, u, (double)pt.x, (double)pt.y);
+        const double diff = q4_value(c) - (double)target[q];
         loc += diff * diff;
-        q4_backward(c, 2.0 * diff * invm, ny, ggx, ggy, gu, nullptr);
+        q4_backward(c, 2.0 * diff * invm, ny, ggx, ggy, gu, (double2 *)nullptr);
     }
     const double tot = block_sum(loc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss, tot * invm);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (T)(tot * invm));
 }
 
 static int grid_l(int64_t n) {
@@ -450,36 +472,32 @@ using namespace hfem;
 
 #define HFEM_N_CHECK(n) HFEM_ARG_CHECK((n) >= 2 && (n) < (1ll << 31), "need 2 <= n < 2^31 grid nodes")
 
-extern "C" int hfem_grid_param_fwd(int device, const double *p, int64_t n, double x0, double xN,
-                                   const uint8_t *mask, const double *initial, double *grid, void *stream) {
+// ---- host side: one implementation per entry point, instantiated for double rows (the fp64 ABI) and float rows (the
+//      *_f32 ABI: the reference's default dtype without widening copies; scratch of the workspace forms stays fp64)
+namespace {
+
+template <typename T>
+int grid_param_fwd_impl(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask, const T *initial,
+                        T *grid, void *stream) {
     HFEM_ARG_CHECK(p && grid && n >= 1, "null pointer / empty increments");
     HFEM_ARG_CHECK(!mask || initial, "mask given without initial grid");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(grid_param_fwd_kernel, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask,
-                       initial, grid);
+    hipLaunchKernelGGL(grid_param_fwd_kernel<T>, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask, initial, grid);
     return launch_status("hfem_grid_param_fwd");
 }
 
-extern "C" int hfem_grid_param_bwd(int device, const double *p, int64_t n, double x0, double xN,
-                                   const uint8_t *mask, const double *ggrid, double *gp, void *stream) {
+template <typename T>
+int grid_param_bwd_impl(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask, const T *ggrid, T *gp,
+                        void *stream) {
     HFEM_ARG_CHECK(p && ggrid && gp && n >= 1, "null pointer / empty increments");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(grid_param_bwd_kernel, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask,
-                       ggrid, gp);
+    hipLaunchKernelGGL(grid_param_bwd_kernel<T>, dim3(1), dim3(kScan), 0, (hipStream_t)stream, p, n, x0, xN, mask, ggrid, gp);
     return launch_status("hfem_grid_param_bwd");
 }
 
-// Workspace forms for long grids (three launches each way over all CUs; the forms above are one workgroup):
-// ws holds hfem_grid_param_ws_elems(n) doubles of scratch; cum[n] is an OUTPUT of the forward (the clamped-softplus
-// running sums, cum[n-1] = their total) that the backward reads back.
-extern "C" int64_t hfem_grid_param_ws_elems(int64_t n) {
-    if (n < 1) return 8;
-    const int64_t nb = (n + kGpChunk - 1) / kGpChunk;
-    return n + 2 * nb + 8;
-}
-
-extern "C" int hfem_grid_param_fwd_ws(int device, const double *p, int64_t n, double x0, double xN, const uint8_t *mask,
-                                      const double *initial, double *grid, double *cum, double *ws, void *stream) {
+template <typename T>
+int grid_param_fwd_ws_impl(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask, const T *initial,
+                           T *grid, double *cum, double *ws, void *stream) {
     HFEM_ARG_CHECK(p && grid && cum && ws && n >= 1, "null pointer / empty increments");
     HFEM_ARG_CHECK(!mask || initial, "mask given without initial grid");
     if (int rc = use_device(device)) return rc;
@@ -487,120 +505,185 @@ extern "C" int hfem_grid_param_fwd_ws(int device, const double *p, int64_t n, do
     HFEM_ARG_CHECK(nb <= 2147483647, "grid too long");
     double *bsum = ws, *scal = ws + nb;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gp_fwd_local_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, p, n, cum, bsum);
+    hipLaunchKernelGGL(gp_fwd_local_kernel<T>, dim3((int)nb), dim3(kGpThreads), 0, s, p, n, cum, bsum);
     hipLaunchKernelGGL(gp_block_offsets_kernel, dim3(1), dim3(kScan), 0, s, bsum, nb, false, (const double *)nullptr, scal);
-    hipLaunchKernelGGL(gp_fwd_final_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, n, x0, xN, mask, initial,
+    hipLaunchKernelGGL(gp_fwd_final_kernel<T>, dim3((int)nb), dim3(kGpThreads), 0, s, n, x0, xN, mask, initial,
                        (const double *)bsum, (const double *)scal, cum, grid);
     return launch_status("hfem_grid_param_fwd_ws");
 }
 
-extern "C" int hfem_grid_param_bwd_ws(int device, const double *p, int64_t n, double x0, double xN, const uint8_t *mask,
-                                      const double *ggrid, const double *cum, double *gp, double *ws, void *stream) {
+template <typename T>
+int grid_param_bwd_ws_impl(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask, const T *ggrid,
+                           const double *cum, T *gp, double *ws, void *stream) {
     HFEM_ARG_CHECK(p && ggrid && cum && gp && ws && n >= 1, "null pointer / empty increments");
     if (int rc = use_device(device)) return rc;
     const int64_t nb = (n + kGpChunk - 1) / kGpChunk;
     HFEM_ARG_CHECK(nb <= 2147483647, "grid too long");
     double *suf = ws, *asum = ws + n, *dsum = asum + nb, *scal = dsum + nb;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gp_bwd_local_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, n, xN - x0, mask, ggrid, cum, suf, asum,
+    hipLaunchKernelGGL(gp_bwd_local_kernel<T>, dim3((int)nb), dim3(kGpThreads), 0, s, n, xN - x0, mask, ggrid, cum, suf, asum,
                        dsum);
     hipLaunchKernelGGL(gp_block_offsets_kernel, dim3(1), dim3(kScan), 0, s, asum, nb, true, (const double *)dsum, scal);
-    hipLaunchKernelGGL(gp_bwd_final_kernel, dim3((int)nb), dim3(kGpThreads), 0, s, p, n, xN - x0, cum, (const double *)suf,
+    hipLaunchKernelGGL(gp_bwd_final_kernel<T>, dim3((int)nb), dim3(kGpThreads), 0, s, p, n, xN - x0, cum, (const double *)suf,
                        (const double *)asum, (const double *)scal, gp);
     return launch_status("hfem_grid_param_bwd_ws");
 }
 
-extern "C" int hfem_line2_eval_fwd(int device, const double *grid, const double *u, int64_t n,
-                                   const double *x_eval, int64_t m, double *pred, double *dudx, void *stream) {
+template <typename T>
+int line2_eval_fwd_impl(int device, const T *grid, const T *u, int64_t n, const T *x_eval, int64_t m, T *pred, T *dudx,
+                        void *stream) {
     HFEM_N_CHECK(n);
     HFEM_ARG_CHECK(m >= 0, "negative point count");
     if (m == 0) return 0;
     HFEM_ARG_CHECK(grid && u && x_eval && (pred || dudx), "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(line2_eval_fwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u,
-                       (int)n, x_eval, m, pred, dudx);
+    hipLaunchKernelGGL(line2_eval_fwd_kernel<T>, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u, (int)n,
+                       x_eval, m, pred, dudx);
     return launch_status("hfem_line2_eval_fwd");
 }
 
-extern "C" int hfem_line2_eval_bwd(int device, const double *grid, const double *u, int64_t n,
-                                   const double *x_eval, int64_t m, const double *cot, const double *cot_dudx,
-                                   double *ggrid, double *gu, double *gx_eval, void *stream) {
+template <typename T>
+int line2_eval_bwd_impl(int device, const T *grid, const T *u, int64_t n, const T *x_eval, int64_t m, const T *cot,
+                        const T *cot_dudx, T *ggrid, T *gu, T *gx_eval, void *stream) {
     HFEM_N_CHECK(n);
     HFEM_ARG_CHECK(m >= 0, "negative point count");
     if (m == 0) return 0;
     HFEM_ARG_CHECK(grid && u && x_eval && (cot || cot_dudx), "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(line2_eval_bwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u,
-                       (int)n, x_eval, m, cot, cot_dudx, ggrid, gu, gx_eval);
+    hipLaunchKernelGGL(line2_eval_bwd_kernel<T>, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u, (int)n,
+                       x_eval, m, cot, cot_dudx, ggrid, gu, gx_eval);
     return launch_status("hfem_line2_eval_bwd");
 }
 
-extern "C" int hfem_bar_energy(int device, const double *grid, const double *u, int64_t n, const double *xq,
-                               const double *wq, const double *bq, int64_t npts, double E, double *loss_acc,
-                               double *ggrid, double *gu, void *stream) {
+template <typename T>
+int bar_energy_impl(int device, const T *grid, const T *u, int64_t n, const T *xq, const T *wq, const T *bq, int64_t npts,
+                    double E, T *loss_acc, T *ggrid, T *gu, void *stream) {
     HFEM_N_CHECK(n);
     HFEM_ARG_CHECK(npts >= 0, "negative point count");
     if (npts == 0) return 0;
     HFEM_ARG_CHECK(grid && u && xq && wq && bq && loss_acc, "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(bar_energy_kernel, dim3(grid_l(npts)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u,
-                       (int)n, xq, wq, bq, npts, E, loss_acc, ggrid, gu);
+    hipLaunchKernelGGL(bar_energy_kernel<T>, dim3(grid_l(npts)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u, (int)n, xq,
+                       wq, bq, npts, E, loss_acc, ggrid, gu);
     return launch_status("hfem_bar_energy");
 }
 
-extern "C" int hfem_line2_mse(int device, const double *grid, const double *u, int64_t n, const double *x_eval,
-                              const double *target, int64_t m, double *loss_acc, double *ggrid, double *gu,
-                              void *stream) {
+template <typename T>
+int line2_mse_impl(int device, const T *grid, const T *u, int64_t n, const T *x_eval, const T *target, int64_t m, T *loss_acc,
+                   T *ggrid, T *gu, void *stream) {
     HFEM_N_CHECK(n);
     HFEM_ARG_CHECK(m >= 1, "need at least one point (mean of an empty set)");
     HFEM_ARG_CHECK(grid && u && x_eval && target && loss_acc, "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(line2_mse_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u, (int)n,
-                       x_eval, target, m, loss_acc, ggrid, gu);
+    hipLaunchKernelGGL(line2_mse_kernel<T>, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, grid, u, (int)n, x_eval,
+                       target, m, loss_acc, ggrid, gu);
     return launch_status("hfem_line2_mse");
 }
 
-extern "C" int hfem_rectq4_eval_fwd(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
-                                    const double *u, const double *x_eval, int64_t m, double *pred,
-                                    void *stream) {
+template <typename T>
+int rectq4_eval_fwd_impl(int device, const T *gx, int64_t nx, const T *gy, int64_t ny, const T *u, const T *x_eval, int64_t m,
+                         T *pred, void *stream) {
     HFEM_N_CHECK(nx);
     HFEM_N_CHECK(ny);
     HFEM_ARG_CHECK(m >= 0, "negative point count");
     if (m == 0) return 0;
     HFEM_ARG_CHECK(gx && gy && u && x_eval && pred, "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(rectq4_eval_fwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx,
-                       (int)nx, gy, (int)ny, u, (const double2 *)x_eval, m, pred);
+    hipLaunchKernelGGL(rectq4_eval_fwd_kernel<T>, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx, (int)nx, gy,
+                       (int)ny, u, (const typename Row2<T>::type *)x_eval, m, pred);
     return launch_status("hfem_rectq4_eval_fwd");
 }
 
-extern "C" int hfem_rectq4_eval_bwd(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
-                                    const double *u, const double *x_eval, int64_t m, const double *cot,
-                                    double *ggx, double *ggy, double *gu, double *gx_eval, void *stream) {
+template <typename T>
+int rectq4_eval_bwd_impl(int device, const T *gx, int64_t nx, const T *gy, int64_t ny, const T *u, const T *x_eval, int64_t m,
+                         const T *cot, T *ggx, T *ggy, T *gu, T *gx_eval, void *stream) {
     HFEM_N_CHECK(nx);
     HFEM_N_CHECK(ny);
     HFEM_ARG_CHECK(m >= 0, "negative point count");
     if (m == 0) return 0;
     HFEM_ARG_CHECK(gx && gy && u && x_eval && cot, "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(rectq4_eval_bwd_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx,
-                       (int)nx, gy, (int)ny, u, (const double2 *)x_eval, m, cot, ggx, ggy, gu,
-                       (double2 *)gx_eval);
+    hipLaunchKernelGGL(rectq4_eval_bwd_kernel<T>, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx, (int)nx, gy,
+                       (int)ny, u, (const typename Row2<T>::type *)x_eval, m, cot, ggx, ggy, gu,
+                       (typename Row2<T>::type *)gx_eval);
     return launch_status("hfem_rectq4_eval_bwd");
 }
 
-extern "C" int hfem_rectq4_mse(int device, const double *gx, int64_t nx, const double *gy, int64_t ny,
-                               const double *u, const double *x_eval, const double *target, int64_t m,
-                               double *loss_acc, double *ggx, double *ggy, double *gu, void *stream) {
+template <typename T>
+int rectq4_mse_impl(int device, const T *gx, int64_t nx, const T *gy, int64_t ny, const T *u, const T *x_eval, const T *target,
+                    int64_t m, T *loss_acc, T *ggx, T *ggy, T *gu, void *stream) {
     HFEM_N_CHECK(nx);
     HFEM_N_CHECK(ny);
     HFEM_ARG_CHECK(m >= 1, "need at least one point (mean of an empty set)");
     HFEM_ARG_CHECK(gx && gy && u && x_eval && target && loss_acc, "null pointer");
     if (int rc = use_device(device)) return rc;
-    hipLaunchKernelGGL(rectq4_mse_kernel, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx, (int)nx, gy,
-                       (int)ny, u, (const double2 *)x_eval, target, m, loss_acc, ggx, ggy, gu);
+    hipLaunchKernelGGL(rectq4_mse_kernel<T>, dim3(grid_l(m)), dim3(kBlockL), 0, (hipStream_t)stream, gx, (int)nx, gy, (int)ny,
+                       u, (const typename Row2<T>::type *)x_eval, target, m, loss_acc, ggx, ggy, gu);
     return launch_status("hfem_rectq4_mse");
 }
+
+}  // namespace
+
+// Workspace forms for long grids (three launches each way over all CUs; the forms without _ws are one workgroup):
+// ws holds hfem_grid_param_ws_elems(n) doubles of scratch; cum[n] is an OUTPUT of the forward (the clamped-softplus
+// running sums, cum[n-1] = their total) that the backward reads back.  Both stay fp64 in the _f32 forms.
+extern "C" int64_t hfem_grid_param_ws_elems(int64_t n) {
+    if (n < 1) return 8;
+    const int64_t nb = (n + kGpChunk - 1) / kGpChunk;
+    return n + 2 * nb + 8;
+}
+
+#define HFEM_ROW_ABI(SUFFIX, T)                                                                                                  \
+    extern "C" int hfem_grid_param_fwd##SUFFIX(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask,       \
+                                               const T *initial, T *grid, void *stream) {                                         \
+        return grid_param_fwd_impl<T>(device, p, n, x0, xN, mask, initial, grid, stream);                                        \
+    }                                                                                                                            \
+    extern "C" int hfem_grid_param_bwd##SUFFIX(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask,       \
+                                               const T *ggrid, T *gp, void *stream) {                                             \
+        return grid_param_bwd_impl<T>(device, p, n, x0, xN, mask, ggrid, gp, stream);                                            \
+    }                                                                                                                            \
+    extern "C" int hfem_grid_param_fwd_ws##SUFFIX(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask,    \
+                                                  const T *initial, T *grid, double *cum, double *ws, void *stream) {             \
+        return grid_param_fwd_ws_impl<T>(device, p, n, x0, xN, mask, initial, grid, cum, ws, stream);                            \
+    }                                                                                                                            \
+    extern "C" int hfem_grid_param_bwd_ws##SUFFIX(int device, const T *p, int64_t n, double x0, double xN, const uint8_t *mask,    \
+                                                  const T *ggrid, const double *cum, T *gp, double *ws, void *stream) {           \
+        return grid_param_bwd_ws_impl<T>(device, p, n, x0, xN, mask, ggrid, cum, gp, ws, stream);                                \
+    }                                                                                                                            \
+    extern "C" int hfem_line2_eval_fwd##SUFFIX(int device, const T *grid, const T *u, int64_t n, const T *x_eval, int64_t m,       \
+                                               T *pred, T *dudx, void *stream) {                                                  \
+        return line2_eval_fwd_impl<T>(device, grid, u, n, x_eval, m, pred, dudx, stream);                                        \
+    }                                                                                                                            \
+    extern "C" int hfem_line2_eval_bwd##SUFFIX(int device, const T *grid, const T *u, int64_t n, const T *x_eval, int64_t m,       \
+                                               const T *cot, const T *cot_dudx, T *ggrid, T *gu, T *gx_eval, void *stream) {      \
+        return line2_eval_bwd_impl<T>(device, grid, u, n, x_eval, m, cot, cot_dudx, ggrid, gu, gx_eval, stream);                 \
+    }                                                                                                                            \
+    extern "C" int hfem_bar_energy##SUFFIX(int device, const T *grid, const T *u, int64_t n, const T *xq, const T *wq,             \
+                                           const T *bq, int64_t npts, double E, T *loss_acc, T *ggrid, T *gu, void *stream) {     \
+        return bar_energy_impl<T>(device, grid, u, n, xq, wq, bq, npts, E, loss_acc, ggrid, gu, stream);                         \
+    }                                                                                                                            \
+    extern "C" int hfem_line2_mse##SUFFIX(int device, const T *grid, const T *u, int64_t n, const T *x_eval, const T *target,      \
+                                          int64_t m, T *loss_acc, T *ggrid, T *gu, void *stream) {                                \
+        return line2_mse_impl<T>(device, grid, u, n, x_eval, target, m, loss_acc, ggrid, gu, stream);                            \
+    }                                                                                                                            \
+    extern "C" int hfem_rectq4_eval_fwd##SUFFIX(int device, const T *gx, int64_t nx, const T *gy, int64_t ny, const T *u,          \
+                                                const T *x_eval, int64_t m, T *pred, void *stream) {                              \
+        return rectq4_eval_fwd_impl<T>(device, gx, nx, gy, ny, u, x_eval, m, pred, stream);                                      \
+    }                                                                                                                            \
+    extern "C" int hfem_rectq4_eval_bwd##SUFFIX(int device, const T *gx, int64_t nx, const T *gy, int64_t ny, const T *u,          \
+                                                const T *x_eval, int64_t m, const T *cot, T *ggx, T *ggy, T *gu, T *gx_eval,      \
+                                                void *stream) {                                                                  \
+        return rectq4_eval_bwd_impl<T>(device, gx, nx, gy, ny, u, x_eval, m, cot, ggx, ggy, gu, gx_eval, stream);                \
+    }                                                                                                                            \
+    extern "C" int hfem_rectq4_mse##SUFFIX(int device, const T *gx, int64_t nx, const T *gy, int64_t ny, const T *u,               \
+                                           const T *x_eval, const T *target, int64_t m, T *loss_acc, T *ggx, T *ggy, T *gu,       \
+                                           void *stream) {                                                                       \
+        return rectq4_mse_impl<T>(device, gx, nx, gy, ny, u, x_eval, target, m, loss_acc, ggx, ggy, gu, stream);                 \
+    }
+
+HFEM_ROW_ABI(, double)
+HFEM_ROW_ABI(_f32, float)
+#undef HFEM_ROW_ABI
 
 extern "C" int hfem_version(void) { return HFEM_VERSION; }
 extern "C" const char *hfem_last_error(void) { return hfem::get_error(); }

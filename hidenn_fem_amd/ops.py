@@ -2,8 +2,11 @@
 
 PyTorch tensors are only the container (device memory, streams, autograd
 bookkeeping); every number is produced by a hand-written gfx950 kernel.  All
-kernels compute in fp64; fp32 callers are widened on the way in and narrowed on
-the way out.  Nothing here runs on CPU tensors.
+kernels compute in fp64.  fp32 callers (the reference's default dtype) use the
+float-row entry points where they exist -- the tiled TRI3 energy and every 1D /
+structured op: rows are widened on load and rounded once on store, no copies --
+and are widened on the way in / narrowed on the way out elsewhere.  Nothing here
+runs on CPU tensors.
 """
 from __future__ import annotations
 
@@ -27,6 +30,32 @@ def _f64(t, name):
     if t.dtype != F64:
         t = t.to(F64)
     return t.contiguous()
+
+
+F32 = torch.float32
+
+
+def _as(t, name, dtype):
+    """Contiguous ROCm tensor of ``dtype`` (no copy when it already is one)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        require_gpu_tensor(t, name, dtype=None)
+    t = t.detach()
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _rows(*pairs):
+    """-> (ABI suffix, working dtype, tensors) for the 1D / structured ops: when every tensor is float32 (the
+    reference's default dtype, src/models.py:36-40, 142) the float-row entry points (``*_f32``: widened on load,
+    rounded once on store, fp64 arithmetic inside) take them as they are -- no widening copies; any other mix goes
+    through the fp64 entry points."""
+    ts = [t for t, _ in pairs if t is not None]
+    if ts and all(t.dtype == F32 for t in ts):
+        return "_f32", F32, [_as(t, name, F32) for t, name in pairs]
+    return "", F64, [_f64(t, name) for t, name in pairs]
 
 
 def _dvec(vals):
@@ -197,40 +226,41 @@ class GridParamFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, x0, xN, mask_u8, initial):
         dev = p.device
-        pd = _f64(p, "increments")
+        suf, dt, (pd, init) = _rows((p, "increments"), (initial, "initial grid"))
         n = pd.shape[0]
-        grid = torch.empty((n + 1,), dtype=F64, device=dev)
-        init = _f64(initial, "initial grid")
+        grid = torch.empty((n + 1,), dtype=dt, device=dev)
         L = _lib.lib()
         if n > GRID_PARAM_ONE_BLOCK:                  # long grids: three small launches over all CUs
-            cum = torch.empty(n, dtype=F64, device=dev)
+            cum = torch.empty(n, dtype=F64, device=dev)                       # scratch stays fp64 in both ABIs
             ws = torch.empty(L.hfem_grid_param_ws_elems(n), dtype=F64, device=dev)
-            check(L.hfem_grid_param_fwd_ws(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8), ptr(init),
-                                           ptr(grid), ptr(cum), ptr(ws), stream_ptr(dev)), "hfem_grid_param_fwd_ws")
+            check(getattr(L, "hfem_grid_param_fwd_ws" + suf)(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8),
+                                                             ptr(init), ptr(grid), ptr(cum), ptr(ws), stream_ptr(dev)),
+                  "hfem_grid_param_fwd_ws")
             ctx.save_for_backward(pd, cum)
         else:
-            check(L.hfem_grid_param_fwd(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8), ptr(init),
-                                        ptr(grid), stream_ptr(dev)), "hfem_grid_param_fwd")
+            check(getattr(L, "hfem_grid_param_fwd" + suf)(dev_index(dev), ptr(pd), n, float(x0), float(xN), ptr(mask_u8),
+                                                          ptr(init), ptr(grid), stream_ptr(dev)), "hfem_grid_param_fwd")
             ctx.save_for_backward(pd)
-        ctx.mask, ctx.x0, ctx.xN, ctx.dt = mask_u8, float(x0), float(xN), p.dtype
-        return grid.to(p.dtype) if p.dtype != F64 else grid
+        ctx.mask, ctx.x0, ctx.xN, ctx.dt, ctx.suf = mask_u8, float(x0), float(xN), p.dtype, suf
+        return grid if grid.dtype == p.dtype else grid.to(p.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gg):
         pd = ctx.saved_tensors[0]
-        dev = pd.device
+        dev, suf = pd.device, ctx.suf
         gp = torch.empty_like(pd)
+        ggd = _as(gg, "ggrid", pd.dtype)
+        L, n = _lib.lib(), pd.shape[0]
         if len(ctx.saved_tensors) == 2:
-            L, n = _lib.lib(), pd.shape[0]
             ws = torch.empty(L.hfem_grid_param_ws_elems(n), dtype=F64, device=dev)
-            check(L.hfem_grid_param_bwd_ws(dev_index(dev), ptr(pd), n, ctx.x0, ctx.xN, ptr(ctx.mask), ptr(_f64(gg, "ggrid")),
-                                           ptr(ctx.saved_tensors[1]), ptr(gp), ptr(ws), stream_ptr(dev)),
+            check(getattr(L, "hfem_grid_param_bwd_ws" + suf)(dev_index(dev), ptr(pd), n, ctx.x0, ctx.xN, ptr(ctx.mask), ptr(ggd),
+                                                             ptr(ctx.saved_tensors[1]), ptr(gp), ptr(ws), stream_ptr(dev)),
                   "hfem_grid_param_bwd_ws")
-            return gp.to(ctx.dt), None, None, None, None
-        check(_lib.lib().hfem_grid_param_bwd(dev_index(dev), ptr(pd), pd.shape[0], ctx.x0, ctx.xN, ptr(ctx.mask),
-                                             ptr(_f64(gg, "ggrid")), ptr(gp), stream_ptr(dev)), "hfem_grid_param_bwd")
-        return gp.to(ctx.dt), None, None, None, None
+        else:
+            check(getattr(L, "hfem_grid_param_bwd" + suf)(dev_index(dev), ptr(pd), n, ctx.x0, ctx.xN, ptr(ctx.mask), ptr(ggd),
+                                                          ptr(gp), stream_ptr(dev)), "hfem_grid_param_bwd")
+        return (gp if gp.dtype == ctx.dt else gp.to(ctx.dt)), None, None, None, None
 
 
 class Line2EvalFn(torch.autograd.Function):
@@ -244,33 +274,33 @@ class Line2EvalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid, u_full, x_eval):
         dev = grid.device
-        gd, ud, xd = _f64(grid, "grid"), _f64(u_full, "u_full"), _f64(x_eval.reshape(-1), "x_eval")
+        suf, dt, (gd, ud, xd) = _rows((grid, "grid"), (u_full, "u_full"), (x_eval.reshape(-1), "x_eval"))
         m = xd.shape[0]
-        pred = torch.empty((m,), dtype=F64, device=dev)
-        dudx = torch.empty((m,), dtype=F64, device=dev)
-        check(_lib.lib().hfem_line2_eval_fwd(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), m, ptr(pred),
-                                             ptr(dudx), stream_ptr(dev)), "hfem_line2_eval_fwd")
+        pred = torch.empty((m,), dtype=dt, device=dev)
+        dudx = torch.empty((m,), dtype=dt, device=dev)
+        check(getattr(_lib.lib(), "hfem_line2_eval_fwd" + suf)(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), m,
+                                                               ptr(pred), ptr(dudx), stream_ptr(dev)), "hfem_line2_eval_fwd")
         ctx.save_for_backward(grid, u_full, x_eval)
         ctx.dt = grid.dtype
         shp = x_eval.shape
         pred, dudx = pred.reshape(shp), dudx.reshape(shp)
-        return (pred.to(grid.dtype), dudx.to(grid.dtype)) if grid.dtype != F64 else (pred, dudx)
+        return (pred, dudx) if dt == grid.dtype else (pred.to(grid.dtype), dudx.to(grid.dtype))
 
     @staticmethod
     def backward(ctx, g_pred, g_dudx):
         grid, u_full, x_eval = ctx.saved_tensors
         dev = grid.device
-        gd, ud, xd = _f64(grid, "grid"), _f64(u_full, "u_full"), _f64(x_eval.reshape(-1), "x_eval")
+        suf, dt, (gd, ud, xd, cp, cdd) = _rows((grid, "grid"), (u_full, "u_full"), (x_eval.reshape(-1), "x_eval"),
+                                               (None if g_pred is None else g_pred.reshape(-1), "g_pred"),
+                                               (None if g_dudx is None else g_dudx.reshape(-1), "g_dudx"))
         m = xd.shape[0]
         ggrid = torch.zeros_like(gd) if ctx.needs_input_grad[0] else None     # only what autograd asks for
         gu = torch.zeros_like(ud) if ctx.needs_input_grad[1] else None
         gx = torch.empty_like(xd) if ctx.needs_input_grad[2] else None
-        cp = None if g_pred is None else _f64(g_pred.reshape(-1), "g_pred")
-        cdd = None if g_dudx is None else _f64(g_dudx.reshape(-1), "g_dudx")
         if cp is None and cdd is None:
             return None, None, None
-        check(_lib.lib().hfem_line2_eval_bwd(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), m, ptr(cp),
-                                             ptr(cdd), ptr(ggrid), ptr(gu), ptr(gx), stream_ptr(dev)),
+        check(getattr(_lib.lib(), "hfem_line2_eval_bwd" + suf)(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), m, ptr(cp),
+                                                               ptr(cdd), ptr(ggrid), ptr(gu), ptr(gx), stream_ptr(dev)),
               "hfem_line2_eval_bwd")
         gxe = None
         if gx is not None:
@@ -291,22 +321,22 @@ class BarEnergyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid, u_full, xq, wq, bq, E):
         dev = grid.device
-        gd, ud = _f64(grid, "grid"), _f64(u_full, "u_full")
-        xqd, wqd, bqd = (_f64(t.reshape(-1), n) for t, n in ((xq, "xq"), (wq, "wq"), (bq, "bq")))
-        loss = torch.zeros((), dtype=F64, device=dev)
+        suf, dt, (gd, ud, xqd, wqd, bqd) = _rows((grid, "grid"), (u_full, "u_full"), (xq.reshape(-1), "xq"),
+                                                 (wq.reshape(-1), "wq"), (bq.reshape(-1), "bq"))
+        loss = torch.zeros((), dtype=dt, device=dev)
         ggrid, gu = torch.zeros_like(gd), torch.zeros_like(ud)
-        check(_lib.lib().hfem_bar_energy(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xqd), ptr(wqd), ptr(bqd),
-                                         xqd.shape[0], float(E), ptr(loss), ptr(ggrid), ptr(gu), stream_ptr(dev)),
-              "hfem_bar_energy")
+        check(getattr(_lib.lib(), "hfem_bar_energy" + suf)(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xqd), ptr(wqd),
+                                                           ptr(bqd), xqd.shape[0], float(E), ptr(loss), ptr(ggrid), ptr(gu),
+                                                           stream_ptr(dev)), "hfem_bar_energy")
         ctx.unit, ctx.dts = (ggrid, gu), (grid.dtype, u_full.dtype)
-        return loss.to(grid.dtype) if grid.dtype != F64 else loss
+        return loss if loss.dtype == grid.dtype else loss.to(grid.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         ggrid, gu = ctx.unit
-        g64 = g.to(F64)
-        return (ggrid * g64).to(ctx.dts[0]), (gu * g64).to(ctx.dts[1]), None, None, None, None
+        gg = g.to(ggrid.dtype)
+        return (ggrid * gg).to(ctx.dts[0]), (gu * gg).to(ctx.dts[1]), None, None, None, None
 
 
 class Line2MseFn(torch.autograd.Function):
@@ -315,23 +345,23 @@ class Line2MseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid, u_full, x_eval, target):
         dev = grid.device
-        gd, ud = _f64(grid, "grid"), _f64(u_full, "u_full")
-        xd, td = _f64(x_eval.reshape(-1), "x_eval"), _f64(target.reshape(-1), "target")
-        loss = torch.zeros((), dtype=F64, device=dev)
+        suf, dt, (gd, ud, xd, td) = _rows((grid, "grid"), (u_full, "u_full"), (x_eval.reshape(-1), "x_eval"),
+                                          (target.reshape(-1), "target"))
+        loss = torch.zeros((), dtype=dt, device=dev)
         ggrid = torch.zeros_like(gd) if ctx.needs_input_grad[0] else None       # fixed grid: no grid-gradient atomics
         gu = torch.zeros_like(ud) if ctx.needs_input_grad[1] else None
-        check(_lib.lib().hfem_line2_mse(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), ptr(td), xd.shape[0],
-                                        ptr(loss), ptr(ggrid), ptr(gu), stream_ptr(dev)), "hfem_line2_mse")
+        check(getattr(_lib.lib(), "hfem_line2_mse" + suf)(dev_index(dev), ptr(gd), ptr(ud), gd.shape[0], ptr(xd), ptr(td),
+                                                          xd.shape[0], ptr(loss), ptr(ggrid), ptr(gu), stream_ptr(dev)),
+              "hfem_line2_mse")
         ctx.unit, ctx.dts = (ggrid, gu), (grid.dtype, u_full.dtype)
-        return loss.to(grid.dtype) if grid.dtype != F64 else loss
+        return loss if loss.dtype == grid.dtype else loss.to(grid.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         ggrid, gu = ctx.unit
-        g64 = g.to(F64)
-        return (None if ggrid is None else (ggrid * g64).to(ctx.dts[0]),
-                None if gu is None else (gu * g64).to(ctx.dts[1]), None, None)
+        return (None if ggrid is None else (ggrid * g.to(ggrid.dtype)).to(ctx.dts[0]),
+                None if gu is None else (gu * g.to(gu.dtype)).to(ctx.dts[1]), None, None)
 
 
 class RectQ4EvalFn(torch.autograd.Function):
@@ -340,14 +370,15 @@ class RectQ4EvalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, gy, u_full, x_eval):
         dev = gx.device
-        gxd, gyd, ud, xd = _f64(gx, "grid_x"), _f64(gy, "grid_y"), _f64(u_full, "u_full"), _f64(x_eval, "x_eval")
+        suf, dt, (gxd, gyd, ud, xd) = _rows((gx, "grid_x"), (gy, "grid_y"), (u_full, "u_full"), (x_eval, "x_eval"))
         m = xd.shape[0]
-        pred = torch.empty((m,), dtype=F64, device=dev)
-        check(_lib.lib().hfem_rectq4_eval_fwd(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
-                                              ptr(xd), m, ptr(pred), stream_ptr(dev)), "hfem_rectq4_eval_fwd")
+        pred = torch.empty((m,), dtype=dt, device=dev)
+        check(getattr(_lib.lib(), "hfem_rectq4_eval_fwd" + suf)(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0],
+                                                                ptr(ud), ptr(xd), m, ptr(pred), stream_ptr(dev)),
+              "hfem_rectq4_eval_fwd")
         ctx.save_for_backward(gxd, gyd, ud, xd)
-        ctx.dts = (gx.dtype, gy.dtype, u_full.dtype, x_eval.dtype)
-        return pred.to(u_full.dtype) if u_full.dtype != F64 else pred
+        ctx.dts, ctx.suf = (gx.dtype, gy.dtype, u_full.dtype, x_eval.dtype), suf
+        return pred if pred.dtype == u_full.dtype else pred.to(u_full.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -358,9 +389,10 @@ class RectQ4EvalFn(torch.autograd.Function):
         ggy = torch.zeros_like(gyd) if ctx.needs_input_grad[1] else None
         gu = torch.zeros_like(ud) if ctx.needs_input_grad[2] else None
         gxe = torch.empty_like(xd) if ctx.needs_input_grad[3] else None
-        check(_lib.lib().hfem_rectq4_eval_bwd(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
-                                              ptr(xd), xd.shape[0], ptr(_f64(g, "grad")), ptr(ggx), ptr(ggy), ptr(gu),
-                                              ptr(gxe), stream_ptr(dev)), "hfem_rectq4_eval_bwd")
+        check(getattr(_lib.lib(), "hfem_rectq4_eval_bwd" + ctx.suf)(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0],
+                                                                    ptr(ud), ptr(xd), xd.shape[0], ptr(_as(g, "grad", ud.dtype)),
+                                                                    ptr(ggx), ptr(ggy), ptr(gu), ptr(gxe), stream_ptr(dev)),
+              "hfem_rectq4_eval_bwd")
         d = ctx.dts
         return tuple(None if t is None else t.to(dt) for t, dt in zip((ggx, ggy, gu, gxe), d))
 
@@ -371,25 +403,24 @@ class RectQ4MseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, gy, u_full, x_eval, target):
         dev = gx.device
-        gxd, gyd, ud = _f64(gx, "grid_x"), _f64(gy, "grid_y"), _f64(u_full, "u_full")
-        xd, td = _f64(x_eval, "x_eval"), _f64(target.reshape(-1), "target")
-        loss = torch.zeros((), dtype=F64, device=dev)
+        suf, dt, (gxd, gyd, ud, xd, td) = _rows((gx, "grid_x"), (gy, "grid_y"), (u_full, "u_full"), (x_eval, "x_eval"),
+                                                (target.reshape(-1), "target"))
+        loss = torch.zeros((), dtype=dt, device=dev)
         # only the gradients somebody asked for: with fixed nodes the grid gradients are M x 4 atomics onto a few
         # hundred addresses (most of the kernel's time at M = 262 144) for nothing
         ggx = torch.zeros_like(gxd) if ctx.needs_input_grad[0] else None
         ggy = torch.zeros_like(gyd) if ctx.needs_input_grad[1] else None
         gu = torch.zeros_like(ud) if ctx.needs_input_grad[2] else None
-        check(_lib.lib().hfem_rectq4_mse(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
-                                         ptr(xd), ptr(td), xd.shape[0], ptr(loss), ptr(ggx), ptr(ggy), ptr(gu),
-                                         stream_ptr(dev)), "hfem_rectq4_mse")
+        check(getattr(_lib.lib(), "hfem_rectq4_mse" + suf)(dev_index(dev), ptr(gxd), gxd.shape[0], ptr(gyd), gyd.shape[0], ptr(ud),
+                                                           ptr(xd), ptr(td), xd.shape[0], ptr(loss), ptr(ggx), ptr(ggy), ptr(gu),
+                                                           stream_ptr(dev)), "hfem_rectq4_mse")
         ctx.unit, ctx.dts = (ggx, ggy, gu), (gx.dtype, gy.dtype, u_full.dtype)
-        return loss.to(u_full.dtype) if u_full.dtype != F64 else loss
+        return loss if loss.dtype == u_full.dtype else loss.to(u_full.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        g64 = g.to(F64)
-        return tuple(None if t is None else (t * g64).to(dt) for t, dt in zip(ctx.unit, ctx.dts)) + (None, None)
+        return tuple(None if t is None else (t * g.to(t.dtype)).to(dt) for t, dt in zip(ctx.unit, ctx.dts)) + (None, None)
 
 
 # ---------------------------------------------------------------- QUAD4-iso extension (planless)

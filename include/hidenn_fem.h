@@ -403,6 +403,36 @@ int hfem_rectq4_mse(int device, const double *gx, int64_t nx, const double *gy, 
                     const double *u, const double *x_eval, const double *target, int64_t m,
                     double *loss_acc, double *ggx, double *ggy, double *gu, void *stream);
 
+/* Float-row twins of the 1D / structured entry points above, for models in the reference's default dtype
+ * (torch.float32: src/models.py:36-40, 142; examples 1-3 as shipped): every array argument is float -- parameters,
+ * points, targets, per-point outputs, gradient accumulators (float atomics) and the loss scalar; rows are widened on
+ * load and rounded once on store, the arithmetic in between is fp64, exactly as hfem_tri3_energy_plan_f32 does.
+ * No widening copies on either side of the call.  The scratch of the *_ws forms (cum, ws) stays fp64.           */
+int hfem_grid_param_fwd_f32(int device, const float *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                            const float *initial, float *grid, void *stream);
+int hfem_grid_param_bwd_f32(int device, const float *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                            const float *ggrid, float *gp, void *stream);
+int hfem_grid_param_fwd_ws_f32(int device, const float *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                               const float *initial, float *grid, double *cum, double *ws, void *stream);
+int hfem_grid_param_bwd_ws_f32(int device, const float *p, int64_t n, double x0, double xN, const uint8_t *mask,
+                               const float *ggrid, const double *cum, float *gp, double *ws, void *stream);
+int hfem_line2_eval_fwd_f32(int device, const float *grid, const float *u, int64_t n, const float *x_eval, int64_t m,
+                            float *pred, float *dudx, void *stream);
+int hfem_line2_eval_bwd_f32(int device, const float *grid, const float *u, int64_t n, const float *x_eval, int64_t m,
+                            const float *cot, const float *cot_dudx, float *ggrid, float *gu, float *gx_eval, void *stream);
+int hfem_bar_energy_f32(int device, const float *grid, const float *u, int64_t n, const float *xq, const float *wq,
+                        const float *bq, int64_t npts, double E, float *loss_acc, float *ggrid, float *gu, void *stream);
+int hfem_line2_mse_f32(int device, const float *grid, const float *u, int64_t n, const float *x_eval, const float *target,
+                       int64_t m, float *loss_acc, float *ggrid, float *gu, void *stream);
+int hfem_rectq4_eval_fwd_f32(int device, const float *gx, int64_t nx, const float *gy, int64_t ny, const float *u,
+                             const float *x_eval, int64_t m, float *pred, void *stream);
+int hfem_rectq4_eval_bwd_f32(int device, const float *gx, int64_t nx, const float *gy, int64_t ny, const float *u,
+                             const float *x_eval, int64_t m, const float *cot, float *ggx, float *ggy, float *gu,
+                             float *gx_eval, void *stream);
+int hfem_rectq4_mse_f32(int device, const float *gx, int64_t nx, const float *gy, int64_t ny, const float *u,
+                        const float *x_eval, const float *target, int64_t m, float *loss_acc, float *ggx, float *ggy,
+                        float *gu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

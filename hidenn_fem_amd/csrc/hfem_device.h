@@ -103,7 +103,6 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
     const double b = PHYS ? X0.y - X2.y : X1.x - X2.x, c = PHYS ? X1.x - X2.x : X0.y - X2.y;
     const double det = a * d - b * c;
     const double inv = fast_rcp(det);
-    const double A = fabs(det);
     const double ai = a * inv, bi = b * inv, ci = c * inv, di = d * inv;      // rows of Jinv (up to sign/placement)
     const double g0x = U0.x - U2.x, g0y = U0.y - U2.y;
     const double g1x = U1.x - U2.x, g1y = U1.y - U2.y;
@@ -113,15 +112,20 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
     const double sxx = k.c11 * h00 + k.c12 * h11;
     const double syy = k.c12 * h00 + k.c22 * h11;
     const double sxy = k.c33 * gam;
-    const double wpsi = (0.5 * k.W) * (h00 * sxx + h11 * syy + gam * sxy);   // W psi
-    double dens = wpsi;
-    double beta = 0.0;
+    const double hs = h00 * sxx + h11 * syy + gam * sxy;                      // h : sigma = 2 psi
+    // |det| and sign(det) enter only through sW = W sign(det) (one v_bfi on the high word): A W = det sW,
+    // A W psi = (det sW / 2) hs, -sign(det) W psi = (-sW / 2) hs.  No compare / select chain (round-2 VALU trimming).
+    const double sW = __builtin_copysign(k.W, det);
+    const double aw = det * sW;                                               // A W
+    double e = (0.5 * aw) * hs;                                               // A W psi
+    double beta = 0.0, A = 0.0, sgn = 0.0;
     if (HASB) {
+        A = fabs(det);
+        sgn = __builtin_copysign(1.0, det);
         beta = U0.x * k.Bk[0] + U0.y * k.Bk[1] + U1.x * k.Bk[2] + U1.y * k.Bk[3] + U2.x * k.Bk[4] + U2.y * k.Bk[5];
-        dens -= beta;
+        e -= A * beta;
     }
     if (GRAD) {
-        const double aw = A * k.W;
         const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;         // P = dL/dH (P10 = P01)
         const double dg0x = p00 * di - p01 * ci, dg0y = p01 * di - p11 * ci;
         const double dg1x = p01 * ai - p00 * bi, dg1y = p11 * ai - p01 * bi;
@@ -134,9 +138,9 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
             gu[1] = make_double2(dg1x, dg1y);
             gu[2] = make_double2(-dg0x - dg1x, -dg0y - dg1y);
         }
-        const double q = det < 0.0 ? -k.W : k.W;                              // W sign(det) = A W / det
-        const double wb = HASB ? wpsi + beta : wpsi;
-        const double ddet = det < 0.0 ? wb : -wb;                             // -sign(det) (W psi + beta)
+        const double q = sW;                                                  // W sign(det) = A W / det
+        double ddet = (-0.5 * sW) * hs;                                       // -sign(det) W psi
+        if (HASB) ddet -= sgn * beta;                                         // -sign(det) (W psi + beta)
         const double da = q * (sxy * g1x + syy * g1y) + ddet * d;
         const double db = -q * (sxx * g1x + sxy * g1y) - ddet * c;
         const double dc = -q * (sxy * g0x + syy * g0y) - ddet * b;
@@ -145,7 +149,7 @@ __device__ __forceinline__ double tri3_element(const double2 X0, const double2 X
         gx[1] = PHYS ? make_double2(dc, dd) : make_double2(db, dd);
         gx[2] = PHYS ? make_double2(-da - dc, -db - dd) : make_double2(-da - db, -dc - dd);
     }
-    return A * dens;
+    return e;
 }
 
 // One Neumann edge (i,j): work ds*m and gradient of (-work).   src/loss.py:91-110,

@@ -32,7 +32,7 @@ namespace hfem {
 // float2 for fp32 models: widened on load, rounded once on store, fp64 arithmetic); ADAM: the write-out applies
 // torch.optim.Adam's update instead of storing the gradient (AdamFuse, hfem_tri3_energy_adam_step).
 template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
-          bool ADAM = false, bool CHAIN = false>
+          bool ADAM = false, bool CHAIN = false, int CAPN = 0>
 __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
     const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
@@ -40,10 +40,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     V2 *__restrict__ gx_free, V2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
     LagSum lag, AdamFuse af, int col_stride, int lab_bits) {
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
+    const int cap_n = CAPN > 0 ? CAPN : cap_nodes;       // CAPN > 0: the uv array's offset folds into the ds_read immediates
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
-    double2 *nd_uv = lds + cap_nodes;
-    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double2 *nd_uv = lds + cap_n;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_n);
     double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
     double *red = acc3 + cap_owned;
 
@@ -304,10 +305,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     }
 }
 
+constexpr int kPairCapN = 656, kPairCapO = 560;          // compile-time LDS strides of the default tile shape (557 owned nodes)
 template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM, bool CHAIN>
 static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
-    const size_t lds = CAPO > 0 ? (size_t)(A.max_nodes * 32 + CAPO * 32 + 128) : A.lds;
-    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN>), dim3(A.grid), dim3(BLK), lds, A.s,
+    constexpr int CAPN = CAPO > 0 ? kPairCapN : 0;
+    const size_t lds = CAPO > 0 ? (size_t)(CAPN * 32 + CAPO * 32 + 128) : A.lds;
+    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN>), dim3(A.grid), dim3(BLK), lds, A.s,
                        A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
                        (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
                        CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride, A.lab_bits);
@@ -329,7 +332,7 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.lds = (size_t)plan->lds_bytes;
     A.col_stride = h.col_stride;
     if (A.chain < 0) A.chain = h.n_chained > 0 ? 1 : 0;   // chained records need the carrying slot loop
-    const bool cc = h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 38912;   // four workgroups per CU
+    const bool cc = h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN;   // (656 + 560) * 32 + 128 = 39040 B: four workgroups per CU
     const int npt = h.max_nodes <= 3 * 256 ? 3 : 4;
     const int ept = h.max_rows;                          // slots per thread
     if (h.max_nodes > 4 * 256 || ept > 6 || ept < 1) return 0;

@@ -248,6 +248,34 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
+    # ---- N = 1, reported beside the headline: the step of a caller that needs ITS OWN loss before it goes on (a line
+    #      search, an L-BFGS check): the 1-block reduction launched right after every energy launch, on the critical path
+    inline_step = None
+    if world == 1 and lagged and not a.no_extra:
+        try:
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                for _ in range(3):
+                    sh.evaluate_local()
+            torch.cuda.current_stream().wait_stream(s_)
+            torch.cuda.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                for _ in range(a.steps):
+                    sh.evaluate_local()
+            g_.replay()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            g_.replay()
+            torch.cuda.synchronize()
+            el_ = time.perf_counter() - t0_
+            assert sh._views(sh.send)[0].item() == loss_gpu
+            inline_step = dict(mode="loss of step k reduced by its own 1-block launch before step k+1 (--inline-loss-sum)",
+                               ms_per_step=el_ / a.steps * 1e3, value=ne / (el_ / a.steps))
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] inline-loss leg failed: {e}", file=sys.stderr)
+
     # ---- N > 1 only, reported beside the headline: the north-star's literal exchange, a dense all-reduce of the
     #      full gradient + loss (every rank ends with everything; 16 B x 2 x nodes x N on the wire)
     def timed_alt(body):
@@ -518,6 +546,8 @@ def main():
         )
         if extras:
             out["config"]["extra"] = extras
+        if inline_step is not None:
+            out["config"]["inline_loss_step"] = inline_step
         if alt is not None:
             out["config"]["alt_exchange"] = alt
         if train is not None:

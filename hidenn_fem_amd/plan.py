@@ -145,7 +145,7 @@ class TilePlan:
                 np.concatenate([home, ((w1[hb] >> 11) & 1).astype(bool)]))
 
     def shard_range(self, rank: int, world: int):
-        """Contiguous tile range of ``rank`` (tiles are Morton-ordered, so a range is a
+        """Contiguous tile range of ``rank`` (tiles follow the locality curve -- Hilbert by default --, so a range is a
         spatially compact strip).  Balanced to within one tile."""
         nt = self.n_tiles
         lo = (nt * rank) // world

@@ -570,11 +570,12 @@ def test_cfg3_structured_256x256_l2_projection_vs_reference_chain():
             assert_grad_close(m.increments_y.grad, iy.grad.numpy(), "cfg3 g increments_y", rtol=1e-8)
 
 
-@pytest.mark.parametrize("order", [3, 5])
+@pytest.mark.parametrize("order", [3, 5, 6])
 def test_golden_tri3_cases_in_both_element_orders(g_tri, order):
     """The reference's golden TRI3 cases (all gauss orders, body force, traction function, flipped elements, permuted mesh)
     through BOTH production element orders: 3 = one element per slot (tri3_energy_fast_kernel / generic loop kernel),
-    5 = paired slots (tri3_pair.hip: two fan-adjacent elements per slot, shared-node contributions added in registers).
+    5 = paired slots (tri3_pair.hip: two fan-adjacent elements per slot, shared-node contributions added in registers),
+    and the optional strip order 6 (pairs chained along a row, rows carried in registers; the carrying slot loop).
     The auto policy picks between them by pairing coverage; parity must not depend on the pick.  Also the fp32-row and
     physical-convention instances of the pair kernel against the one-element-per-slot path."""
     from hidenn_fem_amd import _lib
@@ -589,7 +590,7 @@ def test_golden_tri3_cases_in_both_element_orders(g_tri, order):
             b, t = tri_case_forces(case)
             m = tri_model_from_golden(g_tri, case, d)
             lf = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=go, gauss_order_1d=go1, device=d, dtype=F64)
-            assert m.tile_plan(lf.tile_elems).is_paired() == (order == 5)
+            assert m.tile_plan(lf.tile_elems).is_paired() == (order >= 5)
             loss = lf(m, b_force=(lambda x: b(x.cpu()).to(d)) if b else None, t_force=(lambda x: t(x.cpu()).to(d)) if t else None)
             loss.backward()
             want = g_tri[case + "/loss"].item()
@@ -615,7 +616,7 @@ def test_pair_kernel_variants_match_the_single_slot_kernels():
     coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 151, jitter=0.25, seed=8, flip_fraction=0.1, dtype=F64)
     out = {}
     try:
-        for order in (3, 5):
+        for order in (3, 5, 6):
             _lib.check(L.hfem_set_option(b"plan_elem_order", order))
             res = {}
             for tag, dt, conv in (("f64", F64, None), ("phys", F64, "physical"), ("f32", torch.float32, None)):
@@ -625,7 +626,9 @@ def test_pair_kernel_variants_match_the_single_slot_kernels():
                 with torch.no_grad():
                     m.u_free.mul_(50.0)
                 lf = EnergyLoss2D(device=d, dtype=dt, grad_convention=conv)
-                assert m.tile_plan(lf.tile_elems).is_paired() == (order == 5)
+                assert m.tile_plan(lf.tile_elems).is_paired() == (order >= 5)
+                if order == 6:                                   # the strip order really chains pairs on this mesh
+                    assert ((m.tile_plan(lf.tile_elems).export("elem_pack_hi") >> 12) & 1).sum() > 1000
                 v = lf.value_and_grad_(m) if conv is None else None
                 if conv is not None:
                     v = lf(m)
@@ -639,12 +642,13 @@ def test_pair_kernel_variants_match_the_single_slot_kernels():
             out[order] = res
     finally:
         L.hfem_set_option(b"plan_elem_order", prev)
-    for tag in ("f64", "phys", "f32"):
-        a, b = out[5][tag], out[3][tag]
-        rt = 1e-12 if tag != "f32" else 1e-6
-        assert abs(a[0] - b[0]) <= rt * abs(b[0]), tag
-        assert np.abs(a[1] - b[1]).max() <= (1e-11 if tag != "f32" else 2e-6) * np.abs(b[1]).max(), tag
-        assert np.abs(a[2] - b[2]).max() <= (1e-11 if tag != "f32" else 2e-6) * np.abs(b[2]).max(), tag
-    np.testing.assert_allclose(out[5]["adam"][0], out[3]["adam"][0], rtol=1e-12)
-    assert np.abs(out[5]["adam"][1] - out[3]["adam"][1]).max() <= 1e-12 * np.abs(out[3]["adam"][1]).max()
-    assert np.abs(out[5]["adam"][2] - out[3]["adam"][2]).max() <= 1e-10 * np.abs(out[3]["adam"][2]).max()
+    for o in (5, 6):
+        for tag in ("f64", "phys", "f32"):
+            a, b = out[o][tag], out[3][tag]
+            rt = 1e-12 if tag != "f32" else 1e-6
+            assert abs(a[0] - b[0]) <= rt * abs(b[0]), (o, tag)
+            assert np.abs(a[1] - b[1]).max() <= (1e-11 if tag != "f32" else 2e-6) * np.abs(b[1]).max(), (o, tag)
+            assert np.abs(a[2] - b[2]).max() <= (1e-11 if tag != "f32" else 2e-6) * np.abs(b[2]).max(), (o, tag)
+        np.testing.assert_allclose(out[o]["adam"][0], out[3]["adam"][0], rtol=1e-12)
+        assert np.abs(out[o]["adam"][1] - out[3]["adam"][1]).max() <= 1e-12 * np.abs(out[3]["adam"][1]).max()
+        assert np.abs(out[o]["adam"][2] - out[3]["adam"][2]).max() <= 1e-10 * np.abs(out[3]["adam"][2]).max()

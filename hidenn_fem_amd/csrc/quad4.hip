@@ -41,27 +41,32 @@ __device__ __forceinline__ double jac_point(double a, double b, double c, double
                                             double w, const Tri3Consts &k, JacGrad &o, double beta_w = 0.0, double *A_out = nullptr) {
     const double det = a * d - b * c;
     const double inv = fast_rcp(det);
-    const double A = fabs(det);
     const double ai = a * inv, bi = b * inv, ci = c * inv, di = d * inv;
     const double h00 = g0.x * di - g1.x * bi, h01 = g1.x * ai - g0.x * ci;
     const double h10 = g0.y * di - g1.y * bi, h11 = g1.y * ai - g0.y * ci;
     const double gam = h01 + h10;
     const double sxx = k.c11 * h00 + k.c12 * h11, syy = k.c12 * h00 + k.c22 * h11, sxy = k.c33 * gam;
-    const double wpsi = (0.5 * w) * (h00 * sxx + h11 * syy + gam * sxy) - beta_w;
-    if (A_out) *A_out = A;
+    // |det| and sign(det) enter through sw = w sign(det) (one v_bfi on the high word, as in tri3_element):
+    // A w = det sw, sign(det) w psi = (sw / 2)(h : sigma) -- no compare / select chain
+    const double sw = __builtin_copysign(w, det);
+    const double aw = det * sw;                                            // A w
+    const double hs = h00 * sxx + h11 * syy + gam * sxy;
+    if (A_out) *A_out = fabs(det);
     if (GRAD) {
-        const double aw = A * w;
         const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;
         o.dg0 = make_double2(p00 * di - p01 * ci, p01 * di - p11 * ci);
         o.dg1 = make_double2(p01 * ai - p00 * bi, p11 * ai - p01 * bi);
-        // dJ = -dG^T H + sign(det) w psi cof(J)
-        const double sd = det < 0.0 ? -wpsi : wpsi;
+        // dJ = -dG^T H + sign(det) (w psi - beta_w) cof(J)
+        double sd = (0.5 * sw) * hs;
+        if (A_out) sd -= __builtin_copysign(1.0, det) * beta_w;            // body-force instances only
         o.da = sd * d - (o.dg0.x * h00 + o.dg0.y * h10);
         o.db = -sd * c - (o.dg0.x * h01 + o.dg0.y * h11);
         o.dc = -sd * b - (o.dg1.x * h00 + o.dg1.y * h10);
         o.dd = sd * a - (o.dg1.x * h01 + o.dg1.y * h11);
     }
-    return A * wpsi;
+    double e = (0.5 * aw) * hs;                                            // A w psi
+    if (A_out) e -= fabs(det) * beta_w;
+    return e;
 }
 
 // reference-square corner signs, CCW from (-1,-1): xi_k = {-1,1,1,-1}, eta_k = {-1,-1,1,1}

@@ -19,7 +19,7 @@
 namespace hfem {
 
 #ifdef HFEM_LAB
-#define HFEM_PAIR_LAB(bit) (lab_bits & (bit))          /* ablations: 1 no atomics, 2 no slot phase, 4 no write-out, 8 no gather loads, 16 return at once, 32 return after the row-map loads, 64 after the record loads, 128 after the first barrier, 256 no tile-energy store, 512 no edges, 1024 no record loads, 2048 no LDS fill */
+#define HFEM_PAIR_LAB(bit) (lab_bits & (bit))          /* ablations: 1 no atomics, 2 no slot phase, 4 no write-out, 8 no gather loads, 16 return at once, 32 return after the row-map loads, 64 after the record loads, 128 after the first barrier, 256 no tile-energy store, 512 no edges, 1024 no record loads, 2048 no LDS fill, 4096 lane-chain cost model (8 atomics + DPP), 8192 8 atomics only */
 #else
 #define HFEM_PAIR_LAB(bit) false
 #endif
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
                 double2 gx[3], gu[3];
                 const double e = tri3_element<true, HASB, PHYS>(Xn, nd_xy[lb], Xc, Un, nd_uv[lb], Uc, k, gx, gu);
                 if (p & kHomeBit) e_loc += e;
-                if (lb < n_owned) add_row(lb, gx[1], gu[1]);
+                if (lb < n_owned && !HFEM_PAIR_LAB(4096 | 8192)) add_row(lb, gx[1], gu[1]);
                 sxn = gx[0]; sun = gu[0]; sxc = gx[2]; suc = gu[2];
             }
             if (q & (1u << 10)) {                       // B = (n, c, d)
@@ -165,6 +165,21 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
                 sxn.x += gx[0].x; sxn.y += gx[0].y; sun.x += gu[0].x; sun.y += gu[0].y;
                 sxc.x += gx[1].x; sxc.y += gx[1].y; suc.x += gu[1].x; suc.y += gu[1].y;
             }
+#ifdef HFEM_LAB
+            if (HFEM_PAIR_LAB(4096 | 8192)) {           // lab: what a LANE chain would cost (timing only, results are not valid):
+                if (HFEM_PAIR_LAB(4096)) {              // rows of b, c handed to the next lane by DPP and added to its n, d rows
+                    auto shr = [](double v) {
+                        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xF, 0xF, false);
+                        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xF, 0xF, false);
+                        return __hiloint2double(hi, lo);
+                    };
+                    sxn.x += shr(sxc.x); sxn.y += shr(sxc.y); sun.x += shr(suc.x); sun.y += shr(suc.y);
+                    sxn.x += shr(sxc.y); sxn.y += shr(sxc.x); sun.x += shr(suc.y); sun.y += shr(suc.x);
+                }
+                if (ln < n_owned) add_row(ln, sxn, sun);   // n flushed; b was flushed above (stands in for d), c is not
+                continue;
+            }
+#endif
             if (ln < n_owned) add_row(ln, sxn, sun);
             if (lc < n_owned) add_row(lc, sxc, suc);
         }

@@ -113,7 +113,9 @@ int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
  * (lab build only), 7 elem_pack_hi u32 (QUAD4 plans: 4th local node of every slot; paired TRI3
  * plans: node d + presence/home bits of element B), 8 tile_chunks (chunked lab order), 9 elem_gid_b
  * i32 (paired plans: global id of every slot's element B; -1 = none).
- * Returns the element count, or <0.  buf may be NULL to query the size.       */
+ * Returns the element count, or <0.  buf may be NULL to query the size.  The per-tile arrays are laid out
+ * with uniform strides (tile t's node records start at t * node_stride, its slot records at t * elem_stride, padded;
+ * extra records follow the last tile): walk them through tile_desc's offsets and counts, not as dense arrays.    */
 int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t cap_elems);
 
 #define HFEM_FLAG_NO_GX 1   /* do not write gx_free (nodes fixed / no r-adaptivity) */
@@ -180,7 +182,8 @@ int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, do
  * serialises its own launches with a mutex).  Product knobs: "tiled_block" (threads per tile of the
  * one-element-per-slot kernels: 256, 512, 1024), "store_policy", "tiled_fast", "fast_const_caps",
  * "quad4_const_caps", "plan_elem_order" (-1 auto, 3 one element per slot, 5 paired slots), "plan_node_cap",
- * "plan_chunk_cap", "plan_curve" (0 Morton, 1 Hilbert).  The ablation / stamp / pipeline knobs exist only in
+ * "plan_chunk_cap", "plan_curve" (0 Morton, 1 Hilbert), "plan_snap" (tile cuts snap back to coarse curve cells by up
+ * to that percentage of a tile; 0 = off), "plan_elem_order" 6 = paired slots chained into strips (optional).  The ablation / stamp / pipeline knobs exist only in
  * the lab build (libhidenn_hip_lab.so, hfem_get_option("lab_build") == 1); the product library rejects them.
  * hfem_get_option returns the value or -1.                                     */
 int hfem_set_option(const char *name, int value);

@@ -512,6 +512,51 @@ def main():
               unstructured_tri_mesh(2_050_000, seed=2, dtype=f64))
         kreps = keep
 
+    # ---- config.train_step_1gpu (N = 1): the hot path INSIDE an optimiser loop on T1M -- what a training iteration costs
+    #      when the kernel's inputs are what the optimiser just wrote.  (i) energy launch + FusedAdam launch (the
+    #      reference's `loss.backward(); optimizer.step()`), (ii) one launch: the tiles apply Adam to the rows they own
+    #      (hfem_tri3_energy_adam_step).  K iterations in one hipGraph each; lr tiny so the mesh stays valid.
+    train1 = None
+    if world == 1 and not a.no_extra and not only:
+        try:
+            from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
+            from hidenn_fem_amd.graphed import GraphedTraining
+            res = {}
+            K = max(2, (a.steps // 2) * 2)
+            for mode in ("two_launch", "one_launch"):
+                torch.manual_seed(0)
+                m_ = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                              neumann_edges=edges).to(dev)
+                lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+                if mode == "two_launch":
+                    opt = FusedAdam([dict(params=[m_.node_coords_free], lr=1e-9), dict(params=[m_.u_free], lr=1e-12)],
+                                    capturable=True)
+                    gt = GraphedTraining(lambda: lf_.value_and_grad_(m_), opt, steps_per_replay=K, direct=True, warmup=2)
+                else:
+                    tr = EnergyAdamStep(m_, lf_, lr_x=1e-9, lr_u=1e-12)
+                    gt = GraphedTraining(tr.step_lagged, None, steps_per_replay=K, direct=True, begin=tr.begin_lagged,
+                                         end=tr.flush_loss)
+                for _ in range(3):
+                    gt.replay()
+                torch.cuda.synchronize()
+                t_pw = time.perf_counter()
+                while time.perf_counter() - t_pw < a.prewarm:
+                    gt.replay()
+                    torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    gt.replay()
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0_) / K)
+                it = sorted(ts)[2]
+                res[mode] = dict(us_per_iteration=it * 1e6, element_evals_per_s=ne / it)
+                del gt, m_
+            train1 = dict(workload="T1M, Adam on node_coords_free and u_free, K iterations per hipGraph", **res)
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] train_step_1gpu leg failed: {e}", file=sys.stderr)
+
     out = None
     if rank == 0:
         cpu = None
@@ -548,6 +593,8 @@ def main():
             out["config"]["extra"] = extras
         if inline_step is not None:
             out["config"]["inline_loss_step"] = inline_step
+        if train1 is not None:
+            out["config"]["train_step_1gpu"] = train1
         if alt is not None:
             out["config"]["alt_exchange"] = alt
         if train is not None:

@@ -14,21 +14,57 @@
 
 namespace hfem {
 
+// One element of torch.optim.Adam's update (betas, eps, bias correction folded into step_size / sqrt_bc2; no weight decay,
+// no amsgrad), operation for operation as torch's single-tensor path.
+template <typename T>
+__device__ __forceinline__ void adam_one(T &p, const T g, T &m, T &v, double w1, double b2, double w2, double step_size,
+                                         double sqrt_bc2, double eps) {
+    const T mi = m + (T)w1 * (g - m);                            // lerp_(grad, 1 - beta1)
+    const T vi = v * (T)b2 + (T)w2 * (g * g);                    // mul_(beta2).addcmul_(g, g, 1 - beta2): a + alpha (b c)
+    const T denom = (T)sqrt((double)vi) / (T)sqrt_bc2 + (T)eps;  // (sqrt(v) / sqrt(bc2)).add_(eps): a true division
+    m = mi;
+    v = vi;
+    p = p - (T)step_size * (mi / denom);
+}
+template <typename T> struct AdamVec;                           // 16-byte vectors of the parameter dtype
+template <> struct AdamVec<double> { typedef double2 type; static constexpr int N = 2; };
+template <> struct AdamVec<float> { typedef float4 type; static constexpr int N = 4; };
+
+// Body shared by the two kernels below: 16-byte loads / stores (four arrays in flight per thread), grid-stride over the
+// vector part, the < N-element tail by the first threads.  The update is memory-bound: 7 array passes per parameter.
+template <typename T>
+__device__ __forceinline__ void adam_body(T *__restrict__ p, const T *__restrict__ g, T *__restrict__ m, T *__restrict__ v,
+                                          int64_t n, double w1, double b2, double w2, double step_size, double sqrt_bc2,
+                                          double eps) {
+    typedef typename AdamVec<T>::type V;
+    constexpr int N = AdamVec<T>::N;
+    // views that do not start on a 16-byte boundary take the scalar loop for everything
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int64_t nv = aligned ? n / N : 0, stride = (int64_t)gridDim.x * 256;
+    V *pv = reinterpret_cast<V *>(p), *mv = reinterpret_cast<V *>(m), *vv = reinterpret_cast<V *>(v);
+    const V *gv = reinterpret_cast<const V *>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        V P = pv[i], M = mv[i], Vv = vv[i];
+        const V G = gv[i];
+        T *pp = reinterpret_cast<T *>(&P), *mm = reinterpret_cast<T *>(&M), *vx = reinterpret_cast<T *>(&Vv);
+        const T *gg = reinterpret_cast<const T *>(&G);
+#pragma unroll
+        for (int k = 0; k < N; ++k) adam_one<T>(pp[k], gg[k], mm[k], vx[k], w1, b2, w2, step_size, sqrt_bc2, eps);
+        mv[i] = M;
+        vv[i] = Vv;
+        pv[i] = P;
+    }
+    for (int64_t t = nv * N + (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride)   // tail / unaligned views
+        adam_one<T>(p[t], g[t], m[t], v[t], w1, b2, w2, step_size, sqrt_bc2, eps);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adam_step_kernel(T *__restrict__ p, const T *__restrict__ g,
                                                         T *__restrict__ m, T *__restrict__ v, int64_t n,
                                                         double w1, double b2, double w2, double step_size,
                                                         double sqrt_bc2, double eps) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const T gi = g[i];
-        const T mi = m[i] + (T)w1 * (gi - m[i]);                 // lerp_(grad, 1 - beta1)
-        const T vi = v[i] * (T)b2 + (T)w2 * (gi * gi);           // mul_(beta2).addcmul_(g, g, 1 - beta2): a + alpha (b c)
-        const T denom = (T)sqrt((double)vi) / (T)sqrt_bc2 + (T)eps;   // (sqrt(v) / sqrt(bc2)).add_(eps): a true division
-        m[i] = mi;
-        v[i] = vi;
-        p[i] = p[i] - (T)step_size * (mi / denom);
-    }
+    adam_body<T>(p, g, m, v, n, w1, b2, w2, step_size, sqrt_bc2, eps);
 }
 
 // hipGraph-capturable variant: the step count lives on the device (kernel arguments are frozen inside a graph),
@@ -40,17 +76,7 @@ __global__ __launch_bounds__(256) void adam_step_dev_kernel(T *__restrict__ p, c
                                                             const int64_t *__restrict__ step_dev) {
     const double step = (double)step_dev[0];
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
-    const double step_size = lr / bc1, sqrt_bc2 = sqrt(bc2), w1 = 1.0 - b1, w2 = 1.0 - b2;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const T gi = g[i];
-        const T mi = m[i] + (T)w1 * (gi - m[i]);
-        const T vi = v[i] * (T)b2 + (T)w2 * (gi * gi);
-        const T denom = (T)sqrt((double)vi) / (T)sqrt_bc2 + (T)eps;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] = p[i] - (T)step_size * (mi / denom);
-    }
+    adam_body<T>(p, g, m, v, n, 1.0 - b1, b2, 1.0 - b2, lr / bc1, sqrt(bc2), eps);
 }
 
 // the same update on the [.][2] fp64 rows listed in rows[] only (owner-sharded multi-GPU mode: a rank updates exactly the
@@ -98,8 +124,9 @@ extern "C" int hfem_adam_step(int device, void *p, const void *g, void *m, void 
     if (int rc = use_device(device)) return rc;
     const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
     const double step_size = lr / bc1, sqrt_bc2 = std::sqrt(bc2);
-    int64_t grid = (n + 255) / 256;
-    if (grid > 8192) grid = 8192;
+    int64_t grid = (n / (dtype == 0 ? 2 : 4) + 255) / 256;     // one 16-byte vector per thread, grid-stride beyond 8 blocks / CU
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
     if (dtype == 0)
         hipLaunchKernelGGL(adam_step_kernel<double>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (double *)p,
                            (const double *)g, (double *)m, (double *)v, n, 1.0 - beta1, beta2, 1.0 - beta2, step_size,
@@ -121,8 +148,9 @@ extern "C" int hfem_adam_step_dev(int device, void *p, const void *g, void *m, v
     HFEM_ARG_CHECK(p && g && m && v && step_dev, "null pointer");
     HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64, 1 = fp32");
     if (int rc = use_device(device)) return rc;
-    int64_t grid = (n + 255) / 256;
-    if (grid > 8192) grid = 8192;
+    int64_t grid = (n / (dtype == 0 ? 2 : 4) + 255) / 256;     // one 16-byte vector per thread, grid-stride beyond 8 blocks / CU
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
     if (dtype == 0)
         hipLaunchKernelGGL(adam_step_dev_kernel<double>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (double *)p,
                            (const double *)g, (double *)m, (double *)v, n, beta1, beta2, lr, eps, step_dev);

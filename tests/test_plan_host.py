@@ -365,3 +365,38 @@ def test_strip_element_order_chains():
             assert abs(loss - e_ref) <= 1e-12 * abs(e_ref), name
             assert np.abs(gX - gX_ref).max() <= 1e-10 * np.abs(gX_ref).max() and np.abs(gU - gU_ref).max() <= 1e-10 * np.abs(gU_ref).max()
             plan.close()
+
+
+def test_snapped_tile_cuts_keep_the_invariants():
+    """plan_snap (csrc/plan.cpp cut_tiles): tile cuts move back to the boundary of the coarsest locality-curve cell in reach.
+    Every element still has exactly one home tile, every node one owner, the emulation reproduces the closed forms, and on
+    a structured mesh the tiles need no more slots than with plain greedy cuts."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import unstructured_tri_mesh
+    L = _lib.lib()
+    mat, W, Tc = CF.plane_stress(), 0.25, np.array([2e5, 0.0, 0.0, 0.0])
+    cases = {
+        "fixed": structured_tri_mesh(161, 121, jitter=0.2, seed=3, dtype=torch.float64),
+        "delaunay": unstructured_tri_mesh(6000, seed=9, dtype=torch.float64),
+    }
+    prev = L.hfem_get_option(b"plan_snap")
+    try:
+        for name, (coords, conn, geom, bc, mn, edges) in cases.items():
+            X, cn, ed = coords.numpy(), conn.numpy(), edges.numpy()
+            slots = {}
+            for snap in (0, 25):
+                _lib.check(L.hfem_set_option(b"plan_snap", snap))
+                plan = TilePlan(cn, X.shape[0], coords_hint=X, edges=ed)
+                a = check_invariants(cn, ed, X.shape[0], plan)
+                slots[snap] = plan.stats["tile_elem_total"]
+                U = 1e-4 * np.random.default_rng(2).standard_normal(X.shape)
+                e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, cn, mat, W)
+                e_ref -= CF.edge2_energy(X, U, ed, Tconst=Tc, gX=gX_ref, gU=gU_ref)
+                loss, gX, gU = emulate(a, X, U, mat, W, None, Tc)
+                assert abs(loss - e_ref) <= 1e-12 * abs(e_ref), (name, snap)
+                assert np.abs(gX - gX_ref).max() <= 1e-10 * np.abs(gX_ref).max()
+                assert np.abs(gU - gU_ref).max() <= 1e-10 * np.abs(gU_ref).max()
+                plan.close()
+            assert slots[25] <= 1.05 * slots[0], (name, slots)
+    finally:
+        L.hfem_set_option(b"plan_snap", prev)

@@ -92,6 +92,7 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
                     HostPlan &out);
 
 void set_plan_curve(int c);   // 0 Morton, 1 Hilbert (default)
+void set_plan_read_pack(int v);     // paired slots packed against ds_read_b128 bank conflicts as well (default 1)
 void set_plan_snap(int percent);   // tile cuts snap back to coarse curve-cell boundaries by up to this share of a tile (0 off)
 
 }  // namespace hfem

@@ -703,6 +703,7 @@ struct Defaults {
     std::atomic<int> plan_node_cap{-1};     // max distinct nodes among a tile's own elements; 0: cut by element count only;
                                             // -1 (auto): 557 when tile_elems is left to the library, else 0.  557 nodes keep
                                             // (n_node + n_owned) * 32 B <= 38.9 KB: four 512-thread workgroups per CU
+    std::atomic<int> plan_read_pack{2};     // paired slots packed against ds_read_b128 bank conflicts too (partner rows examined; 0 off)
     std::atomic<int> plan_snap{0};          // tile cuts snap to coarse curve cells (percent of a tile they may move back)
     std::atomic<int> plan_chunk_cap{512};   // chunked plans: longest strip of a tile (slots)
 } g_def;
@@ -1332,6 +1333,9 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "plan_curve") {
         HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");
         set_plan_curve(value);
+    } else if (n == "plan_read_pack") {
+        g_def.plan_read_pack = value;
+        set_plan_read_pack(value);
     } else if (n == "plan_snap") {
         HFEM_ARG_CHECK(value >= 0 && value <= 50, "plan_snap: 0..50 (percent of a tile)");
         g_def.plan_snap = value;
@@ -1407,6 +1411,7 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "plan_node_cap") return g_def.plan_node_cap.load();
     if (n == "plan_chunk_cap") return g_def.plan_chunk_cap.load();
     if (n == "plan_snap") return g_def.plan_snap.load();
+    if (n == "plan_read_pack") return g_def.plan_read_pack.load();
     if (n == "lab_build") {
 #ifdef HFEM_LAB
         return 1;

@@ -183,7 +183,8 @@ int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, do
  * one-element-per-slot kernels: 256, 512, 1024), "store_policy", "tiled_fast", "fast_const_caps",
  * "quad4_const_caps", "plan_elem_order" (-1 auto, 3 one element per slot, 5 paired slots), "plan_node_cap",
  * "plan_chunk_cap", "plan_curve" (0 Morton, 1 Hilbert), "plan_snap" (tile cuts snap back to coarse curve cells by up
- * to that percentage of a tile; 0 = off), "plan_elem_order" 6 = paired slots chained into strips (optional).  The ablation / stamp / pipeline knobs exist only in
+ * to that percentage of a tile; 0 = off), "plan_elem_order" 6 = paired slots chained into strips (optional), "plan_read_pack" (paired slots also packed against
+ * ds_read_b128 bank conflicts: number of partner rows examined, default 2; 0 = off).  The ablation / stamp / pipeline knobs exist only in
  * the lab build (libhidenn_hip_lab.so, hfem_get_option("lab_build") == 1); the product library rejects them.
  * hfem_get_option returns the value or -1.                                     */
 int hfem_set_option(const char *name, int value);

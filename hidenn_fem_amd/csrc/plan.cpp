@@ -72,8 +72,14 @@ void set_locality_curve(int c) { g_curve = c; }
 // bit -- the edge of the coarsest curve cell in reach.  Tiles become unions of whole cells (straight, axis-aligned sides)
 // instead of ending mid-cell on a staircase: fewer halo elements and nodes per tile.  0 = off.
 static int g_hw_window = 2;       // rows examined as partner of a row (pack_slot_halfwaves); > 100: exhaustive split search (lab)
+static int g_halfwave_all = 1;    // also for one-element-per-slot TRI3 / QUAD4 records (plan_read_pack >= 1000: paired plans only)
 static int g_halfwave_pack = 1;   // paired slots packed for ds_read_b128's lane groups too (pack_slot_halfwaves); 0: atomics only
-void set_halfwave_pack(int v) { g_halfwave_pack = v ? 1 : 0; if (v > 1) g_hw_window = v; }
+void set_halfwave_pack(int v) {
+    g_halfwave_all = v < 1000;
+    if (v >= 1000) v -= 1000;
+    g_halfwave_pack = v ? 1 : 0;
+    if (v > 1) g_hw_window = v;
+}
 static int g_snap = 0;
 void set_tile_snap(int percent) { g_snap = percent < 0 ? 0 : (percent > 50 ? 50 : percent); }
 static thread_local std::vector<uint32_t> g_codes;   // curve code of every element, in sorted order (empty: no coordinates)
@@ -425,7 +431,18 @@ void order_tile_elements(std::vector<int32_t> &telems, const int64_t *conn, int 
     if (mode == 3) {
         std::vector<int32_t> out;
         out.reserve(n + n / 8 + 16);
-        pack_bank_groups(telems, conn, npe, lid, n_owned, false, false, out);
+        if (g_halfwave_pack && g_halfwave_all) {
+            // one-element-per-slot TRI3 and QUAD4 records through the same two-level packing as the paired slots: atomic
+            // rows of 16, then half-waves whose ds_read_b128 lane groups are conflict-poor as well
+            std::vector<std::array<int32_t, 4>> items(n);
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < 4; ++k) items[i][k] = k < npe ? lid[conn[npe * (int64_t)telems[i] + k]] : -1;
+            std::vector<int32_t> o;
+            pack_slot_halfwaves(items, n_owned, o);
+            for (int32_t v : o) out.push_back(v < 0 ? -1 : telems[v]);
+        } else {
+            pack_bank_groups(telems, conn, npe, lid, n_owned, false, false, out);
+        }
         telems.swap(out);
         return;
     }

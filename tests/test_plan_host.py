@@ -112,6 +112,55 @@ def bank_passes(a):
     return tot / max(ninstr, 1)
 
 
+READ_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+READ_GROUPS = READ_GROUPS + [[x + 32 for x in g] for g in READ_GROUPS]     # ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS)
+
+
+def read_passes(a, block):
+    """LDS cycles per ds_read_b128 lane group: distinct ids of a group sharing a 16-byte slot (id mod 16) serialise; equal
+    ids broadcast.  Slots sit at i -> thread i % block -> lane i % 64."""
+    tot = ngrp = 0
+    for (eo, nel, no, nno, nown, go, ned, _) in a["td"]:
+        pk = a["ep"][eo:eo + nel].astype(np.int64)
+        hi = a["hi"][eo:eo + nel].astype(np.int64) if a["hi"] is not None else None
+        for w0_ in range(0, nel, 64):
+            w = pk[w0_:w0_ + 64]
+            for g in READ_GROUPS:
+                g = [x for x in g if x < len(w)]
+                sub = w[g]
+                keep = (sub & SKIP) == 0
+                for c in range(3 if hi is None else 4):
+                    l = ((sub >> (10 * c)) & MASK)[keep] if c < 3 else (hi[w0_:w0_ + 64][g] & MASK)[keep]
+                    l = np.unique(l)
+                    if len(l):
+                        tot += np.bincount(l % 16, minlength=16).max()
+                        ngrp += 1
+    return tot / max(ngrp, 1)
+
+
+def test_read_aware_packing_lowers_ds_read_b128_conflicts():
+    """plan_read_pack (csrc/plan.cpp pack_slot_halfwaves): slots are packed for ds_read_b128's non-consecutive lane groups as
+    well as for ds_add_f64's consecutive ones -- the plan stays a valid plan and the modelled read conflicts drop."""
+    from hidenn_fem_amd import _lib
+    L = _lib.lib()
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(301, 201, jitter=0.2, seed=0, dtype=torch.float64)
+    prev = L.hfem_get_option(b"plan_read_pack")
+    res = {}
+    try:
+        for order in (3, 5):
+            for rp in (0, 2):
+                _lib.check(L.hfem_set_option(b"plan_read_pack", rp))
+                plan = TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges, elem_order=order)
+                a = check_invariants(conn.numpy(), edges.numpy(), coords.shape[0], plan)
+                if order == 3:
+                    res[(order, rp)] = (read_passes(a, 512), bank_passes(a))
+                plan.close()
+    finally:
+        L.hfem_set_option(b"plan_read_pack", prev)
+    assert res[(3, 2)][0] < 0.92 * res[(3, 0)][0], res          # fewer read conflicts ...
+    assert res[(3, 2)][1] <= 1.03                                # ... with the atomic groups still (nearly) conflict-free
+
+
 def test_default_element_order_is_lds_bank_conflict_free():
     coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 101, jitter=0.2, seed=0, dtype=torch.float64)
     stats = {}
@@ -120,7 +169,7 @@ def test_default_element_order_is_lds_bank_conflict_free():
         a = check_invariants(conn.numpy(), edges.numpy(), coords.shape[0], plan)
         stats[mode] = (bank_passes(a), plan.stats["tile_elem_total"])
     TilePlan(conn, coords.shape[0], elem_order=3)                      # restore the default for later tests
-    assert stats[3][0] == 1.0                                           # every group conflict-free
+    assert stats[3][0] <= 1.03                                          # atomic groups conflict-free (holes are filled, not padded: a few clashes)
     assert stats[0][0] > 2.0 and stats[2][0] > 2.0                      # what it replaces
     assert stats[3][1] <= 1.2 * stats[2][1]                             # padding stays modest
 
@@ -157,7 +206,7 @@ def test_quad4_plan_invariants_and_bank_groups(tile_elems):
     plan = TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges, tile_elems=tile_elems, nodes_per_elem=4)
     assert plan.stats["n_elems"] == conn.shape[0]
     a = check_invariants(conn.numpy(), edges.numpy(), coords.shape[0], plan)
-    assert bank_passes(a) == 1.0
+    assert bank_passes(a) <= 1.05
     assert plan.stats["tile_elem_total"] <= 1.25 * conn.shape[0] + 16 * plan.n_tiles
     with pytest.raises(ValueError):
         TilePlan(conn, coords.shape[0], nodes_per_elem=5)

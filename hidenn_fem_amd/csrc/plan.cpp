@@ -940,7 +940,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
     //      becomes {desc, maps} -> rows).  Padding repeats the tile's last record (a valid row pair: loads through it are
     //      harmless); kNodeTailPad more records follow the last tile so that lanes past a tile's stride stay inside the array.
     {
-        const int32_t stride = (P.max_nodes + 15) / 16 * 16;
+        const int32_t stride = std::max(16, (P.max_nodes + 15) / 16 * 16);   // >= 16: kernels clamp unguarded loads to stride - 1
         if ((int64_t)nt * stride + kNodeTailPad > (int64_t)std::numeric_limits<int32_t>::max()) {
             set_error("plan: tile arrays exceed int32 offsets");
             return -1;
@@ -978,7 +978,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             }
             P.col_stride = cs;
         }
-        const int64_t stride = (P.max_elems + 15) / 16 * 16;
+        const int64_t stride = std::max(16, (P.max_elems + 15) / 16 * 16);   // >= 16 even for plans without elements (orphan-node tiles only)
         const size_t total = (size_t)nt * stride + kElemTailPad;
         if (total > (size_t)std::numeric_limits<int32_t>::max()) { set_error("plan: tile arrays exceed int32 offsets"); return -1; }
         const bool hi = !P.elem_pack_hi.empty(), gb = !P.elem_gid_b.empty();

@@ -349,8 +349,8 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     if (A.chain < 0) A.chain = h.n_chained > 0 ? 1 : 0;   // chained records need the carrying slot loop
     const bool cc = h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN;   // (656 + 560) * 32 + 128 = 39040 B: four workgroups per CU
     const int npt = h.max_nodes <= 3 * 256 ? 3 : 4;
-    const int ept = h.max_rows;                          // slots per thread
-    if (h.max_nodes > 4 * 256 || ept > 6 || ept < 1) return 0;
+    const int ept = h.max_rows > 0 ? h.max_rows : 1;     // slots per thread (0: a plan of element-less tiles)
+    if (h.max_nodes > 4 * 256 || ept > 6) return 0;
 #define HFEM_PAIR_EPT(NPT, CO, HB, PH, V, AD)                                                    \
     switch (ept) {                                                                               \
         case 1: case 2: case 3: launch_pair_inst<256, NPT, 3, CO, HB, PH, V, AD>(A, lag, af); return 1; \

@@ -76,3 +76,44 @@ def test_lbfgs_on_tiny_problems():
         got_l, got_p = run(FusedLBFGS)
         np.testing.assert_allclose(got_l, ref_l, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(got_p, ref_p, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_planned_energy_on_degenerate_meshes():
+    """hfem_tri3_energy_plan on plans that are mostly padding: nodes without any element (orphan-node tiles only: zero
+    energy, zero gradient rows), one single element, and one element plus 700 unreferenced nodes.  The kernels load their
+    index arrays unguarded from uniform strides, so these sizes exercise the stride floors and the tail padding."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.plan import TilePlan
+    from oracle import closed_form as CF
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    dv = lambda a: (C.c_double * len(a))(*a)
+    mat, W = CF.plane_stress(), 0.25
+    rng = np.random.default_rng(0)
+    cases = {
+        "no elements": (np.zeros((0, 3), dtype=np.int64), 40),
+        "one element": (np.array([[0, 1, 2]], dtype=np.int64), 3),
+        "one element + orphans": (np.array([[5, 9, 2]], dtype=np.int64), 703),
+    }
+    for name, (conn, nn) in cases.items():
+        X = rng.random((nn, 2))
+        U = 1e-3 * rng.standard_normal((nn, 2))
+        for order in (3, 5):
+            plan = TilePlan(conn, nn, coords_hint=X, edges=np.zeros((0, 2), dtype=np.int64), device=d, elem_order=order)
+            Xd, Ud = torch.from_numpy(X).to(d), torch.from_numpy(U).to(d)
+            loss = torch.full((), 7.0, dtype=F64, device=d)
+            gX, gU = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+            _lib.check(L.hfem_tri3_energy_plan(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv([0.0] * 6),
+                                               None, dv([0.0] * 4), 0, -1, loss.data_ptr(), gX.data_ptr(), gU.data_ptr(), 0, st))
+            torch.cuda.synchronize()
+            if conn.shape[0]:
+                e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn, mat, W)
+            else:
+                e_ref, gX_ref, gU_ref = 0.0, np.zeros_like(X), np.zeros_like(U)
+            assert abs(loss.item() - e_ref) <= 1e-12 * max(abs(e_ref), 1e-300), (name, order)
+            assert not torch.isnan(gX).any() and not torch.isnan(gU).any(), (name, order)      # every row written
+            assert np.abs(gX.cpu().numpy() - gX_ref).max() <= 1e-10 * max(np.abs(gX_ref).max(), 1e-300), (name, order)
+            assert np.abs(gU.cpu().numpy() - gU_ref).max() <= 1e-10 * max(np.abs(gU_ref).max(), 1e-300), (name, order)
+            plan.close()

@@ -117,3 +117,56 @@ def test_planned_energy_on_degenerate_meshes():
             assert np.abs(gX.cpu().numpy() - gX_ref).max() <= 1e-10 * max(np.abs(gX_ref).max(), 1e-300), (name, order)
             assert np.abs(gU.cpu().numpy() - gU_ref).max() <= 1e-10 * max(np.abs(gU_ref).max(), 1e-300), (name, order)
             plan.close()
+
+
+@pytest.mark.gpu
+def test_tiny_models_through_every_planned_entry_point():
+    """One-quad / two-triangle models through the host mirror: QUAD4 plan kernel, fp32-row TRI3 kernel, fused energy+Adam
+    step -- the planned kernels on tiles that are almost entirely stride padding."""
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import EnergyAdamStep
+    d = torch.device("cuda:0")
+    coords = torch.tensor([[0.0, 0.0], [1.0, 0.0], [1.1, 0.9], [0.0, 1.0], [2.0, 0.1], [2.1, 1.2]], dtype=F64)
+    bc = torch.tensor([True, False, False, True, False, False])
+    for conn in (torch.tensor([[0, 1, 2, 3], [1, 4, 5, 2]]), torch.tensor([[0, 1, 2], [0, 2, 3], [1, 4, 5], [1, 5, 2]])):
+        for dt in (F64, torch.float32):
+            torch.manual_seed(3)
+            m = PiecewiseLinearShapeNN2D(coords.to(dt), conn, boundary_mask=None, dirichlet_mask=bc, u_fixed=0.0).to(d)
+            with torch.no_grad():
+                m.u_free.mul_(1e-3)
+            lf = EnergyLoss2D(device=d, dtype=dt)
+            loss = lf(m)
+            loss.backward()
+            assert torch.isfinite(loss) and torch.isfinite(m.u_free.grad).all() and torch.isfinite(m.node_coords_free.grad).all()
+            # oracle on the same numbers
+            X = m.coords.detach().double().cpu()
+            U = m.u_full.detach().double().cpu()
+            if conn.shape[1] == 4:
+                from oracle import closed_form as CF
+                want = CF.quad4_energy(X.numpy(), U.numpy(), conn.numpy(), CF.plane_stress())[0]
+            else:
+                from oracle import closed_form as CF
+                want = CF.tri3_energy(X.numpy(), U.numpy(), conn.numpy(), CF.plane_stress(), lf._W)[0]
+            tol = 1e-11 if dt == F64 else 2e-5
+            assert abs(loss.item() - want) <= tol * abs(want), (conn.shape, dt, loss.item(), want)
+    # fused energy + Adam step on the four-triangle model == energy launch + FusedAdam launch on a copy, step by step
+    from hidenn_fem_amd.optim import FusedAdam
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3], [1, 4, 5], [1, 5, 2]])
+    models = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        m = PiecewiseLinearShapeNN2D(coords, tri, boundary_mask=None, dirichlet_mask=bc, u_fixed=0.0).double().to(d)
+        with torch.no_grad():
+            m.u_free.mul_(1e-3)
+        models.append(m)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    tr = EnergyAdamStep(models[0], lf, lr_x=1e-7, lr_u=1e-9)
+    opt = FusedAdam([dict(params=[models[1].node_coords_free], lr=1e-7), dict(params=[models[1].u_free], lr=1e-9)])
+    for _ in range(5):
+        l0 = tr.step().item()
+        l1 = lf.value_and_grad_(models[1]).item()
+        opt.step()
+        assert abs(l0 - l1) <= 1e-12 * abs(l1)
+    assert torch.allclose(models[0].u_free, models[1].u_free, rtol=1e-12, atol=0)
+    assert torch.allclose(models[0].node_coords_free, models[1].node_coords_free, rtol=1e-13, atol=0)

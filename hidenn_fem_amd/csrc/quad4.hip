@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlockQ) void quad4_eval_bwd_kernel(
 // CAPO > 0: compile-time stride of the four accumulator arrays (their LDS addresses become one scaled id + immediate).
 struct Quad4Body { double2 b[4]; };      // body force at the 2x2 Gauss points (reference coordinates)
 
-template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false>
+template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false, int CAPN = 0>
 __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     PlanDev pd, int tile_begin, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
     const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
@@ -322,10 +322,11 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     if ((ABL & 4) && threadIdx.x == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_QSTAMP(0)
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
+    const int cap_n = CAPN > 0 ? CAPN : cap_nodes;       // CAPN > 0: the uv array's offset folds into the ds_read immediates
     extern __shared__ double2 lds[];
     double2 *nd_xy = lds;
-    double2 *nd_uv = lds + cap_nodes;
-    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
+    double2 *nd_uv = lds + cap_n;
+    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_n);
     double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
     double *red = acc3 + cap_owned;
 
@@ -813,7 +814,16 @@ extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free
         const int stagger = 0;
 #endif
         if (hasb) HFEM_LAUNCH_Q4(4, 4, 0, 0, true);                  // body force: general instance (runtime strides)
-        else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
+        else if (g_quad4_const_caps && h.max_nodes <= 672 && h.max_owned <= 560 && h.max_elems <= 3 * 256) {
+            // default tile shape (557 owned nodes): compile-time LDS strides, (672 + 560) * 32 + 128 = 39552 B: 4 workgroups per CU
+            hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 3, 3, 0, 560, false, 672>), dim3(n), dim3(256), (size_t)39552, s,
+                               plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,
+                               (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
+                               plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
+                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, 672, 560,
+                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger,
+                               g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps, body);
+        } else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
         else if (g_quad4_const_caps && h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 40960) {
             // default tile shape: compile-time accumulator stride (launched with the matching LDS size)
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 4, 4, 0, 560>), dim3(n), dim3(256),

@@ -696,7 +696,7 @@ struct Defaults {
     std::atomic<int> fast_const_caps{1};    // default tile shape: instance with compile-time accumulator strides
     std::atomic<int> pair_pipe_wps{4};      // pipelined kernel: register budget sized for this many waves per SIMD (3 or 4)
     std::atomic<int> pair_tiles_per_wg{1};  // paired plans: > 1 = software-pipelined kernel, that many tiles per workgroup
-    std::atomic<int> plan_elem_order{-1};   // TRI3: -1 = auto (paired when >= 90 % of the elements find a partner, else 3; measured
+    std::atomic<int> plan_elem_order{-1};   // TRI3: -1 = auto (paired when the pair slots cover >= 0.7 x the elements, else 3; measured
                                             // crossover), 5 = paired slots (two fan-adjacent elements per slot, tri3_pair.hip; the default),
                                             // 3 = one element per slot in LDS-bank-aware 16-lane groups, 4 = the same inside three
                                             // strips (lab), 0..2 legacy orders; QUAD4 plans always use 3
@@ -947,9 +947,12 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, order,
                         g_def.plan_chunk_cap.load(), p->host))
         return -1;
-    if (auto_order && p->host.paired && 2 * p->host.n_pairs * 10 < 9 * ne) {
+    if (auto_order && p->host.paired && 2 * p->host.n_pairs * 10 < 7 * ne) {
         // few fan-adjacent partners (local node orders are what they are -- they cannot be rotated): the
-        // one-element-per-slot order with the 512-thread kernel is faster there (profiles/r02: random diagonals 11.3 vs 12.1 us)
+        // one-element-per-slot order with the 512-thread kernel is faster there.  Crossover measured after the round-2 prologue
+        // and packing work (profiles/r02/r2_lab32_*.jsonl; the ratio counts halo slots, ~1.13 x the element coverage): random
+        // diagonals (73 % of the elements pair, ratio 0.82) paired 10.35 vs 10.65 us; zigzag (50 %, 0.57) 11.67 vs 11.18 us;
+        // Delaunay (39 %, 0.44) 42.4-43.0 vs 41.9 us
         p->host = HostPlan();
         if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, 3,
                             g_def.plan_chunk_cap.load(), p->host))

@@ -27,6 +27,7 @@ class PlanStats(C.Structure):
         ("max_tile_nodes", _i32), ("max_tile_owned", _i32),
         ("max_tile_elems", _i32), ("max_tile_edges", _i32),
         ("device_bytes", _i64), ("lds_bytes", _i32),
+        ("shards", _i32), ("threads_per_tile", _i32), ("paired", _i32), ("slot_rows", _i32),
     ]
 
     def as_dict(self):
@@ -80,6 +81,10 @@ PROTOTYPES = {
     "hfem_mg_allreduce_sum": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "hfem_mg_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "hfem_adam_step_rows_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _vp, _vp]),
+    "hfem_plan_set_span_stamps": (C.c_int, [_vp, _vp, _i64]),
+    "hfem_plan_iface_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "hfem_adam_step_rows2_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _f64,
+                                           _f64, _f64, _f64, _vp, _i64, _vp]),
     "hfem_quad4_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_energy_plan_body": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -10,7 +10,7 @@
 // arrays and adds the partial energies in rank order (deterministic).  Pure data movement, a few KB..MB.
 #include <hip/hip_runtime.h>
 
-#include "hfem_device.h"
+#include "hfem_plan_dev.h"
 
 namespace hfem {
 
@@ -37,6 +37,37 @@ __global__ __launch_bounds__(256) void iface_unpack_kernel(const double2 *__rest
         for (int r = 0; r < world; ++r) tot += recv[(int64_t)r * stride + loss_slot].x;   // fixed order
         loss_out[0] = tot;
     }
+}
+
+// pack + the rank's energy + the step counter, one launch (hfem_plan_iface_pack): block 0 also reduces the tile energies
+// exactly as sum_partials_kernel does (256 adders, shuffle tree, wave sums in wave order: the same bits)
+__global__ __launch_bounds__(256) void iface_pack_sum_kernel(const double2 *__restrict__ x_free,
+                                                             const double2 *__restrict__ u_free,
+                                                             const int32_t *__restrict__ rows, int n_x, int n_u,
+                                                             double2 *__restrict__ out, int64_t loss_slot,
+                                                             const double *__restrict__ partials, int n_partials,
+                                                             int64_t *__restrict__ counter) {
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_x) out[i] = x_free[rows[i]];
+    else if (i < n_x + n_u) out[i] = u_free[rows[i]];
+    if (blockIdx.x == 0) {
+        double v = 0.0;
+        for (int k = threadIdx.x; k < n_partials; k += 256) v += partials[k];
+        const double tot = block_sum(v, red);
+        if (threadIdx.x == 0) {
+            out[loss_slot] = make_double2(tot, 0.0);
+            if (counter) counter[0] += 1;
+        }
+    }
+}
+
+int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
+                          int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, hipStream_t s) {
+    const int n = n_x + n_u > 0 ? n_x + n_u : 1;
+    hipLaunchKernelGGL(iface_pack_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double2 *)x_free,
+                       (const double2 *)u_free, rows, n_x, n_u, (double2 *)out, loss_slot, partials, n_partials, counter);
+    return launch_status("hfem_plan_iface_pack");
 }
 
 }  // namespace hfem

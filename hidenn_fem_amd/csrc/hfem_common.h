@@ -82,6 +82,12 @@ struct HostPlan {
     // compact copies of the inputs (the deterministic node-centric kernel walks the mesh itself, tri3_det.hip)
     std::vector<int32_t> conn32, x_src_g, u_src_g, edges32;
     int32_t max_chunk_elems = 0;       // longest strip (slots); 0 = not chunked
+    // Element sharding (plan_shards): rank r's tiles are [lo, hi) = shard_desc[4r + 0], [4r + 2]); its BOUNDARY tiles (they
+    // read a node another rank's tile owns, or own a node another rank's tile reads) are [lo, mid), mid = shard_desc[4r + 1],
+    // its interior tiles [mid, hi).  shards = 1: one record {0, 0, n_tiles, 0}.
+    int32_t shards = 1;
+    std::vector<int32_t> shard_desc;
+    int32_t pair_block = 256;          // paired plans: threads per tile = columns of a tile's slot array (256 or 512)
 };
 constexpr int kChunks = 3;
 
@@ -89,7 +95,7 @@ constexpr int kChunks = 3;
 int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
                     int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, int32_t chunk_cap,
-                    HostPlan &out);
+                    HostPlan &out, int32_t pair_block = 256, int32_t shards = 1);
 
 void set_plan_curve(int c);   // 0 Morton, 1 Hilbert (default)
 void set_plan_read_pack(int v);     // paired slots packed against ds_read_b128 bank conflicts as well (default 1)

@@ -18,6 +18,7 @@ struct PlanDev {
     const int4 *tile_chunks;        // chunked plans only (HostPlan::tile_chunks)
     int node_stride;                // tile t's node_src records start at t * node_stride (HostPlan::node_stride)
     int elem_stride;                // tile t's slot records start at t * elem_stride
+    unsigned long long *span;       // span stamps (hfem_plan_set_span_stamps): {start, end} s_memrealtime ticks per tile, or NULL
 };
 
 struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
@@ -78,6 +79,10 @@ struct hfem_plan {
     // tuning options captured at creation (hfem_set_option only changes the defaults of LATER plans)
     struct Tune { int tiled_block = 512, store_policy = 16, tiled_fast = 1, fast_const_caps = 1, pair_tiles_per_wg = 1, pair_pipe_wps = 4; } tune;
     unsigned long long *d_stamps = nullptr;   // lab build only: [n_tiles][16] s_memrealtime stamps (NULL otherwise)
+    // span stamps (hfem_plan_set_span_stamps; caller-owned buffer of span_slots x n_tiles x 2 uint64): launch i of the
+    // paired-slot kernel writes every tile's {start, end} into slot span_next++ % span_slots.  Guarded by `mu`.
+    unsigned long long *span_buf = nullptr;
+    int64_t span_slots = 0, span_next = 0;
     int64_t device_bytes = 0;
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
@@ -85,7 +90,7 @@ struct hfem_plan {
 
 namespace hfem {
 inline PlanDev plan_dev(const hfem_plan *p) {
-    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi, p->d_tile_chunks, p->host.node_stride, p->host.elem_stride};
+    return PlanDev{p->d_tiles, p->d_elem_pack, p->d_node_src, p->d_edge_pack, p->d_edge_gid, p->d_elem_pack_hi, p->d_tile_chunks, p->host.node_stride, p->host.elem_stride, nullptr};
 }
 inline Tri3Consts make_consts(const double mat[4], double W, const double Bk[6]) {
     Tri3Consts k;
@@ -113,6 +118,7 @@ struct PairLaunch {
     int chain = -1;               // -1: by the plan (chained records -> carrying slot loop); lab: 0 / 1 forces
     int lab_bits = 0;             // lab build: ablation bits (tri3_pair.hip)
     int col_stride = 256;         // columns of every tile's slot array (HostPlan::col_stride)
+    unsigned long long *span = nullptr;   // this launch's span-stamp slot (or NULL)
     size_t lds = 0;
     hipStream_t s = nullptr;
 };
@@ -125,6 +131,9 @@ int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed
                     const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,
                     double *gx_free, double *gu_free, int skip_edges, bool phys, hipStream_t s);
 void free_tri3_det(hfem_plan *plan);
+// exchange.hip: interface pack + tile-energy sum + step-counter bump in one launch (hfem_plan_iface_pack)
+int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
+                          int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, hipStream_t s);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

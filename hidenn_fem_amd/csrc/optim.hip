@@ -101,6 +101,36 @@ __global__ __launch_bounds__(256) void adam_step_rows_dev_kernel(double2 *__rest
     m[r] = mi; v[r] = vi; p[r] = pi;
 }
 
+// both parameter tensors of the TRI3 model in one launch: rows_x[n_x] of (px, gx, mx, vx) with lr_x, then rows_u[n_u] of
+// (pu, gu, mu, vu) with lr_u; the step the bias corrections use is step_dev[0] + step_offset
+__global__ __launch_bounds__(256) void adam_step_rows2_dev_kernel(double2 *__restrict__ px, const double2 *__restrict__ gx,
+                                                                  double2 *__restrict__ mx, double2 *__restrict__ vx,
+                                                                  const int32_t *__restrict__ rows_x, int64_t n_x, double lr_x,
+                                                                  double2 *__restrict__ pu, const double2 *__restrict__ gu,
+                                                                  double2 *__restrict__ mu, double2 *__restrict__ vu,
+                                                                  const int32_t *__restrict__ rows_u, int64_t n_u, double lr_u,
+                                                                  double b1, double b2, double eps,
+                                                                  const int64_t *__restrict__ step_dev, int64_t step_offset) {
+    const double step = (double)(step_dev[0] + step_offset);
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const double sqrt_bc2 = sqrt(bc2), w1 = 1.0 - b1, w2 = 1.0 - b2;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_x + n_u) return;
+    const bool isx = i < n_x;
+    if (!isx) i -= n_x;
+    double2 *p = isx ? px : pu, *m = isx ? mx : mu, *v = isx ? vx : vu;
+    const double2 *g = isx ? gx : gu;
+    const double step_size = (isx ? lr_x : lr_u) / bc1;
+    const int32_t r = (isx ? rows_x : rows_u)[i];
+    const double2 gi = g[r], m0 = m[r], v0 = v[r], p0 = p[r];
+    double2 mi, vi, pi;
+    mi.x = m0.x + w1 * (gi.x - m0.x); mi.y = m0.y + w1 * (gi.y - m0.y);
+    vi.x = v0.x * b2 + w2 * (gi.x * gi.x); vi.y = v0.y * b2 + w2 * (gi.y * gi.y);
+    pi.x = p0.x - step_size * (mi.x / (sqrt(vi.x) / sqrt_bc2 + eps));
+    pi.y = p0.y - step_size * (mi.y / (sqrt(vi.y) / sqrt_bc2 + eps));
+    m[r] = mi; v[r] = vi; p[r] = pi;
+}
+
 __global__ void counter_add_kernel(int64_t *c, int64_t inc) { c[0] += inc; }
 
 // step += 1; bc = {1 - b1^step, sqrt(1 - b2^step)}: the scalars of one Adam step, for kernels that fuse the update
@@ -171,6 +201,23 @@ extern "C" int hfem_adam_step_rows_dev(int device, double *p, const double *g, d
                        (double2 *)p, (const double2 *)g, (double2 *)m, (double2 *)v, rows, n_rows, beta1, beta2, lr, eps,
                        step_dev);
     return launch_status("hfem_adam_step_rows_dev");
+}
+
+extern "C" int hfem_adam_step_rows2_dev(int device, double *px, const double *gx, double *mx, double *vx,
+                                        const int32_t *rows_x, int64_t n_x, double lr_x, double *pu, const double *gu,
+                                        double *mu, double *vu, const int32_t *rows_u, int64_t n_u, double lr_u,
+                                        double beta1, double beta2, double eps, const int64_t *step_dev,
+                                        int64_t step_offset, void *stream) {
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0, "negative row count");
+    if (n_x + n_u == 0) return 0;
+    HFEM_ARG_CHECK(step_dev && (n_x == 0 || (px && gx && mx && vx && rows_x)) && (n_u == 0 || (pu && gu && mu && vu && rows_u)),
+                   "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(adam_step_rows2_dev_kernel, dim3((int)((n_x + n_u + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (double2 *)px, (const double2 *)gx, (double2 *)mx, (double2 *)vx, rows_x, n_x, lr_x, (double2 *)pu,
+                       (const double2 *)gu, (double2 *)mu, (double2 *)vu, rows_u, n_u, lr_u, beta1, beta2, eps, step_dev,
+                       step_offset);
+    return launch_status("hfem_adam_step_rows2_dev");
 }
 
 extern "C" int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream) {

@@ -544,7 +544,8 @@ void cut_tiles(const int64_t *conn, int npe, int64_t ne, int64_t nn, const std::
 
 int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *xy, const int32_t *x_src,
               const int32_t *u_src, const int64_t *edges, int64_t ned, int32_t T, int32_t node_cap,
-              const std::vector<int32_t> &order, int elem_order, int32_t chunk_cap, HostPlan &P) {
+              const std::vector<int32_t> &order, int elem_order, int32_t chunk_cap, int32_t pair_block, int32_t shards,
+              HostPlan &P) {
     std::vector<int64_t> bounds;
     cut_tiles(conn, npe, ne, nn, order, T, node_cap, bounds);
     const int32_t nt_main = ne > 0 ? (int32_t)bounds.size() - 1 : 0;
@@ -565,6 +566,16 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
         if (owner[n] == std::numeric_limits<int32_t>::max())
             owner[n] = nt_main + (int32_t)(n_orphan++ / kOrphanTileNodes);
     const int32_t nt = nt_main + (int32_t)((n_orphan + kOrphanTileNodes - 1) / kOrphanTileNodes);
+
+    // element sharding (shards > 1): rank r evaluates the contiguous tile range [nt r / shards, nt (r + 1) / shards).  A tile is
+    // a BOUNDARY tile of its rank when it reads a node that a tile of another rank owns, or owns a node that a tile of
+    // another rank reads -- only those tiles take part in the interface exchange of the owner-sharded mode
+    // (hidenn_fem_amd/sharded.py); the rest (interior) depend on nothing another rank produces.
+    if (shards < 1) shards = 1;
+    std::vector<int32_t> shard_of(nt, 0);
+    std::vector<char> bnd(nt, 0);
+    for (int32_t r = 0; r < shards; ++r)
+        for (int64_t t = ((int64_t)nt * r) / shards; t < ((int64_t)nt * (r + 1)) / shards; ++t) shard_of[t] = r;
 
     // node -> element adjacency (CSR), elements listed in sorted-position order
     std::vector<int64_t> adj_ptr(nn + 1, 0);
@@ -651,6 +662,9 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             }
         std::sort(halo.begin(), halo.end());
         if (d.n_owned + (int32_t)halo.size() > kMaxLocal) return 1;
+        if (shards > 1)
+            for (int32_t n : halo)
+                if (shard_of[owner[n]] != shard_of[t]) { bnd[t] = 1; bnd[owner[n]] = 1; }
         int32_t chunk_rec[4] = {0, 0, 0, 0};
         if (chunked) {
             // ---- strips: sort the tile's elements along the longer side of their bounding box (centroids; without
@@ -769,7 +783,8 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             std::vector<char> chain(slots.size(), 0);           // slot's b, c rows are carried into the next slot of its column
             size_t n_pair = 0;
             while (n_pair < slots.size() && slots[n_pair][1] >= 0) ++n_pair;
-            d.pad = 256;                                        // column stride of the slot array (slot j of thread t at j*stride + t)
+            d.pad = pair_block;                                 // column stride of the slot array (slot j of thread t at j*stride + t)
+            if (elem_order == 6 && pair_block != 256) { set_error("plan: the strip order (lab) needs 256-thread tiles"); return -1; }
             if (elem_order == 6) {
                 // ---- strips: pair Q follows pair P in a strip when Q.n = P.b and Q.d = P.c (the next split quad along a
                 //      row): the thread that walks the strip keeps P's rows of b and c in registers and adds them to Q's
@@ -878,7 +893,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
                 pack_slot_groups(part, d.n_owned, o);
                 for (int32_t v : o) order_s.push_back(v < 0 ? -1 : v + (int32_t)n_pair);
             }
-            P.max_rows = std::max(P.max_rows, ((int)order_s.size() + 255) / 256);
+            P.max_rows = std::max(P.max_rows, ((int)order_s.size() + pair_block - 1) / pair_block);
             }
             d.n_elem = (int32_t)order_s.size();
             for (int32_t si : order_s) {
@@ -934,6 +949,27 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
         P.max_owned = std::max(P.max_owned, d.n_owned);
         P.max_elems = std::max(P.max_elems, d.n_elem);
         P.max_edges = std::max(P.max_edges, d.n_edge);
+    }
+    // ---- sharded plans: inside every rank's tile range the boundary tiles come first, so that a rank launches them as one
+    //      contiguous sub-range, starts the interface exchange, and runs the interior sub-range under it.  Ownership was
+    //      fixed above; the tile index only decides where a tile's records live, which workgroup walks it and where its
+    //      partial energy goes (the loss is summed in the new tile order).
+    P.shards = shards;
+    P.pair_block = pair_block;
+    P.shard_desc.clear();
+    {
+        std::vector<TileDesc> sorted_tiles;
+        sorted_tiles.reserve(nt);
+        for (int32_t r = 0; r < shards; ++r) {
+            const int32_t lo = (int32_t)(((int64_t)nt * r) / shards), hi = (int32_t)(((int64_t)nt * (r + 1)) / shards);
+            for (int32_t t = lo; t < hi; ++t)
+                if (bnd[t]) sorted_tiles.push_back(P.tiles[t]);
+            const int32_t mid = (int32_t)sorted_tiles.size();
+            for (int32_t t = lo; t < hi; ++t)
+                if (!bnd[t]) sorted_tiles.push_back(P.tiles[t]);
+            P.shard_desc.insert(P.shard_desc.end(), {lo, mid, hi, 0});
+        }
+        if (shards > 1) P.tiles.swap(sorted_tiles);
     }
     // ---- uniform node stride: tile t's row-map records start at t * node_stride, so a kernel can load them from its
     //      tile index alone, in parallel with the descriptor (one dependent memory round trip less: desc -> maps -> rows
@@ -1023,7 +1059,9 @@ void set_plan_read_pack(int v) { set_halfwave_pack(v); }
 int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double *coords,
                     const int32_t *x_src, const int32_t *u_src, const int64_t *edges,
                     int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, int32_t chunk_cap,
-                    HostPlan &out) {
+                    HostPlan &out, int32_t pair_block, int32_t shards) {
+    if (pair_block != 256 && pair_block != 512) { set_error("plan: pair_block must be 256 or 512"); return -1; }
+    if (shards < 1 || shards > 4096) { set_error("plan: shards must be in [1, 4096]"); return -1; }
     if (npe != 3 && npe != 4) { set_error("plan: nodes per element must be 3 (TRI3) or 4 (QUAD4)"); return -1; }
     if (ne < 0 || nn < 0 || ned < 0 || nn > std::numeric_limits<int32_t>::max() ||
         ne > std::numeric_limits<int32_t>::max() || ned > std::numeric_limits<int32_t>::max()) {
@@ -1041,9 +1079,10 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
     std::vector<int32_t> order;
     morton_order(conn, npe, ne, nn, coords, order);
     for (int32_t T = tile_elems; T >= 16; T = (T * 2) / 3) {
-        const int rc = try_build(conn, npe, ne, nn, coords, x_src, u_src, edges, ned, T, node_cap, order, elem_order, chunk_cap, out);
+        const int rc = try_build(conn, npe, ne, nn, coords, x_src, u_src, edges, ned, T, node_cap, order, elem_order, chunk_cap,
+                                 pair_block, shards, out);
         if (rc == 0 && npe == 4 && out.max_elems > kMaxQuadSlots) continue;   // QUAD4 kernel: <= 4 slots x 256 threads
-        if (rc == 0 && out.paired && out.max_rows > kMaxRows) continue;      // pair kernel: <= 6 slots per thread
+        if (rc == 0 && out.paired && out.max_rows > (pair_block == 512 ? 2 : kMaxRows)) continue;   // pair kernel: <= 6 slots per thread (2 at 512 threads)
         if (rc == 0) {
             out.conn32.assign(conn, conn + npe * ne);
             out.edges32.assign(edges, edges + 2 * ned);

@@ -706,6 +706,9 @@ struct Defaults {
     std::atomic<int> plan_read_pack{2};     // paired slots packed against ds_read_b128 bank conflicts too (partner rows examined; 0 off)
     std::atomic<int> plan_snap{0};          // tile cuts snap to coarse curve cells (percent of a tile they may move back)
     std::atomic<int> plan_chunk_cap{512};   // chunked plans: longest strip of a tile (slots)
+    std::atomic<int> plan_shards{1};        // ranks the plan's tiles will be sharded over (contiguous tile ranges): sizes the tiles
+                                            // for elements PER RANK and orders every rank's boundary tiles first (plan.cpp)
+    std::atomic<int> plan_pair_block{-1};   // paired plans: threads per tile, 256 or 512; -1 = by the shard-aware policy below
 } g_def;
 
 #ifdef HFEM_LAB
@@ -939,13 +942,34 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     std::unique_ptr<hfem_plan> p(new hfem_plan);
     p->tune = current_tune();
     int32_t node_cap = g_def.plan_node_cap.load();
-    if (node_cap < 0) node_cap = tile_elems <= 0 ? 557 : 0;
+    const int32_t shards = std::max(1, g_def.plan_shards.load());
+    int32_t pair_block = g_def.plan_pair_block.load();
+    // Shard-aware tile policy (TRI3, tile size left to the library).  A launch over E elements is one resident round of
+    // workgroups whatever E is, so what a small launch costs is the critical path of ONE tile: fewer slot rows per thread
+    // and, below ~256 tiles, smaller tiles.  Measured on one MI355X, kernel only, per-rank tile ranges of T1M and whole
+    // meshes of the same sizes (profiles/r03/shard_sweep_*.jsonl; us per launch, old -> new):
+    //   E > 600 k           557 home nodes per tile, 256 threads, three slot rows per thread      (1 M: 8.96; 512 threads: 11.0)
+    //   200 k < E <= 600 k  the same tiles, 512 threads, two slot rows                            (500 k: 6.4 -> 6.1, 250 k: 5.3 -> 4.8)
+    //   100 k < E <= 200 k  430 home nodes, 512 threads, ONE slot row, <= 1 tile per CU            (125 k: 5.2 -> 4.2)
+    //   E <= 100 k          208 home nodes, 256 threads, one slot row                             (62 k: 5.1 -> 3.7, 10 k: 5.2 -> 3.7)
+    const int64_t per_shard = ne / shards;
+    if (node_cap < 0) {
+        node_cap = 0;
+        if (tile_elems <= 0) {
+            node_cap = 557;
+            if (nodes_per_elem == 3 && per_shard <= 600000) {
+                if (pair_block < 0) pair_block = per_shard > 100000 ? 512 : 256;
+                if (per_shard <= 200000) node_cap = pair_block == 512 ? 430 : 208;
+            }
+        }
+    }
+    if (pair_block < 0) pair_block = 256;
     if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
     int order = g_def.plan_elem_order.load();
     const bool auto_order = order < 0;
     if (auto_order) order = nodes_per_elem == 3 ? 5 : 3;
     if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, order,
-                        g_def.plan_chunk_cap.load(), p->host))
+                        g_def.plan_chunk_cap.load(), p->host, pair_block, shards))
         return -1;
     if (auto_order && p->host.paired && 2 * p->host.n_pairs * 10 < 7 * ne) {
         // few fan-adjacent partners (local node orders are what they are -- they cannot be rotated): the
@@ -955,7 +979,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         // Delaunay (39 %, 0.44) 42.4-43.0 vs 41.9 us
         p->host = HostPlan();
         if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, 3,
-                            g_def.plan_chunk_cap.load(), p->host))
+                            g_def.plan_chunk_cap.load(), p->host, 256, shards))
             return -1;
     }
     const HostPlan &h = p->host;
@@ -1000,6 +1024,10 @@ extern "C" int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out) 
     out->max_tile_elems = h.max_elems; out->max_tile_edges = h.max_edges;
     out->device_bytes = plan->device_bytes;
     out->lds_bytes = plan->lds_bytes;
+    out->shards = h.shards;
+    out->threads_per_tile = h.paired ? h.pair_block : (h.npe == 4 ? 256 : plan->tune.tiled_block);
+    out->paired = h.paired ? 1 : 0;
+    out->slot_rows = h.paired ? h.max_rows : 0;
     return 0;
 }
 
@@ -1019,6 +1047,7 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 7: src = h.elem_pack_hi.data(); n = (int64_t)h.elem_pack_hi.size(); break;
         case 8: src = h.tile_chunks.data(); n = (int64_t)h.tile_chunks.size(); break;
         case 9: src = h.elem_gid_b.data(); n = (int64_t)h.elem_gid_b.size(); break;
+        case 10: src = h.shard_desc.data(); n = (int64_t)h.shard_desc.size(); break;
         case 6: {   // lab build: device stamps, 16 x uint64 per tile, returned as 32 x int32 per tile
             n = (int64_t)h.tiles.size() * 32;
             if (buf) {
@@ -1081,7 +1110,11 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
     HFEM_ARG_CHECK(!lag_consume || plan->prev_stream == stream,
                    "HFEM_FLAG_SUM_PREVIOUS: the previous unsummed launch went to another stream (one plan = one stream)");
-    const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
+    // HFEM_FLAG_SAME_BANK: this launch is another tile range of the SAME evaluation as the previous unsummed launch (boundary
+    // tiles after interior tiles, hidenn_fem_amd/sharded.py): its tile energies go to the bank that launch wrote
+    const bool same_bank = (flags & HFEM_FLAG_SAME_BANK) != 0;
+    HFEM_ARG_CHECK(!same_bank || ((flags & HFEM_FLAG_NO_LOSS_SUM) && !lag_consume), "HFEM_FLAG_SAME_BANK needs HFEM_FLAG_NO_LOSS_SUM and excludes HFEM_FLAG_SUM_PREVIOUS");
+    const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (same_bank ? plan->bank : (plan->bank ^ 1)) : plan->bank;
     double *pbase = plan->d_partials + (size_t)wbank * nt;
     LagSum lag;
     if (lag_consume) {
@@ -1117,6 +1150,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
             P.chain = g_pair_chain; P.lab_bits = g_pair_ablate;
 #endif
             HFEM_ARG_CHECK(!(lag.prev && (hasb || phys)), "HFEM_FLAG_SUM_PREVIOUS: default forces and convention only");
+            if (plan->span_buf) P.span = plan->span_buf + (size_t)(plan->span_next++ % plan->span_slots) * 2 * (size_t)nt;
             int rc_pair = 0;
 #ifdef HFEM_LAB
             if (plan->tune.pair_tiles_per_wg > 1 && !hasb && !phys) {
@@ -1145,7 +1179,14 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         if (int rc = launch_status("hfem_tri3_energy_plan")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) {
-        plan->bank = wbank; plan->prev_begin = tile_begin; plan->prev_n = n > 0 ? n_partials : 0; plan->prev_stream = stream;
+        if (same_bank && plan->prev_n > 0 && n > 0 && n_partials == n &&
+            (tile_end == plan->prev_begin || tile_begin == plan->prev_begin + plan->prev_n)) {
+            plan->prev_begin = std::min(plan->prev_begin, (int)tile_begin);      // adjacent ranges of one evaluation: their union
+            plan->prev_n += n;
+        } else if (!same_bank || n > 0) {
+            plan->prev_begin = tile_begin; plan->prev_n = n > 0 ? n_partials : 0;
+        }
+        plan->bank = wbank; plan->prev_stream = stream;
         return 0;
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase + tile_begin, n_partials, loss_out);
@@ -1305,6 +1346,44 @@ extern "C" int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t t
     return launch_status("hfem_plan_loss_sum");
 }
 
+// Span stamps: a measurement aid for callers that need the duration of the energy kernel INSIDE a launch sequence
+// (bench.py's cache regimes; HIP events only see whole sequences and a profiler is not always at hand).  While a buffer is
+// set, launch i of the paired-slot kernel through hfem_tri3_energy_plan writes, for every tile it evaluates, the
+// s_memrealtime tick (100 MHz) at which the tile's workgroup started and the tick at which its first wave had issued and
+// drained its gradient stores, into dev_buf[(i % n_slots) * n_tiles * 2 + 2 * tile + {0, 1}].  max(end) - min(start) over
+// the tiles of a launch is its first-workgroup-start to last-workgroup-end span.  NULL switches it off (the default; the
+// kernel then pays one scalar compare).  Other kernels ignore the setting.
+extern "C" int hfem_plan_set_span_stamps(hfem_plan *plan, uint64_t *dev_buf, int64_t n_slots) {
+    HFEM_ARG_CHECK(plan, "null pointer");
+    HFEM_ARG_CHECK(dev_buf == nullptr || n_slots >= 1, "need n_slots >= 1 with a buffer");
+    PlanLock lock(plan);
+    plan->span_buf = (unsigned long long *)dev_buf;
+    plan->span_slots = dev_buf ? n_slots : 0;
+    plan->span_next = 0;
+    return 0;
+}
+
+// Owner-sharded step, one launch: pack this rank's interface rows into its all_gather payload (hfem_iface_pack), put
+// the sum of the tile energies that the HFEM_FLAG_NO_LOSS_SUM launch(es) over [tile_begin, tile_end) left in the plan into
+// out[loss_slot] (same order and bits as hfem_plan_loss_sum), and -- when `counter` is given -- bump that device counter
+// (the optimiser's step count: hfem_adam_step_rows2_dev reads it BEFORE this launch with step_offset = 1).
+extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
+                                    const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
+                                    int64_t loss_slot, int64_t *counter, void *stream) {
+    HFEM_ARG_CHECK(plan && out, "null pointer");
+    HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && loss_slot >= n_x + n_u, "bad sizes");
+    HFEM_ARG_CHECK((n_x + n_u == 0 || rows) && (n_x == 0 || x_free) && (n_u == 0 || u_free), "null pointer");
+    const int32_t nt = (int32_t)plan->host.tiles.size();
+    if (tile_end < 0) tile_end = nt;
+    HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
+    if (int rc = use_device(plan->device)) return rc;
+    PlanLock lock(plan);
+    return launch_iface_pack_sum(x_free, u_free, rows, n_x, n_u, out, loss_slot,
+                                 plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, counter,
+                                 (hipStream_t)stream);
+}
+
 // Options.  Product: tiled_block (256 / 512 / 1024 threads per tile), store_policy (0 plain, 16 sc1 write-through),
 // tiled_fast, fast_const_caps, quad4_const_caps, plan_elem_order (0..4), plan_node_cap, plan_chunk_cap, plan_curve
 // (0 Morton, 1 Hilbert): DEFAULTS that the next hfem_plan_create captures (a plan keeps what it was created with).
@@ -1333,6 +1412,12 @@ extern "C" int hfem_set_option(const char *name, int value) {
     } else if (n == "plan_chunk_cap") {
         HFEM_ARG_CHECK(value >= 0 && value <= 4096, "plan_chunk_cap: 0 (no limit) .. 4096 slots");
         g_def.plan_chunk_cap = value;
+    } else if (n == "plan_shards") {
+        HFEM_ARG_CHECK(value >= 1 && value <= 4096, "plan_shards: 1 .. 4096 ranks");
+        g_def.plan_shards = value;
+    } else if (n == "plan_pair_block") {
+        HFEM_ARG_CHECK(value == -1 || value == 256 || value == 512, "plan_pair_block: -1 (auto), 256 or 512 threads per tile");
+        g_def.plan_pair_block = value;
     } else if (n == "plan_curve") {
         HFEM_ARG_CHECK(value == 0 || value == 1, "plan_curve: 0 Morton, 1 Hilbert");
         set_plan_curve(value);
@@ -1413,6 +1498,8 @@ extern "C" int hfem_get_option(const char *name) {
     if (n == "plan_elem_order") return g_def.plan_elem_order.load();
     if (n == "plan_node_cap") return g_def.plan_node_cap.load();
     if (n == "plan_chunk_cap") return g_def.plan_chunk_cap.load();
+    if (n == "plan_shards") return g_def.plan_shards.load();
+    if (n == "plan_pair_block") return g_def.plan_pair_block.load();
     if (n == "plan_snap") return g_def.plan_snap.load();
     if (n == "plan_read_pack") return g_def.plan_read_pack.load();
     if (n == "lab_build") {

@@ -60,6 +60,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     }
     if (HFEM_PAIR_LAB(16)) return;                      // lab: dispatch cost of this grid shape alone
     const int slot = xcd_tile(blockIdx.x, n_launch);
+    // span stamps (hfem_plan_set_span_stamps, off by default): when this workgroup started -- scalar registers only
+    unsigned long long t_start = 0;
+    if (pd.span) t_start = __builtin_amdgcn_s_memrealtime();
     // ---- row maps first, from the tile index alone (uniform node stride, plan.cpp): these loads and the descriptor's are in
     //      flight together.  Unguarded: lanes past n_node read padding / the next tile's records -- valid rows, never stored.
     int2 s[NPT];
@@ -318,6 +321,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
         if (!HFEM_PAIR_LAB(256) || tile_e == 1.2345) partials[slot] = tile_e;
     }
+    if (pd.span && tid == 0) {                          // ... and when its first wave's stores had left (100 MHz ticks)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        pd.span[2 * (size_t)(tile_begin + slot)] = t_start;
+        pd.span[2 * (size_t)(tile_begin + slot) + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 constexpr int kPairCapN = 656, kPairCapO = 560;          // compile-time LDS strides of the default tile shape (557 owned nodes)
@@ -344,9 +352,28 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     const HostPlan &h = plan->host;
     if (!h.paired || !plan->d_elem_pack_hi) return 0;
     A.pd = plan_dev(plan);
+    A.pd.span = A.span;
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.lds = (size_t)plan->lds_bytes;
     A.col_stride = h.col_stride;
     if (A.chain < 0) A.chain = h.n_chained > 0 ? 1 : 0;   // chained records need the carrying slot loop
+    if (h.pair_block == 512) {
+        // 512 threads per tile (shard-aware tile policy, hfem_plan_create: launches of 100 k - 600 k elements): NPT = 2
+        // (<= 1024 nodes), one or two slot rows; the plain slot loop only
+        if (h.max_nodes > 2 * 512 || h.max_rows > 2 || A.chain) return 0;
+        if (mode == 0) {
+            if (h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN) launch_pair_inst2<512, 2, 2, 560, false, false, double2, false, false>(A, lag, af);
+            else launch_pair_inst2<512, 2, 2, 0, false, false, double2, false, false>(A, lag, af);
+            return 1;
+        }
+        if (mode == 1) {
+            if (phys) launch_pair_inst2<512, 2, 2, 0, true, true, double2, false, false>(A, lag, af);
+            else launch_pair_inst2<512, 2, 2, 0, true, false, double2, false, false>(A, lag, af);
+            return 1;
+        }
+        if (mode == 2) { launch_pair_inst2<512, 2, 2, 0, false, false, float2, false, false>(A, lag, af); return 1; }
+        if (mode == 3) { launch_pair_inst2<512, 2, 2, 0, false, false, double2, true, false>(A, lag, af); return 1; }
+        return 0;
+    }
     const bool cc = h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN;   // (656 + 560) * 32 + 128 = 39040 B: four workgroups per CU
     const int npt = h.max_nodes <= 3 * 256 ? 3 : 4;
     const int ept = h.max_rows > 0 ? h.max_rows : 1;     // slots per thread (0: a plan of element-less tiles)

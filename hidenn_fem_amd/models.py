@@ -321,16 +321,18 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
         return NeumannEdgesWrapper(self.coords, self.neumann_edges)
 
     # -- tile plan for the fused energy ----------------------------------------------------
-    def tile_plan(self, tile_elems: int = 0) -> TilePlan:
+    def tile_plan(self, tile_elems: int = 0, shards: int = 1) -> TilePlan:
+        """The owner-computes tile plan of this mesh on this device (built once, cached).  ``shards``: ranks the tiles
+        will be split over (``hidenn_fem_amd.sharded``): tiles sized for the elements per rank, boundary tiles first."""
         if self.device.type != "cuda":
             raise RuntimeError(f"hidenn_fem_amd: model is on {self.device}; the fused energy kernel needs a ROCm "
                                "device. There is no CPU fallback -- call model.to('cuda').")
-        key = (str(self.device), int(tile_elems))
+        key = (str(self.device), int(tile_elems)) if shards == 1 else (str(self.device), int(tile_elems), int(shards))
         if key not in self._plans:
             self._plans[key] = TilePlan(self.connectivity, self.Nnodes, coords_hint=self.initial_node_coords,
                                         x_src=self._x_src, u_src=self._u_src, edges=self.neumann_edges,
                                         tile_elems=tile_elems, device=self.device,
-                                        nodes_per_elem=getattr(self, "nodes_per_element", 3))
+                                        nodes_per_elem=getattr(self, "nodes_per_element", 3), shards=shards)
         return self._plans[key]
 
     # -- the (x_ref, element_id) forward contract -------------------------------------------

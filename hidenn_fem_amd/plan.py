@@ -16,7 +16,7 @@ import torch
 from . import _lib
 
 EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
-              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8, "elem_gid_b": 9}
+              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8, "elem_gid_b": 9, "shard_desc": 10}
 
 
 def _np(a, dtype):
@@ -42,7 +42,11 @@ class TilePlan:
 
     def __init__(self, connectivity, n_nodes: int, coords_hint=None, x_src=None, u_src=None,
                  edges=None, tile_elems: int = 0, device: Optional[torch.device] = None,
-                 elem_order: Optional[int] = None, nodes_per_elem: int = 3):
+                 elem_order: Optional[int] = None, nodes_per_elem: int = 3, shards: int = 1,
+                 pair_block: Optional[int] = None):
+        """``shards``: number of ranks the tiles will be split over (``shard_range`` / ``shard_parts``): the library sizes
+        the tiles for the elements PER RANK and puts every rank's boundary tiles first in its range (``plan_shards``).
+        ``pair_block``: threads per tile of a paired plan, 256 or 512 (``None``: the library's shard-aware policy)."""
         if nodes_per_elem not in (3, 4):
             raise ValueError("nodes_per_elem must be 3 (TRI3) or 4 (QUAD4)")
         self.nodes_per_elem = nodes_per_elem
@@ -66,16 +70,20 @@ class TilePlan:
             return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
 
         L = _lib.lib()
-        prev_order = None
-        if elem_order is not None:            # a creation-time default of the library: set, create, restore
-            prev_order = L.hfem_get_option(b"plan_elem_order")
-            _lib.check(L.hfem_set_option(b"plan_elem_order", int(elem_order)), "hfem_set_option")
+        # creation-time defaults of the library: set, create, restore
+        wanted = {b"plan_elem_order": elem_order, b"plan_shards": int(shards) if int(shards) != 1 else None,
+                  b"plan_pair_block": pair_block}
+        prev = {}
         try:
+            for name, val in wanted.items():
+                if val is not None:
+                    prev[name] = L.hfem_get_option(name)
+                    _lib.check(L.hfem_set_option(name, int(val)), "hfem_set_option")
             rc = L.hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
                                        p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
         finally:
-            if prev_order is not None:
-                L.hfem_set_option(b"plan_elem_order", prev_order)
+            for name, val in prev.items():
+                L.hfem_set_option(name, val)
         _lib.check(rc, "hfem_plan_create")
         st = _lib.PlanStats()
         _lib.check(_lib.lib().hfem_plan_get_stats(self._h, C.byref(st)), "hfem_plan_get_stats")
@@ -101,7 +109,7 @@ class TilePlan:
             out = out.reshape(-1, 8)
         elif name == "node_src":
             out = out.reshape(-1, 2)
-        elif name == "tile_chunks":
+        elif name in ("tile_chunks", "shard_desc"):
             out = out.reshape(-1, 4)
         elif name == "stamps":
             out = out.view(np.uint64).reshape(-1, 16)
@@ -151,6 +159,18 @@ class TilePlan:
         lo = (nt * rank) // world
         hi = (nt * (rank + 1)) // world
         return lo, hi
+
+    def shard_parts(self, rank: int, world: int):
+        """``(lo, mid, hi)``: boundary tiles ``[lo, mid)`` and interior tiles ``[mid, hi)`` of ``rank``.  Boundary tiles
+        read a node that another rank's tile owns, or own a node that another rank's tile reads; the plan orders them
+        first when it was created with ``shards == world``.  Any other plan (or ``world == 1``) has no such order, and
+        the whole range is reported as boundary (``mid == hi``) -- always correct, never overlapping."""
+        lo, hi = self.shard_range(rank, world)
+        if world > 1 and self.stats["shards"] == world:
+            sd = self.export("shard_desc")
+            assert (int(sd[rank, 0]), int(sd[rank, 2])) == (lo, hi), (sd[rank], lo, hi)
+            return lo, int(sd[rank, 1]), hi
+        return lo, (lo if world == 1 else hi), hi
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -102,9 +102,11 @@ class ShardedTri3Energy:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is not None and world is not None:      # planning / single-process tests: act as rank of world
             self.rank, self.world = rank, world
-        self.plan = plan if plan is not None else model.tile_plan(loss_fn.tile_elems)
-        self.lo, self.hi = self.plan.shard_range(self.rank, self.world)
+        # the model's plan for THIS world size: tiles sized for the elements per rank, every rank's boundary tiles first
+        self.plan = plan if plan is not None else model.tile_plan(loss_fn.tile_elems, shards=self.world)
+        self.lo, self.mid, self.hi = self.plan.shard_parts(self.rank, self.world)   # boundary [lo, mid), interior [mid, hi)
         self._evaluate = evaluate or self._evaluate_hip
+        self._hip = evaluate is None
         nx, nu = model.node_coords_free.numel(), model.u_free.numel()
         self._nx, self._nu = nx, nu
         dev = model.node_coords_free.device
@@ -238,7 +240,8 @@ class ShardedTri3Energy:
         self._need_src, self._need_dst = i32(np.concatenate(src)), i32(np.concatenate(dst))
         self.payload = torch.zeros(self.iface_stride, 2, dtype=F64, device=dev)
         self.gathered = torch.zeros(world * self.iface_stride, 2, dtype=F64, device=dev)
-        self.loss_global = torch.zeros((), dtype=F64, device=dev)
+        self._loss_slots = torch.zeros(2, dtype=F64, device=dev)      # the overlapped step alternates between the two
+        self.loss_global = self._loss_slots[0]
         self._pack, self._unpack = pack_unpack or (self._pack_hip, self._unpack_hip)
         self.interface_stats = dict(publish_x=int(n_pub[0][r]), publish_u=int(n_pub[1][r]), need_x=self._need_n[0],
                                     need_u=self._need_n[1], payload_bytes=int(self.iface_stride * 16))
@@ -250,12 +253,13 @@ class ShardedTri3Energy:
                                               self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1],
                                               self.payload.data_ptr(), _lib.stream_ptr(dev)), "hfem_iface_pack")
 
-    def _unpack_hip(self):
+    def _unpack_hip(self, loss=None):
         m, dev = self.model, self.send.device
+        loss = self.loss_global if loss is None else loss
         _lib.check(_lib.lib().hfem_iface_unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(),
                                                 self._need_dst.data_ptr(), self._need_n[0], self._need_n[1],
                                                 m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.world,
-                                                self.iface_stride, self.iface_rows, self.loss_global.data_ptr(),
+                                                self.iface_stride, self.iface_rows, loss.data_ptr(),
                                                 _lib.stream_ptr(dev)), "hfem_iface_unpack")
 
     def evaluate_owner(self):
@@ -319,9 +323,11 @@ class ShardedTri3Energy:
         return self.loss_global, c["out"][0], c["out"][1]
 
     # ------------------------------------------------------------------ a whole owner-sharded training iteration
-    def init_owner_adam(self, lr_x: float, lr_u: float, betas=(0.9, 0.999), eps: float = 1e-8):
-        """State of ``owner_train_step``: Adam moments of the rows this rank OWNS (full-size arrays, only owned rows
-        are ever touched), the device step counter and the owned-row lists.  Call once, before any graph capture."""
+    def init_owner_adam(self, lr_x: float, lr_u: float, betas=(0.9, 0.999), eps: float = 1e-8, adam=None):
+        """State of ``owner_train_step`` / ``owner_train_step_overlapped``: Adam moments of the rows this rank OWNS
+        (full-size arrays, only owned rows are ever touched), the device step counter (= completed steps) and the
+        owned-row lists.  Call once, before any graph capture.  ``adam`` is the test seam of the CPU multi-process
+        tests (torch indexing standing in for ``hfem_adam_step_rows2_dev``)."""
         dev = self.send.device
         xr, ur = self.owned_rows()
         m = self.model
@@ -330,28 +336,123 @@ class ShardedTri3Energy:
                           mu=torch.zeros_like(m.u_free.data), vu=torch.zeros_like(m.u_free.data),
                           step=torch.zeros(1, dtype=torch.int64, device=dev), lr=(float(lr_x), float(lr_u)),
                           betas=(float(betas[0]), float(betas[1])), eps=float(eps))
+        self._adam_step = adam or self._adam_hip
+        self._e_parts = torch.zeros(2, dtype=F64, device=dev)      # seam evaluators: energies of the two tile sub-ranges
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._pending = None
         return self
+
+    def _adam_hip(self):
+        """torch.optim.Adam's update on the rows this rank owns, both parameter tensors in ONE launch; the step it uses
+        is (completed steps) + 1 -- the counter is bumped by the pack launch that follows."""
+        a, m = self._adam, self.model
+        dev = self.send.device
+        _, gx_v, gu_v = self._views(self.send)
+        _lib.check(_lib.lib().hfem_adam_step_rows2_dev(
+            _lib.dev_index(dev), m.node_coords_free.data_ptr(), gx_v.data_ptr(), a["mx"].data_ptr(), a["vx"].data_ptr(),
+            a["rows_x"].data_ptr(), a["rows_x"].numel(), a["lr"][0], m.u_free.data_ptr(), gu_v.data_ptr(),
+            a["mu"].data_ptr(), a["vu"].data_ptr(), a["rows_u"].data_ptr(), a["rows_u"].numel(), a["lr"][1],
+            a["betas"][0], a["betas"][1], a["eps"], a["step"].data_ptr(), 1, _lib.stream_ptr(dev)), "hfem_adam_step_rows2_dev")
+
+    def _eval_range(self, lo, hi, part, cont):
+        """Energy + gradients over ONE tile range of an evaluation; ``cont``: an earlier range of the same evaluation was
+        launched.  The tile energies stay in the plan (HIP: HFEM_FLAG_NO_LOSS_SUM, later ranges HFEM_FLAG_SAME_BANK; seam
+        evaluators: ``_e_parts[part]``) until ``_pack_loss`` sums them."""
+        _, gx_v, gu_v = self._views(self.send)
+        if not self._hip:
+            self._e_parts[part] = 0.0
+            if hi > lo:
+                self._evaluate(lo, hi, self._e_parts[part:part + 1], gx_v, gu_v)
+        elif hi > lo:
+            self._evaluate_hip(lo, hi, self.loss_global, gx_v, gu_v, 8 | (256 if cont else 0))
+
+    def _pack_loss(self):
+        """Interface rows + this rank's energy into the payload, step counter += 1 (HIP: one launch)."""
+        if self._hip:
+            m, dev = self.model, self.send.device
+            _lib.check(_lib.lib().hfem_plan_iface_pack(
+                self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
+                self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
+                self._adam["step"].data_ptr(), _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
+        else:
+            self._pack()
+            with torch.no_grad():
+                self.payload[self.iface_rows, 0] = self._e_parts[0] + self._e_parts[1]
+                self._adam["step"] += 1
 
     def owner_train_step(self):
         """ONE training iteration of the owner-sharded mode, all stream-ordered launches (capturable when ``comm`` is
-        a ``LibraryComm``): energy + gradients of this rank's tiles -> Adam on the rows this rank owns
-        (``hfem_adam_step_rows_dev``) -> pack the updated interface rows + the partial energy -> ONE all_gather ->
-        copy in the interface rows this rank's tiles read, sum the partial energies in rank order.  Returns the
-        global energy at the parameters BEFORE the update (as ``loss = closure(); optimizer.step()`` reports it)."""
-        a, L, m = self._adam, _lib.lib(), self.model
-        dev = self.send.device
-        di, sp = _lib.dev_index(dev), _lib.stream_ptr(dev)
-        _, gx_v, gu_v = self._views(self.send)
-        self._evaluate_hip(self.lo, self.hi, self.payload[self.iface_rows, 0:1], gx_v, gu_v)
-        _lib.check(L.hfem_counter_add(di, a["step"].data_ptr(), 1, sp), "hfem_counter_add")
-        for p, g, mm, vv, rows, lr in ((m.node_coords_free, gx_v, a["mx"], a["vx"], a["rows_x"], a["lr"][0]),
-                                       (m.u_free, gu_v, a["mu"], a["vu"], a["rows_u"], a["lr"][1])):
-            _lib.check(L.hfem_adam_step_rows_dev(di, p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(),
-                                                 rows.data_ptr(), rows.numel(), lr, a["betas"][0], a["betas"][1],
-                                                 a["eps"], a["step"].data_ptr(), sp), "hfem_adam_step_rows_dev")
-        self._pack()
+        a ``LibraryComm``): energy + gradients of this rank's tiles -> Adam on the rows this rank owns -> pack the
+        updated interface rows + the partial energy -> ONE all_gather -> copy in the interface rows this rank's tiles
+        read, sum the partial energies in rank order.  Four launches + the collective.  Returns the global energy at
+        the parameters BEFORE the update (as ``loss = closure(); optimizer.step()`` reports it)."""
+        self._eval_range(self.lo, self.hi, 0, False)
+        if not self._hip:
+            self._e_parts[1] = 0.0
+        self._adam_step()
+        self._pack_loss()
         self._gather_payloads()
         self._unpack()
+        return self.loss_global
+
+    def owner_train_step_overlapped(self):
+        """The same iteration with the exchange of step k hidden under the interior tiles of step k + 1.
+
+        Interior tiles (``plan.shard_parts``: ~95 % of a rank's tiles) read only rows this rank owns, so they never
+        wait for another rank.  Per step, on the main stream: interior tiles -> JOIN the previous step's exchange ->
+        boundary tiles -> Adam on all owned rows (after BOTH evaluations: boundary-owned rows are halo of interior
+        tiles) -> pack; then FORK: all_gather + unpack run on a side stream (unpack writes only rows other ranks own,
+        which no interior tile reads) while the next step's interior tiles run.  Same arithmetic, launch for launch, as
+        ``owner_train_step``.  ``loss_global`` lags: after step k returns it holds the energy of step k - 1;
+        ``finish_overlapped()`` joins the last exchange (call it before reading parameters or the loss, and at the end
+        of every captured graph)."""
+        self._eval_range(self.mid, self.hi, 0, False)              # interior: depends on nothing another rank produces
+        self._join_exchange()                                      # foreign interface rows of the previous step are in
+        self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)   # boundary tiles, same evaluation
+        self._adam_step()
+        self._pack_loss()
+        self._fork_exchange()
+        return self.loss_global
+
+    def _fork_exchange(self):
+        """all_gather + unpack of THIS step off the main stream.  The global energy goes to the loss slot the caller is
+        not looking at; ``_join_exchange`` makes it ``loss_global``."""
+        slot = self._loss_slots[1] if self.loss_global.data_ptr() == self._loss_slots[0].data_ptr() else self._loss_slots[0]
+        if self._side is not None:                                 # GPU: all_gather + unpack on the side stream
+            main = torch.cuda.current_stream(self.send.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self._gather_payloads()
+                if self._unpack == self._unpack_hip:
+                    self._unpack_hip(slot)
+                else:
+                    raise RuntimeError("owner_train_step_overlapped on a GPU needs the HIP pack / unpack")
+            self._pending = (None, slot)
+        elif self.world > 1 and self.comm is None:                 # CPU processes (gloo tests): asynchronous collective
+            self._pending = (dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group, async_op=True), slot)
+        else:
+            self._gather_payloads()
+            self._pending = (None, slot)
+
+    def _join_exchange(self):
+        if self._pending is None:
+            return
+        work, slot = self._pending
+        if self._side is not None:
+            torch.cuda.current_stream(self.send.device).wait_stream(self._side)
+            self.loss_global = slot
+        else:
+            if work is not None:
+                work.wait()
+            self.loss_global = slot
+            self._unpack()                                         # the seam writes self.loss_global
+        self._step_cache = None                                    # owner_step() caches the loss pointer
+        self._pending = None
+
+    def finish_overlapped(self):
+        """Join the exchange ``owner_train_step_overlapped`` left in flight: parameters and ``loss_global`` (the energy
+        of the last step) are then complete on this rank."""
+        self._join_exchange()
         return self.loss_global
 
     def owned_rows(self):

@@ -94,6 +94,10 @@ typedef struct hfem_plan_stats {
     int32_t max_tile_nodes, max_tile_owned, max_tile_elems, max_tile_edges;
     int64_t device_bytes;                 /* plan arrays resident in HBM */
     int32_t lds_bytes;                    /* dynamic LDS per workgroup */
+    int32_t shards;                       /* ranks the tile order was prepared for ("plan_shards"; 1 = not sharded) */
+    int32_t threads_per_tile;             /* workgroup size of the tiled kernel this plan takes */
+    int32_t paired;                       /* 1: paired slots (two fan-adjacent TRI3 per slot) */
+    int32_t slot_rows;                    /* paired plans: slots per thread in the widest tile */
 } hfem_plan_stats;
 
 int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
@@ -112,7 +116,8 @@ int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
  * 5 elem_gid i32 (global element id of every slot's element A; -1 = padding), 6 lab stamps
  * (lab build only), 7 elem_pack_hi u32 (QUAD4 plans: 4th local node of every slot; paired TRI3
  * plans: node d + presence/home bits of element B), 8 tile_chunks (chunked lab order), 9 elem_gid_b
- * i32 (paired plans: global id of every slot's element B; -1 = none).
+ * i32 (paired plans: global id of every slot's element B; -1 = none), 10 shard_desc [shards][4] i32 = {tile_lo,
+ * tile_mid, tile_hi, 0} per rank: the rank's boundary tiles are [tile_lo, tile_mid), its interior tiles [tile_mid, tile_hi).
  * Returns the element count, or <0.  buf may be NULL to query the size.  The per-tile arrays are laid out
  * with uniform strides (tile t's node records start at t * node_stride, its slot records at t * elem_stride, padded;
  * extra records follow the last tile): walk them through tile_desc's offsets and counts, not as dense arrays.    */
@@ -135,6 +140,11 @@ int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t ca
                                    * loss_out -- the energy of evaluation k arrives with launch k+1, and the 1-block
                                    * reduction + kernel boundary leave the critical path.  hfem_plan_loss_sum
                                    * delivers the last one.  TRI3 default kernel path only.                    */
+
+#define HFEM_FLAG_SAME_BANK 256 /* with NO_LOSS_SUM: another tile range of the SAME evaluation as the previous NO_LOSS_SUM
+                                 * launch on this plan (a rank's boundary tiles after its interior tiles): the tile energies
+                                 * go to the bank that launch wrote, so one hfem_plan_loss_sum / hfem_plan_iface_pack over
+                                 * the union delivers the evaluation's energy.  Not with SUM_PREVIOUS.          */
 
 /* One fwd+bwd "element-eval" pass over tiles [tile_begin, tile_end):
  *   loss_out[0]  = sum_elem A (W psi - beta)  -  sum_edge ds m        (OVERWRITTEN)
@@ -176,6 +186,14 @@ int hfem_adam_prep(int device, int64_t *step_dev, double beta1, double beta2, do
 /* loss_out[0] = sum, in tile order, of the per-tile partial energies that a launch with
  * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
 int hfem_plan_loss_sum(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, double *loss_out, void *stream);
+
+/* Span stamps (measurement aid): while dev_buf (n_slots x n_tiles x 2 uint64, caller-owned device memory) is set, launch i
+ * of the paired-slot kernel through hfem_tri3_energy_plan writes for every tile it evaluates {tick at which the tile's
+ * workgroup started, tick at which its first wave's gradient stores had drained} (s_memrealtime, 100 MHz) at
+ * dev_buf[(i % n_slots) * n_tiles * 2 + 2 * tile].  max(end) - min(start) over a launch's tiles = its duration from the
+ * first workgroup's start to the last one's end, measurable INSIDE any launch sequence (bench.py's cache regimes).
+ * NULL = off (default).  Plans that take another kernel ignore it.                                                */
+int hfem_plan_set_span_stamps(hfem_plan *plan, uint64_t *dev_buf, int64_t n_slots);
 
 /* Process-wide DEFAULTS (atomics) that hfem_plan_create captures into the plan it builds; changing one
  * never affects an existing plan, and launches on different plans may run from different threads (a plan
@@ -324,6 +342,14 @@ int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const 
                       int32_t n_u, double *x_free, double *u_free, int32_t world, int64_t stride,
                       int64_t loss_slot, double *loss_out, void *stream);
 
+/* hfem_iface_pack + the rank's energy + the optimiser's step counter in ONE launch (the owner-sharded training step is a
+ * chain of small dependent launches, each worth a kernel boundary): out as hfem_iface_pack; out[loss_slot] = {sum, in tile
+ * order, of the tile energies that the HFEM_FLAG_NO_LOSS_SUM launch(es) over [tile_begin, tile_end) left in the plan, 0};
+ * counter (may be NULL) += 1.  loss_slot >= n_x + n_u, in double2 units.                                          */
+int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
+                         const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
+                         int64_t loss_slot, int64_t *counter, void *stream);
+
 /* In-library collectives: one RCCL communicator per rank (one process per GPU).  Rank 0 calls
  * hfem_mg_unique_id and broadcasts the 128 bytes by any side channel (torch.distributed, a file, MPI); every rank
  * then calls hfem_mg_comm_create.  The collectives only ENQUEUE on the caller's stream -- in stream order right
@@ -343,6 +369,14 @@ int hfem_mg_allgather(hfem_mg_comm *comm, const double *send, double *recv, int6
 int hfem_adam_step_rows_dev(int device, double *p, const double *g, double *m, double *v, const int32_t *rows,
                             int64_t n_rows, double lr, double beta1, double beta2, double eps,
                             const int64_t *step_dev, void *stream);
+
+/* Both parameter tensors of the triangular model in one launch: rows_x[n_x] of (px, gx, mx, vx) with lr_x and rows_u[n_u]
+ * of (pu, gu, mu, vu) with lr_u.  The (1-based) step of the bias corrections is step_dev[0] + step_offset: 0 when the
+ * counter was bumped before (hfem_counter_add), 1 when it is bumped after (hfem_plan_iface_pack).                */
+int hfem_adam_step_rows2_dev(int device, double *px, const double *gx, double *mx, double *vx, const int32_t *rows_x,
+                             int64_t n_x, double lr_x, double *pu, const double *gu, double *mu, double *vu,
+                             const int32_t *rows_u, int64_t n_u, double lr_u, double beta1, double beta2, double eps,
+                             const int64_t *step_dev, int64_t step_offset, void *stream);
 
 /* ------------------------------------------------------------------ 1D / structured
  * Grid parametrisation softplus -> clamp(1e-6) -> cumsum -> renormalise

@@ -326,3 +326,151 @@ def test_library_comm_owner_training_step_captures_into_a_graph():
     torch.cuda.synchronize()
     assert torch.equal(sh2.recv, sh2.send)
     comm.close()
+
+
+@pytest.mark.gpu
+def test_overlapped_training_step_hip_eager_and_captured():
+    """owner_train_step_overlapped on the GPU: interior tiles -> join -> boundary tiles (HFEM_FLAG_SAME_BANK) -> Adam (one
+    launch for both tensors) -> pack + energy + step counter (one launch) -> all_gather + unpack on a side stream.  One
+    rank on the in-library RCCL communicator with the tile range split artificially into 'boundary' and 'interior' parts
+    (the split only changes which launch evaluates a tile); eager and 4 iterations per hipGraph; against the plain
+    single-GPU loop (value_and_grad_ + FusedAdam) and the non-overlapped owner_train_step."""
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import FusedAdam
+    from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 151, jitter=0.2, seed=8, dtype=F64)
+
+    def model():
+        torch.manual_seed(4)
+        return PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                        neumann_edges=edges).to(d)
+    lr_x, lr_u, n_iter, per = 1e-6, 1e-8, 13, 4
+    m0 = model()
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    opt = FusedAdam([dict(params=[m0.node_coords_free], lr=lr_x), dict(params=[m0.u_free], lr=lr_u)])
+    ref_losses = []
+    for _ in range(n_iter):
+        ref_losses.append(lf.value_and_grad_(m0).item())
+        opt.step()
+    comm = LibraryComm(d)
+
+    def sharded(m, split):
+        sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm)
+        sh.setup_interfaces()
+        sh.init_owner_adam(lr_x, lr_u)
+        assert (sh.lo, sh.mid, sh.hi) == (0, 0, sh.plan.n_tiles)
+        if split:
+            sh.mid = sh.plan.n_tiles // 3
+        return sh
+    for split in (False, True):
+        # eager
+        m1 = model()
+        sh1 = sharded(m1, split)
+        got = []
+        for k in range(n_iter):
+            sh1.owner_train_step_overlapped()
+            if k:
+                got.append(sh1.loss_global.item())             # lags one step (a device-to-host read joins the streams)
+        got.append(sh1.finish_overlapped().item())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(got, ref_losses, rtol=1e-12)
+        for a, b in zip(m1.parameters(), m0.parameters()):
+            assert (a - b).abs().max().item() <= 1e-12 * b.abs().max().item()
+        assert int(sh1._adam["step"].item()) == n_iter
+        # `per` iterations per hipGraph replay; every graph ends joined
+        m2 = model()
+        sh2 = sharded(m2, split)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            sh2.owner_train_step_overlapped()
+            first = sh2.finish_overlapped().item()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        losses = torch.zeros(per, dtype=F64, device=d)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(per):
+                sh2.owner_train_step_overlapped()
+                if i:
+                    losses[i - 1].copy_(sh2.loss_global)        # after the join inside the step: energy of step i - 1
+            losses[per - 1].copy_(sh2.finish_overlapped())
+        got = [first]
+        n_replays = (n_iter - 1) // per
+        for _ in range(n_replays):
+            g.replay()
+            torch.cuda.synchronize()
+            got += losses.tolist()
+        np.testing.assert_allclose(got, ref_losses[:1 + n_replays * per], rtol=1e-12)
+        assert int(sh2._adam["step"].item()) == 1 + n_replays * per
+    # the non-overlapped step runs the same launches in another order
+    m3 = model()
+    sh3 = sharded(m3, False)
+    plain = [sh3.owner_train_step().item() for _ in range(n_iter)]
+    np.testing.assert_allclose(plain, ref_losses, rtol=1e-12)
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_same_bank_ranges_sum_to_the_whole_evaluation_and_span_stamps():
+    """HFEM_FLAG_SAME_BANK: two tile ranges of one evaluation leave their tile energies in one bank, hfem_plan_loss_sum
+    over the union = the single-launch energy, bit for bit.  Span stamps: every tile of a launch reports start <= end
+    ticks inside the launch's window, only while a buffer is set."""
+    import ctypes as C
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(701, 401, jitter=0.2, seed=4, dtype=F64)
+    torch.manual_seed(1)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    plan = m.tile_plan(0)
+    assert plan.is_paired()
+    L = _lib.lib()
+    dv = lambda v: (C.c_double * len(v))(*v)
+    _, Tconst = lf._traction(m, None)
+    xf, uf, xfix, ufix = m.node_coords_free.detach(), m.u_free.detach(), m.node_coords_fixed, m.u_fixed_rows()
+    gx, gu = torch.empty_like(xf), torch.empty_like(uf)
+    out = torch.zeros(4, dtype=F64, device=d)
+    st = torch.cuda.current_stream().cuda_stream
+    nt = plan.n_tiles
+
+    def run(slot, lo, hi, flags):
+        _lib.check(L.hfem_tri3_energy_plan(plan.handle, xf.data_ptr(), xfix.data_ptr(), uf.data_ptr(), ufix.data_ptr(),
+                                           dv(lf._mat), lf._W, dv([0.0] * 6), None, dv(Tconst), lo, hi,
+                                           out[slot:slot + 1].data_ptr(), gx.data_ptr(), gu.data_ptr(), flags, st), "energy")
+    run(0, 0, -1, 0)
+    g_ref = (gx.clone(), gu.clone())
+    mid = nt // 5
+    gx.zero_(); gu.zero_()
+    run(1, mid, nt, 8)                         # "interior" first ...
+    run(1, 0, mid, 8 | 256)                    # ... then "boundary", same bank
+    _lib.check(L.hfem_plan_loss_sum(plan.handle, 0, -1, out[2:3].data_ptr(), st))
+    torch.cuda.synchronize()
+    assert out[2].item() == out[0].item() and out[1].item() == 0.0
+    assert (gx - g_ref[0]).abs().max().item() <= 1e-12 * g_ref[0].abs().max().item()
+    with pytest.raises(RuntimeError):
+        run(3, 0, -1, 256)                     # SAME_BANK without NO_LOSS_SUM
+    # span stamps
+    slots = 3
+    buf = torch.zeros(slots * nt * 2, dtype=torch.int64, device=d)
+    _lib.check(L.hfem_plan_set_span_stamps(plan.handle, buf.data_ptr(), slots))
+    run(0, 0, -1, 8)
+    run(0, 3, nt - 2, 8)
+    torch.cuda.synchronize()
+    sp = buf.view(slots, nt, 2).cpu().numpy()
+    assert (sp[0, :, 0] > 0).all() and (sp[0, :, 1] >= sp[0, :, 0]).all()
+    span0 = (sp[0, :, 1].max() - sp[0, :, 0].min()) * 0.01       # 100 MHz ticks -> us
+    assert 1.0 < span0 < 200.0, span0
+    assert (sp[1, :3] == 0).all() and (sp[1, nt - 2:] == 0).all() and (sp[1, 3:nt - 2, 0] >= sp[0, :, 0].min()).all()
+    assert (sp[2] == 0).all()
+    _lib.check(L.hfem_plan_set_span_stamps(plan.handle, None, 0))
+    buf.zero_()
+    run(0, 0, -1, 0)
+    torch.cuda.synchronize()
+    assert int(buf.abs().sum().item()) == 0

@@ -452,3 +452,74 @@ def test_snapped_tile_cuts_keep_the_invariants():
             assert slots[25] <= 1.05 * slots[0], (name, slots)
     finally:
         L.hfem_set_option(b"plan_snap", prev)
+
+
+# ------------------------------------------------------------------ sharded plans (plan_shards): boundary tiles first
+def _tile_sets(plan):
+    """Per tile: (owned node ids, all local node ids), identity row maps."""
+    td, ns = plan.export("tile_desc"), plan.export("node_src")
+    return [(ns[no:no + nown, 0], ns[no:no + nno, 0]) for (_, _, no, nno, nown, _, _, _) in td]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("name", ["permuted", "flipped"])
+def test_sharded_plan_orders_boundary_tiles_first(name, world):
+    from hidenn_fem_amd import _lib
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(dtype=torch.float64, **MESHES[name])
+    nn = coords.shape[0]
+    L = _lib.lib()
+    prev = L.hfem_get_option(b"plan_node_cap")
+    L.hfem_set_option(b"plan_node_cap", 40)              # many small tiles, the same cut for both plans
+    try:
+        base = TilePlan(conn, nn, coords_hint=coords, edges=edges)
+        plan = TilePlan(conn, nn, coords_hint=coords, edges=edges, shards=world)
+    finally:
+        L.hfem_set_option(b"plan_node_cap", prev)
+    assert plan.stats["shards"] == world and base.stats["shards"] == 1
+    check_invariants(conn.numpy(), edges.numpy(), nn, plan)
+    # the same tiles, reordered inside every rank's range only
+    nt = plan.n_tiles
+    assert nt == base.n_tiles and nt >= 2 * world
+    own_b, own_s = [set(o.tolist()) for o, _ in _tile_sets(base)], [set(o.tolist()) for o, _ in _tile_sets(plan)]
+    sets = _tile_sets(plan)
+    owner = np.empty(nn, dtype=np.int64)
+    for t, (o, _) in enumerate(sets):
+        owner[o] = t
+    bounds = [plan.shard_range(r, world) for r in range(world)]
+    rank_of = np.concatenate([np.full(hi - lo, r) for r, (lo, hi) in enumerate(bounds)])
+    n_bnd = 0
+    for r, (lo, hi) in enumerate(bounds):
+        assert sorted(map(sorted, own_b[lo:hi])) == sorted(map(sorted, own_s[lo:hi]))
+        lo2, mid, hi2 = plan.shard_parts(r, world)
+        assert (lo2, hi2) == (lo, hi) and lo <= mid <= hi
+        n_bnd += mid - lo
+        # a tile touches another rank when it reads a foreign-owned node or owns a node a foreign tile reads
+        touches = np.zeros(nt, dtype=bool)
+        for t, (_, allv) in enumerate(sets):
+            foreign = rank_of[owner[allv]] != rank_of[t]
+            if foreign.any():
+                touches[t] = True
+                touches[owner[allv[foreign]]] = True
+        assert touches[lo:mid].all(), "every tile in the boundary part takes part in the exchange"
+        assert not touches[mid:hi].any(), "interior tiles depend on nothing another rank owns or reads"
+    assert 0 < n_bnd < nt
+    # a plan that was not prepared for this world size reports everything as boundary (never overlaps wrongly)
+    assert base.shard_parts(1, world)[1] == base.shard_range(1, world)[1]
+    assert plan.shard_parts(0, 1) == (0, 0, nt)
+
+
+def test_shard_aware_tile_policy_sizes_tiles_for_elements_per_rank():
+    """Auto policy of hfem_plan_create by elements per rank: > 600 k -> 557 home nodes, 256 threads, three slot rows;
+    200-600 k -> the same tiles with 512 threads (two rows); 100-200 k -> one slot row of 512 threads; <= 100 k -> one slot
+    row of 256 threads (profiles/r03/shard_sweep_*.jsonl)."""
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(355, 177, jitter=0.2, seed=0, dtype=torch.float64)   # 124 608 el.
+    nn = coords.shape[0]
+    one = TilePlan(conn, nn, coords_hint=coords, edges=edges)
+    assert one.is_paired() and one.stats["threads_per_tile"] == 512 and one.stats["slot_rows"] == 1
+    two = TilePlan(conn, nn, coords_hint=coords, edges=edges, shards=2)                                        # 62 k per rank
+    assert two.stats["threads_per_tile"] == 256 and two.stats["slot_rows"] == 1 and two.n_tiles > one.n_tiles
+    assert two.stats["max_tile_elems"] <= 256
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(501, 251, jitter=0.2, seed=0, dtype=torch.float64)   # 250 000 el.
+    big = TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges)
+    assert big.stats["threads_per_tile"] == 512 and big.stats["slot_rows"] == 2 and big.stats["max_tile_owned"] <= 560
+    check_invariants(conn.numpy(), edges.numpy(), coords.shape[0], TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges, shards=4))

@@ -253,3 +253,125 @@ def test_single_process_sharded_equals_unsharded():
     assert (sh.lo, sh.hi) == (0, plan.n_tiles)
     loss, gx, gu = sh.value_and_grad()
     assert torch.isfinite(loss) and (gx != 0).any(dim=1).all() and (gu != 0).any(dim=1).all()
+
+
+# ------------------------------------------------------------------ whole training iterations, plain and overlapped
+def torch_adam(sh):
+    """torch indexing standing in for hfem_adam_step_rows2_dev (csrc/optim.hip) on CPU tensors: torch.optim.Adam's update
+    on the rows the rank owns, step = completed steps + 1 (the pack that follows bumps the counter)."""
+    import math
+
+    def step():
+        a, m = sh._adam, sh.model
+        t = int(a["step"].item()) + 1
+        b1, b2 = a["betas"]
+        _, gx_v, gu_v = sh._views(sh.send)
+        with torch.no_grad():
+            for p, g, mm, vv, rows, lr in ((m.node_coords_free, gx_v, a["mx"], a["vx"], a["rows_x"], a["lr"][0]),
+                                           (m.u_free, gu_v, a["mu"], a["vu"], a["rows_u"], a["lr"][1])):
+                r = rows.long()
+                gi = g[r]
+                mm[r] = mm[r] + (1.0 - b1) * (gi - mm[r])
+                vv[r] = vv[r] * b2 + (1.0 - b2) * (gi * gi)
+                p[r] = p[r] - (lr / (1.0 - b1 ** t)) * (mm[r] / (vv[r].sqrt() / math.sqrt(1.0 - b2 ** t) + a["eps"]))
+
+    return step
+
+
+def _make_trainer(world, rank_world=None):
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.plan import TilePlan
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    f64 = torch.float64
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(45, 29, jitter=0.2, seed=9, dtype=f64)
+    torch.manual_seed(21)
+    model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges)
+    plan = TilePlan(conn, coords.shape[0], coords_hint=coords, x_src=model._x_src, u_src=model._u_src, edges=edges,
+                    tile_elems=48, shards=world)          # prepared for this world: boundary tiles first
+    kw = {} if rank_world is None else dict(rank=rank_world[0], world=rank_world[1])
+    sh = ShardedTri3Energy(model, EnergyLoss2D(device=torch.device("cpu"), dtype=f64, tile_elems=48),
+                           evaluate=oracle_tile_evaluator(plan, model), plan=plan, **kw)
+    sh.setup_interfaces()
+    sh._pack, sh._unpack = torch_pack_unpack(sh)
+    sh.init_owner_adam(lr_x=2e-6, lr_u=1e-9)
+    sh._adam_step = torch_adam(sh)
+    return sh, (coords, conn, geom, bc, edges)
+
+
+def _worker_overlap(rank, world, port, q):
+    """K Adam iterations with owner_train_step (exchange on the critical path) and with owner_train_step_overlapped
+    (exchange of step k under the interior tiles of step k + 1): bit-identical parameters and energies."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        K = 4
+        plain, _ = _make_trainer(world)
+        over, _ = _make_trainer(world)
+        assert plain.lo <= plain.mid < plain.hi and (world == 1 or plain.lo < plain.mid), "boundary and interior tiles exist"
+        l_plain = []
+        for _ in range(K):
+            l_plain.append(plain.owner_train_step().item())
+        l_over = []
+        for k in range(K):
+            over.owner_train_step_overlapped()
+            if k > 0:
+                l_over.append(over.loss_global.item())      # lags one step
+        l_over.append(over.finish_overlapped().item())
+        own_x, own_u = plain.owned_rows()
+        seen_x = torch.unique(torch.cat([own_x, plain._need_dst[:plain._need_n[0]].long()]))
+        seen_u = torch.unique(torch.cat([own_u, plain._need_dst[plain._need_n[0]:].long()]))
+        # parameters bit-equal; the rank's energy is summed per tile RANGE by the CPU stand-in (two ranges -> another
+        # association, last-bit differences; the HIP path sums the plan's tile energies in tile order either way)
+        same = (np.allclose(l_plain, l_over, rtol=1e-14, atol=0.0)
+                and torch.equal(plain.model.node_coords_free[seen_x], over.model.node_coords_free[seen_x])
+                and torch.equal(plain.model.u_free[seen_u], over.model.u_free[seen_u])
+                and int(over._adam["step"].item()) == K == int(plain._adam["step"].item()))
+        moved = (plain.model.node_coords_free[own_x] - _make_trainer(world)[0].model.node_coords_free[own_x]).abs().max().item()
+        q.put((rank, bool(same), l_plain, moved, plain.mid - plain.lo, plain.hi - plain.mid))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_train_step_equals_plain_step_gloo(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=250) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), f"overlapped trajectory differs from the plain owner-sharded step: {res}"
+    assert all(r[2] == res[0][2] for r in res), "ranks disagree on the global energies"
+    assert all(r[3] > 0 for r in res), "Adam moved the owned rows"
+    assert all(r[4] > 0 and r[5] > 0 for r in res), "every rank has boundary and interior tiles"
+    # the energies are the single-process Adam trajectory's (full-mesh oracle)
+    sys.path.insert(0, ROOT)
+    ref, _ = _make_trainer(1)
+    l_ref = [ref.owner_train_step().item() for _ in range(len(res[0][2]))]
+    assert np.allclose(res[0][2], l_ref, rtol=1e-12, atol=0.0), (res[0][2], l_ref)
+
+
+def test_overlapped_train_step_single_process():
+    """world = 1: everything is interior, the exchange is a copy; same numbers as the plain step."""
+    sys.path.insert(0, ROOT)
+    plain, _ = _make_trainer(1)
+    over, _ = _make_trainer(1)
+    assert (over.lo, over.mid, over.hi) == (0, 0, over.plan.n_tiles)
+    a = [plain.owner_train_step().item() for _ in range(3)]
+    for _ in range(3):
+        over.owner_train_step_overlapped()
+    last = over.finish_overlapped().item()
+    assert last == a[-1]                                        # one range: the same sum
+    assert torch.equal(plain.model.node_coords_free, over.model.node_coords_free)
+    assert torch.equal(plain.model.u_free, over.model.u_free)

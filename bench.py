@@ -3,28 +3,32 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...``
-(one rank per GPU, RCCL).  A *step* is one pass of the hot path over the synthetic mesh:
-loss + d/d node_coords_free + d/d u_free, inputs resident in HBM.
+N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).
+A *step* is one pass of the hot path over the synthetic mesh: loss + d/d node_coords_free + d/d u_free, inputs resident
+in HBM.  The timed region is ONE hipGraph of exactly K steps, bracketed by barrier + synchronize on both sides; it is
+replayed ``--repeats`` (5) times and the MEDIAN replay is reported (max over ranks per replay).
 
-Workload at N = 1: BASELINE.json configs[3] "Example 4", reading (i) of SURVEY F11 = "T1M":
-plate [0,2]x[0,1], 1001x501 nodes -> 1,000,000 TRI3 (each structured quad split in two),
-interior nodes jittered 0.2 h (seed 0), outer boundary fixed, left edge Dirichlet, right edge
-Neumann (500 edges), u_free ~ 1e-5 N(0,1), E=10e9, nu=0.3, gauss_order=4, fp64, r-adaptivity on.
-N > 1 (weak scaling): the plate grows to N x 1,000,000 elements (N*1000+1 x 501 nodes); every rank evaluates its
-contiguous tile range (one process per GPU), then ONE collective.  Headline (`value`) = OWNER-SHARDED mode: owner-computes
-tiles give each rank complete gradient rows for the nodes it owns, so what crosses ranks is one small all_gather of the
-interface parameter rows + the partial energies -- in-library RCCL (hfem_mg_*, csrc/mg.cpp) enqueued on the kernel's
-stream, the K steps captured in one hipGraph.  Reported beside it: `config.train_step` (the same loop with Adam on the
-owned rows inside, so the exchanged rows change every step) and `config.alt_exchange`, the north-star's literal wording:
-a dense sum all-reduce of the packed [gX|gU|loss] buffer.
+Workload at N = 1: BASELINE.json configs[3] "Example 4", reading (i) of SURVEY F11 = "T1M": plate [0,2]x[0,1], 1001x501
+nodes -> 1,000,000 TRI3 (each structured quad split in two), interior nodes jittered 0.2 h (seed 0), outer boundary fixed,
+left edge Dirichlet, right edge Neumann (500 edges), u_free ~ 1e-5 N(0,1), E=10e9, nu=0.3, gauss_order=4, fp64, r-adaptivity on.
 
-One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel
-(tri3_energy_pair_kernel on the paired tile plan a split-quad mesh gets; tri3_energy_fast_kernel otherwise): algorithmic
-bytes (12 Ne + 64 Nn + 8) over its average back-to-back launch time measured with HIP events on the
-launch stream.
-``cpu_baseline`` times the oracle's op-for-op PyTorch restatement of the reference chain on the
-host cores, on the same workload (bounded number of evaluations).
+N > 1: `value` is WEAK scaling (the plate grows to N x 1,000,000 elements; every rank evaluates its contiguous tile range,
+then ONE small all_gather of interface parameter rows + partial energies -- owner-sharded mode, in-library RCCL on the
+kernel's stream, the K steps in one hipGraph).  Beside it, in `config`:
+  train_step / train_step_overlap   whole Adam iterations (exchange on the critical path / hidden under the interior tiles)
+  alt_exchange                      the north-star's literal wording: a dense sum all-reduce of [gX|gU|loss]
+  strong_scaling                    BASELINE configs[3] and [4] AS STATED: 10^6 TRI3 FIXED sharded over the N ranks (and, at
+                                    N = 8, the 4.1 M-element Delaunay mesh), kernel-only per rank and end to end
+At N = 1 `config.strong_scaling_emulated` rehearses those shards on the one GPU: the kernel over the tile range rank r of
+N would evaluate (`--emulate-shard r/N` runs just that).
+
+One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel (tri3_energy_pair_kernel): algorithmic bytes
+(12 Ne + 64 Nn + 8) over its average launch time, HIP events on the launch stream.  Top level = the
+ROTATING-SETS regime (10 parameter / gradient sets, 313 MB > the 256 MB Infinity Cache: the only regime whose reads
+really come from HBM); `regimes` holds the cache-resident `replayed` leg (what the timed headline step is) and the
+`rewritten_inputs` leg; every regime also carries the kernel's in-run span from s_memrealtime stamps
+(hfem_plan_set_span_stamps) and, labelled `rocprof_*`, the profiler's average from the committed run.
+``cpu_baseline`` times the oracle's op-for-op PyTorch restatement of the reference chain on the host cores.
 """
 import argparse
 import ctypes as C
@@ -40,6 +44,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def parse():
@@ -47,6 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="replays of the K-step graph; the median is reported")
     ap.add_argument("--nx", type=int, default=1001, help="nodes along x PER GPU (+1 shared column)")
     ap.add_argument("--ny", type=int, default=501)
     ap.add_argument("--tile-elems", type=int, default=0)
@@ -57,10 +63,15 @@ def parse():
                     "1-block launch after every energy kernel instead of inside the next launch")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed replays before each timed leg")
     ap.add_argument("--option", action="append", default=[], help="name=value for hfem_set_option (lab A/B runs)")
-    ap.add_argument("--no-extra", action="store_true", help="skip config.extra (Q1M, T2M, cfg5 structured / Delaunay kernel timings)")
-    ap.add_argument("--no-regimes", action="store_true", help="skip the extra cache-regime legs of the roofline block")
-    ap.add_argument("--only-regime", default="", help="rocprof helper: run ONLY this roofline leg (replayed | "
+    ap.add_argument("--no-extra", action="store_true", help="skip config.extra / train_step_1gpu / strong_scaling_emulated")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the cache-regime legs (roofline = the replayed leg)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip config.strong_scaling")
+    ap.add_argument("--only-regime", default="", help="profiler helper: run ONLY this roofline leg (replayed | "
                     "rewritten_inputs | rotating_sets) and exit")
+    ap.add_argument("--only-extra", default="", help="profiler helper: run ONLY this config.extra workload (Q1M | T2M | cfg5 | "
+                    "cfg5auto | cfg5r | cfg5u) and exit")
+    ap.add_argument("--emulate-shard", default="", help="N = 1: 'r/N' -- time the kernel over the tile range rank r of N "
+                    "would evaluate on the FIXED 10^6-element mesh (strong-scaling rehearsal) and exit")
     ap.add_argument("--rotating-sets", type=int, default=10, help="parameter/gradient sets of the rotating leg (32 MB each)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the multi-rank path on fewer GPUs than ranks)")
@@ -125,29 +136,292 @@ def main():
     from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
 
     f64 = torch.float64
-    nx = (a.nx - 1) * world + 1
-    mesh6 = structured_tri_mesh(nx, a.ny, length=2.0 * world, height=1.0, jitter=0.2, seed=0, dtype=f64)
-    coords, conn, geom, bc, mn, edges = mesh6
-    ne, nn = conn.shape[0], coords.shape[0]
-    torch.manual_seed(0)
-    model = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
-                                     neumann_edges=edges).to(dev)
+    L = _lib.lib()
+    dv = lambda v: (C.c_double * len(v))(*v)
+    notes = []                                   # everything that did not run the way the docstring says (-> config.notes)
+
+    def note(msg):
+        notes.append(msg)
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr)
+
     for kv in a.option:
         name, val = kv.split("=")
-        _lib.check(_lib.lib().hfem_set_option(name.encode(), int(val)), "hfem_set_option")
-    loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
-    comm = None
-    if world > 1 and a.backend == "nccl":        # in-library RCCL communicator: collectives on the kernel's stream, capturable
+        _lib.check(L.hfem_set_option(name.encode(), int(val)), "hfem_set_option")
+
+    # ------------------------------------------------------------------------------------------------ timing helpers
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def capture(body, n, begin=None, end=None, warm=2):
+        """One hipGraph of `n` calls of body() (bracketed by begin() / end()); (graph, None) or (None, reason)."""
+        if a.no_graph:
+            return None, "--no-graph"
+        if world > 1 and comm is None:
+            return None, "torch.distributed collectives are not capturable; needs the in-library RCCL communicator"
         try:
-            comm = LibraryComm(dev)
-        except Exception as e:  # pragma: no cover
-            if rank == 0:
-                print(f"[bench] in-library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                if begin:
+                    begin()
+                for _ in range(warm):
+                    body()
+                if end:
+                    end()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if begin:
+                    begin()
+                for _ in range(n):
+                    body()
+                if end:
+                    end()
+            return g, None
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            return None, f"{type(e).__name__}: {str(e)[:160]}"
+
+    def timed_steps(body, n, begin=None, end=None, fixed_prewarm=None):
+        """W warm-up steps, then `--repeats` timed regions of EXACTLY n steps (one graph replay each), each bracketed by
+        barrier + synchronize on both sides; per region the MAX over ranks; returns (median seconds, all regions, launch)."""
+        g, why = capture(body, n, begin, end)
+
+        def run():
+            if g is not None:
+                g.replay()
+            else:
+                if begin:
+                    begin()
+                for _ in range(n):
+                    body()
+                if end:
+                    end()
+        # untimed pre-warm: the whole default run is a few ms of GPU time, shorter than the clock ramp of an idle chip.
+        # Fixed count when N > 1 (every rank must issue the same number of collectives).
+        if world == 1 and g is not None:
+            t_pw = time.perf_counter()
+            while time.perf_counter() - t_pw < a.prewarm:
+                g.replay()
+                torch.cuda.synchronize()
+        else:
+            for _ in range(fixed_prewarm if fixed_prewarm is not None else max(1, int(a.prewarm * 400 / max(n, 1)))):
+                run()
+        if begin:
+            begin()
+        for _ in range(a.warmup):
+            body()
+        if end:
+            end()
+        run()
+        regions = []
+        for _ in range(max(1, a.repeats)):
+            sync_all()
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=f64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            regions.append(el)
+        sync_all()
+        launch = "hipgraph" if g is not None else f"eager ({why})"
+        if g is None and why != "--no-graph" and f"eager: {why}" not in notes:
+            note(f"eager: {why}")
+        return sorted(regions)[len(regions) // 2], regions, launch
+
+    stream_box = [torch.cuda.current_stream()]
+
+    def time_launches(body, kreps):
+        """Average time of one body(i) over `kreps` back-to-back calls (one hipGraph unless --no-graph), HIP events on the
+        launch stream, median of 5 regions after the clock pre-warm.  Returns (us, regions)."""
+        g = None
+        if not a.no_graph:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    stream_box[0] = s
+                    body(0)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    stream_box[0] = torch.cuda.current_stream()
+                    for i in range(kreps):
+                        body(i)
+            except Exception as e:  # noqa: BLE001
+                note(f"kernel-only leg: hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches")
+                g = None
+        stream_box[0] = torch.cuda.current_stream()
+        for i in range(5):
+            body(i)
+        t_pw = time.perf_counter()
+        while g is not None and time.perf_counter() - t_pw < a.prewarm:
+            g.replay()
+            torch.cuda.synchronize()
+        regions = []
+        for _ in range(5):                      # 5 timed regions of `kreps` back-to-back bodies each
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream_box[0])
+            if g is not None:
+                g.replay()
+            else:
+                for i in range(kreps):
+                    body(i)
+            ev1.record(stream_box[0])
+            torch.cuda.synchronize()
+            regions.append(ev0.elapsed_time(ev1) * 1e3 / kreps)
+        return sorted(regions)[len(regions) // 2], regions       # median region; each value is a kreps-launch average
+
+    def span_launches(plan, body, kreps):
+        """In-run duration of the energy kernel inside ANY launch sequence: s_memrealtime stamps written by the kernel itself
+        (hfem_plan_set_span_stamps), first-workgroup-start to last-workgroup-end per launch, averaged over `kreps` launches
+        of a replayed graph.  Returns (span_us, gap_us) -- gap = from one launch's last end to the next launch's first
+        start -- or (None, None) if the plan's kernel does not stamp."""
+        nt = plan.n_tiles
+        buf = torch.zeros(kreps * nt * 2, dtype=torch.int64, device=dev)
+        _lib.check(L.hfem_plan_set_span_stamps(plan.handle, buf.data_ptr(), kreps), "hfem_plan_set_span_stamps")
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                stream_box[0] = s
+                body(0)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            _lib.check(L.hfem_plan_set_span_stamps(plan.handle, buf.data_ptr(), kreps), "hfem_plan_set_span_stamps")   # cursor -> 0
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                stream_box[0] = torch.cuda.current_stream()
+                for i in range(kreps):
+                    body(i)
+            stream_box[0] = torch.cuda.current_stream()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            buf.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            sp = buf.view(kreps, nt, 2).cpu().numpy()
+            ok = sp[:, :, 0] > 0
+            if not ok.any():
+                return None, None
+            start = np.where(ok, sp[:, :, 0], np.iinfo(np.int64).max).min(axis=1)
+            end = np.where(ok, sp[:, :, 1], 0).max(axis=1)
+            span = float((end - start).mean()) * 0.01                                  # 100 MHz ticks -> us
+            gap = float((start[1:] - end[:-1]).mean()) * 0.01 if kreps > 1 else None
+            del g
+            return span, gap
+        except Exception as e:  # noqa: BLE001
+            note(f"span stamps failed: {type(e).__name__}: {str(e)[:120]}")
+            return None, None
+        finally:
+            stream_box[0] = torch.cuda.current_stream()
+            L.hfem_plan_set_span_stamps(plan.handle, None, 0)
+
+    # ------------------------------------------------------------------------------------------------ workloads
+    def build_model(mesh6):
+        coords, conn, geom, bc, mn, edges = mesh6
+        torch.manual_seed(0)
+        return PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                        neumann_edges=edges).to(dev)
+
+    def t1m_mesh(nranks=1):
+        nx = (a.nx - 1) * nranks + 1
+        return structured_tri_mesh(nx, a.ny, length=2.0 * nranks, height=1.0, jitter=0.2, seed=0, dtype=f64)
+
+    class KernelOnly:
+        """hfem_tri3_energy_plan on a tile range with every host-side lookup hoisted (HFEM_FLAG_NO_LOSS_SUM)."""
+
+        def __init__(self, model, loss_fn, plan, lo=0, hi=-1):
+            self.plan, self.lo, self.hi = plan, int(lo), int(hi)
+            self.xf, self.uf = model.node_coords_free.detach(), model.u_free.detach()
+            self.xfix, self.ufix = model.node_coords_fixed, model.u_fixed_rows()
+            _, Tconst = loss_fn._traction(model, None)
+            self.mat, self.W, self.Bk, self.Tc = dv(loss_fn._mat), loss_fn._W, dv([0.0] * 6), dv(Tconst)
+            self.gx, self.gu = torch.empty_like(self.xf), torch.empty_like(self.uf)
+            self.loss = torch.zeros((), dtype=f64, device=dev)
+
+        def __call__(self, bufs=None):
+            x_, u_, gx_, gu_ = bufs if bufs is not None else (self.xf, self.uf, self.gx, self.gu)
+            _lib.check(L.hfem_tri3_energy_plan(self.plan.handle, x_.data_ptr(), self.xfix.data_ptr() if self.xfix.numel() else None,
+                                               u_.data_ptr(), self.ufix.data_ptr() if self.ufix.numel() else None, self.mat,
+                                               self.W, self.Bk, None, self.Tc, self.lo, self.hi, self.loss.data_ptr(),
+                                               gx_.data_ptr(), gu_.data_ptr(), 8, stream_box[0].cuda_stream), "hfem_tri3_energy_plan")
+
+    def range_work(plan, lo, hi):
+        """(home elements, owned nodes, algorithmic bytes) of a launch over tiles [lo, hi)."""
+        td = plan.export("tile_desc")
+        hi = plan.n_tiles if hi < 0 else hi
+        if (lo, hi) == (0, plan.n_tiles):
+            ne_ = plan.n_elems
+        else:
+            ne_ = int(sum(int(plan.tile_elements(t)[2].sum()) for t in range(lo, hi)))
+        nn_ = int(td[lo:hi, 4].sum())
+        return ne_, nn_, 12 * ne_ + 64 * nn_ + 8
+
+    def shard_kernel_leg(model, loss_fn, nshards, ranks, kreps):
+        """Kernel-only time of the tile ranges `ranks` of an `nshards`-way sharded plan of `model` (one GPU)."""
+        plan = model.tile_plan(loss_fn.tile_elems, shards=nshards)
+        out = []
+        for r in ranks:
+            lo, mid, hi = plan.shard_parts(r, nshards)
+            ko = KernelOnly(model, loss_fn, plan, lo, hi)
+            us, _ = time_launches(lambda i: ko(), kreps)
+            ne_, nn_, ab = range_work(plan, lo, hi)
+            out.append(dict(rank=r, tiles=hi - lo, boundary_tiles=mid - lo, elements=ne_, owned_nodes=nn_, kernel_us=us,
+                            alg_bytes=ab, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS))
+        st = plan.stats
+        return dict(shards=nshards, tiles=st["n_tiles"], threads_per_tile=st["threads_per_tile"], slot_rows=st["slot_rows"],
+                    max_tile_owned=st["max_tile_owned"], ranks=out, kernel_us_max=max(o["kernel_us"] for o in out))
+
+    # ------------------------------------------------------------------------------------------------ helper modes (N = 1)
+    if a.emulate_shard:
+        r_, n_ = (int(v) for v in a.emulate_shard.split("/"))
+        model = build_model(t1m_mesh())
+        lf = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+        print(json.dumps(dict(emulate_shard=a.emulate_shard, **shard_kernel_leg(model, lf, n_, [r_], max(a.steps, 50)))), flush=True)
+        return None
+
+    # ------------------------------------------------------------------------------------------------ main workload
+    mesh6 = t1m_mesh(world)
+    coords, conn, geom, bc, mn, edges = mesh6
+    ne, nn = conn.shape[0], coords.shape[0]
+    model = build_model(mesh6)
+    loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+    comm, comm_state = None, "none (N = 1)"
+    if world > 1:
+        comm_state = f"torch.distributed {a.backend}"
+        if a.backend == "nccl":      # in-library RCCL communicator: collectives on the kernel's stream, capturable
+            try:
+                comm = LibraryComm(dev)
+                # self-check against torch.distributed on this very communicator size before anything is timed
+                probe = torch.arange(6, dtype=f64, device=dev) + 100.0 * rank
+                got_lib, got_pg = torch.zeros(6 * world, dtype=f64, device=dev), torch.zeros(6 * world, dtype=f64, device=dev)
+                comm.all_gather(probe, got_lib)
+                dist.all_gather_into_tensor(got_pg, probe)
+                red_lib = torch.zeros_like(probe)
+                comm.all_reduce_sum(probe, red_lib)
+                red_pg = probe.clone()
+                dist.all_reduce(red_pg)
+                torch.cuda.synchronize()
+                if not (torch.equal(got_lib, got_pg) and torch.allclose(red_lib, red_pg, rtol=1e-15, atol=0)):
+                    raise RuntimeError("in-library collectives disagree with torch.distributed")
+                comm_state = f"in-library RCCL (hfem_mg_*), verified in this run against torch.distributed on {world} ranks"
+            except Exception as e:  # noqa: BLE001
+                comm = None
+                comm_state = f"torch.distributed nccl (in-library RCCL communicator unavailable: {type(e).__name__}: {str(e)[:120]})"
+                note(comm_state)
     sh = ShardedTri3Energy(model, loss_fn, comm=comm)
     plan = sh.plan
     lo, hi = sh.lo, sh.hi
-    td = plan.export("tile_desc")
-    ne_local_home = ne if world == 1 else None
 
     if world > 1:
         sh.setup_interfaces()
@@ -157,24 +431,20 @@ def main():
         sh.evaluate_local()
         sh.exchange()
 
-    def step_owner():           # owner-sharded: gradient rows stay with their owner; ONE all_gather of the
-        sh.owner_step()         # interface parameter rows + partial energies (what the next evaluation needs)
-
     # N = 1: the energy of step k is reduced by an extra workgroup of launch k+1 (HFEM_FLAG_SUM_PREVIOUS) and the last one
     # by a trailing 1-block launch, inside the timed region: every step's loss is produced, the reduction and its kernel
     # boundary just leave the critical path.  --inline-loss-sum restores the separate reduction after every launch.
     lagged = world == 1 and not a.inline_loss_sum
-    step = (sh.evaluate_local_lagged if lagged else sh.evaluate_local) if world == 1 else step_owner
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    step = (sh.evaluate_local_lagged if lagged else sh.evaluate_local) if world == 1 else sh.owner_step
+    begin = sh.begin_lagged if lagged else None
+    end = sh.flush_loss if lagged else None
 
     # ---- correctness guard: the benchmarked path must produce the oracle's numbers
+    if begin:
+        begin()
     step()
-    if lagged:
-        sh.flush_loss()
+    if end:
+        end()
     torch.cuda.synchronize()
     if world == 1:
         loss_gpu = sh._views(sh.send)[0].item()
@@ -185,289 +455,194 @@ def main():
         loss_dense = sh._views(sh.recv)[0].item()
         assert abs(loss_gpu - loss_dense) <= 1e-12 * abs(loss_dense), (loss_gpu, loss_dense)
 
-    # ---- timed region: W warm-up steps, then exactly K steps between barrier+synchronize
-    use_graph = (world == 1 or comm is not None) and not a.no_graph
-    graph = None
-    if use_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(3):
-                    step()
-                if lagged:
-                    sh.flush_loss()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                if lagged:
-                    sh.begin_lagged()
-                for _ in range(a.steps):
-                    step()
-                if lagged:
-                    sh.flush_loss()
-        except Exception as e:  # pragma: no cover
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
-            graph = None
-    # untimed pre-warm on top of the W warm-up steps: the whole default run is a few ms of GPU time, shorter than
-    # the clock ramp of an idle chip (the first timed regions read 5-7 % slow without it).  Fixed count when N > 1
-    # (every rank must issue the same number of collectives).
-    if graph is not None:
-        t_pw = time.perf_counter()
-        while time.perf_counter() - t_pw < a.prewarm:
-            graph.replay()
-            torch.cuda.synchronize()
+    only = a.only_regime
+    if not only and not a.only_extra:
+        elapsed, regions, launch = timed_steps(step, a.steps, begin, end)
+        if lagged:                  # the trailing flush delivered the last step's energy: same bits as the guard evaluation
+            assert sh._views(sh.send)[0].item() == loss_gpu, (sh._views(sh.send)[0].item(), loss_gpu)
     else:
-        for _ in range(int(a.prewarm * 400)):
-            step()
-    for _ in range(a.warmup):
-        step()
-    if lagged:
-        sh.flush_loss()
-    if graph is not None:
-        graph.replay()
-    sync_all()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(a.steps):
-            step()
-        if lagged:
-            sh.flush_loss()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=f64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    if lagged:                  # the trailing flush delivered the last step's energy: same bits as the guard evaluation
-        assert sh._views(sh.send)[0].item() == loss_gpu, (sh._views(sh.send)[0].item(), loss_gpu)
+        elapsed, regions, launch = float("nan"), [], "skipped"
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
     # ---- N = 1, reported beside the headline: the step of a caller that needs ITS OWN loss before it goes on (a line
     #      search, an L-BFGS check): the 1-block reduction launched right after every energy launch, on the critical path
     inline_step = None
-    if world == 1 and lagged and not a.no_extra:
-        try:
-            s_ = torch.cuda.Stream()
-            s_.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s_):
-                for _ in range(3):
-                    sh.evaluate_local()
-            torch.cuda.current_stream().wait_stream(s_)
-            torch.cuda.synchronize()
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
-                for _ in range(a.steps):
-                    sh.evaluate_local()
-            g_.replay()
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            g_.replay()
-            torch.cuda.synchronize()
-            el_ = time.perf_counter() - t0_
-            assert sh._views(sh.send)[0].item() == loss_gpu
-            inline_step = dict(mode="loss of step k reduced by its own 1-block launch before step k+1 (--inline-loss-sum)",
-                               ms_per_step=el_ / a.steps * 1e3, value=ne / (el_ / a.steps))
-        except Exception as e:  # pragma: no cover
-            print(f"[bench] inline-loss leg failed: {e}", file=sys.stderr)
+    if world == 1 and lagged and not a.no_extra and not only and not a.only_extra:
+        el_, _, ln_ = timed_steps(sh.evaluate_local, a.steps)
+        assert sh._views(sh.send)[0].item() == loss_gpu
+        inline_step = dict(mode="loss of step k reduced by its own 1-block launch before step k+1 (--inline-loss-sum)",
+                           ms_per_step=el_ / a.steps * 1e3, value=ne / (el_ / a.steps), launch=ln_)
 
-    # ---- N > 1 only, reported beside the headline: the north-star's literal exchange, a dense all-reduce of the
-    #      full gradient + loss (every rank ends with everything; 16 B x 2 x nodes x N on the wire)
-    def timed_alt(body):
-        """W warm-up + K timed iterations of `body` (one hipGraph of K when the in-library comm allows capture),
-        bracketed like the headline; returns seconds (max over ranks)."""
-        g = None
-        if comm is not None and not a.no_graph:
-            try:
-                s_ = torch.cuda.Stream()
-                s_.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s_):
-                    for _ in range(2):
-                        body()
-                torch.cuda.current_stream().wait_stream(s_)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for _ in range(a.steps):
-                        body()
-            except Exception:  # pragma: no cover
-                g = None
-        for _ in range(a.warmup):
-            body()
-        if g is not None:
-            g.replay()
-        sync_all()
-        t0_ = time.perf_counter()
-        if g is not None:
-            g.replay()
-        else:
-            for _ in range(a.steps):
-                body()
-        sync_all()
-        el = time.perf_counter() - t0_
-        t = torch.tensor([el], dtype=f64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.item(), g is not None
+    # ---- N > 1: the other readings of a multi-GPU step
+    def leg(body, mode, n_elems, begin_=None, end_=None):
+        el, regs, ln = timed_steps(body, a.steps, begin_, end_)
+        return dict(mode=mode, value=n_elems / (el / a.steps), ms_per_step=el / a.steps * 1e3, launch=ln,
+                    ms_per_step_replays=[round(r / a.steps * 1e3, 5) for r in regs])
 
-    alt = train = None
+    alt = train = train_ov = strong = None
     if world > 1:
-        el2, g2 = timed_alt(step_dense)
-        alt = dict(mode=f"dense: sum all-reduce of [gX|gU|loss] fp64, {sh.send.numel() * 8} B per rank, "
-                        f"{'in-library RCCL on the kernel stream' if comm is not None else 'torch.distributed ' + a.backend}",
-                   value=ne / (el2 / a.steps), ms_per_step=el2 / a.steps * 1e3, launch="hipgraph" if g2 else "eager")
-        el3, g3 = timed_alt(sh.owner_train_step)
-        train = dict(mode="owner-sharded training iteration: energy -> Adam on the rows the rank owns -> pack -> all_gather "
-                          "-> unpack (the exchanged interface rows change every step)",
-                     value=ne / (el3 / a.steps), ms_per_step=el3 / a.steps * 1e3, launch="hipgraph" if g3 else "eager")
+        how = comm_state
+        alt = leg(step_dense, f"dense: sum all-reduce of [gX|gU|loss] fp64, {sh.send.numel() * 8} B per rank, {how}", ne)
+        train = leg(sh.owner_train_step, "owner-sharded training iteration: energy -> Adam on the rows the rank owns -> pack "
+                    "(+ energy sum + step count) -> all_gather -> unpack; four launches + the collective, exchange on the "
+                    "critical path", ne)
+        train_ov = leg(sh.owner_train_step_overlapped, "the same iteration, exchange of step k on a side stream under the "
+                       f"interior tiles of step k+1 (boundary tiles {sh.mid - sh.lo} of {sh.hi - sh.lo} on this rank)", ne,
+                       end_=sh.finish_overlapped)
 
-    # ---- roofline leg: the dominant kernel alone, K back-to-back launches, HIP events on its stream
-    L = _lib.lib()
-    dv = lambda v: (C.c_double * len(v))(*v)
-    xf, uf = model.node_coords_free.detach(), model.u_free.detach()
-    xfix, ufix = model.node_coords_fixed, model.u_fixed_rows()
-    _, Tconst = loss_fn._traction(model, None)
-    loss_s, gx_s, gu_s = sh._views(sh.send)
-    mat, W, Bk, Tc = dv(loss_fn._mat), loss_fn._W, dv([0.0] * 6), dv(Tconst)
-    stream = torch.cuda.current_stream()
+    # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
+    def strong_leg(name, mesh6_s):
+        m_s = build_model(mesh6_s)
+        lf_s = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+        sh_s = ShardedTri3Energy(m_s, lf_s, comm=comm)
+        sh_s.setup_interfaces()
+        sh_s.init_owner_adam(lr_x=1e-9, lr_u=1e-12)
+        ne_s, nn_s = mesh6_s[1].shape[0], mesh6_s[0].shape[0]
+        ko = KernelOnly(m_s, lf_s, sh_s.plan, sh_s.lo, sh_s.hi)
+        us, _ = time_launches(lambda i: ko(), max(a.steps, 50))
+        ne_r, nn_r, ab = range_work(sh_s.plan, sh_s.lo, sh_s.hi)
+        t = torch.tensor([us, float(ab) / (us * 1e-6) / 1e9], dtype=f64, device=dev)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        st = sh_s.plan.stats
+        res = dict(workload=name, elements=ne_s, nodes=nn_s, elements_per_gpu=ne_s // world, tiles=st["n_tiles"],
+                   tiles_per_rank=sh_s.hi - sh_s.lo, boundary_tiles_this_rank=sh_s.mid - sh_s.lo,
+                   threads_per_tile=st["threads_per_tile"], slot_rows=st["slot_rows"],
+                   payload_bytes=sh_s.interface_stats["payload_bytes"],
+                   kernel_only=dict(kernel_us_max_over_ranks=tmax[0].item(), kernel_us_rank0=us,
+                                    value=ne_s / (tmax[0].item() * 1e-6), achieved_GBs_all_ranks=tsum[1].item(),
+                                    frac_of_N_x_8TBs=tsum[1].item() / (HBM_PEAK_GBS * world)),
+                   eval_exchange=leg(sh_s.owner_step, "evaluation + interface exchange (the N = 1 definition of a step + the exchange)", ne_s),
+                   train_step=leg(sh_s.owner_train_step, "Adam iteration, exchange on the critical path", ne_s),
+                   train_step_overlap=leg(sh_s.owner_train_step_overlapped, "Adam iteration, exchange under the next step's interior tiles",
+                                          ne_s, end_=sh_s.finish_overlapped))
+        del sh_s, m_s, ko
+        return res
 
-    def kernel_only(bufs=None):
-        x_, u_, gx_, gu_ = bufs if bufs is not None else (xf, uf, gx_s, gu_s)
-        _lib.check(L.hfem_tri3_energy_plan(plan.handle, x_.data_ptr(), xfix.data_ptr() if xfix.numel() else None,
-                                           u_.data_ptr(), ufix.data_ptr() if ufix.numel() else None, mat, W, Bk, None,
-                                           Tc, lo, hi, loss_s.data_ptr(), gx_.data_ptr(), gu_.data_ptr(),
-                                           8, stream.cuda_stream))           # HFEM_FLAG_NO_LOSS_SUM
+    if world > 1 and not a.no_strong:
+        strong = [strong_leg("T1M FIXED (BASELINE configs[3] as stated): 10^6 TRI3 sharded over the ranks", t1m_mesh(1))]
+        if world >= 8:
+            from hidenn_fem_amd.mesh import unstructured_tri_mesh
+            strong.append(strong_leg("cfg5u FIXED (BASELINE configs[4]): ~4.1 x 10^6 TRI3 Delaunay mesh sharded over the ranks",
+                                     unstructured_tri_mesh(2_050_000, seed=2, dtype=f64)))
 
+    # ------------------------------------------------------------------------------------------------ roofline legs
     kreps = max(a.steps, 50)
-
-    def time_launches(body):
-        """Average time of one `body(i)` over `kreps` back-to-back calls (one hipGraph unless --no-graph), HIP events on
-        the launch stream, median of 5 regions after the clock pre-warm.  Returns (us, regions)."""
-        nonlocal stream
-        g = None
-        if not a.no_graph:
-            try:
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    stream = s
-                    body(0)
-                torch.cuda.current_stream().wait_stream(s)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    stream = torch.cuda.current_stream()
-                    for i in range(kreps):
-                        body(i)
-            except Exception:
-                g = None
-        stream = torch.cuda.current_stream()
-        for i in range(5):
-            body(i)
-        t_pw = time.perf_counter()
-        while g is not None and time.perf_counter() - t_pw < a.prewarm:
-            g.replay()
-            torch.cuda.synchronize()
-        regions = []
-        for _ in range(5):                      # 5 timed regions of `kreps` back-to-back bodies each
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record(stream)
-            if g is not None:
-                g.replay()
-            else:
-                for i in range(kreps):
-                    body(i)
-            ev1.record(stream)
-            torch.cuda.synchronize()
-            regions.append(ev0.elapsed_time(ev1) * 1e3 / kreps)
-        return sorted(regions)[len(regions) // 2], regions       # median region; each value is a kreps-launch average
-
-    only = a.only_regime
-    k_us, samples = time_launches(lambda i: kernel_only()) if only in ("", "replayed") else (float("nan"), [])
-    # ---- the same kernel in the cache regimes a training loop sees (reported beside the headline leg, never instead):
-    #  rewritten_inputs: x and u are rewritten by another kernel before every launch (what an optimiser step does);
-    #                    the kernel's share = (rewrite + energy) - (rewrite alone), both as back-to-back graphs
-    #  rotating_sets:    R parameter / gradient sets (R x 32 MB > the 256 MB Infinity Cache) visited round-robin, so
-    #                    every read of x, u and every gradient line misses the Infinity Cache (plan arrays stay shared)
+    ko_main = KernelOnly(model, loss_fn, plan, lo, hi)
+    k_us, samples = time_launches(lambda i: ko_main(), kreps) if only in ("", "replayed") and not a.only_extra else (float("nan"), [])
+    # The same kernel in the cache regimes a training loop sees:
+    #  replayed:         the same buffers every launch (44 MB working set: Infinity-Cache resident) -- what the headline step is
+    #  rewritten_inputs: x and u are rewritten by another kernel before every launch (what an optimiser step does); HIP events
+    #                    only see the pair, so events give (rewrite + energy) - (rewrite alone), an UPPER bound (the rewrite
+    #                    kernels themselves slow down inside the pair); the kernel's own in-run time comes from its stamps
+    #  rotating_sets:    R parameter / gradient sets (R x 32 MB > the 256 MB Infinity Cache) visited round-robin: every read of
+    #                    x, u and every gradient line misses the Infinity Cache (plan arrays stay shared) -- the HBM regime
     regimes = {}
-    if world == 1 and not a.no_regimes:
+    if world == 1 and not a.no_regimes and not a.only_extra:
+        xf, uf = ko_main.xf, ko_main.uf
+
         def rewrite(i):
-            with torch.cuda.stream(stream):
+            with torch.cuda.stream(stream_box[0]):
                 xf.mul_(1.0)
                 uf.mul_(1.0)
+        if only in ("", "replayed"):
+            sp, gap = span_launches(plan, lambda i: ko_main(), kreps)
+            regimes["replayed"] = dict(kernel_us=k_us, wg_span_us=sp, launch_gap_us=gap)
         if only in ("", "rewritten_inputs"):
-            t_rw, _ = time_launches(rewrite)
-            t_pair, _ = time_launches(lambda i: (rewrite(i), kernel_only()))
-            regimes["rewritten_inputs"] = dict(pair_us=t_pair, rewrite_alone_us=t_rw, kernel_us=t_pair - t_rw)
+            t_rw, _ = time_launches(rewrite, kreps)
+            t_pair, _ = time_launches(lambda i: (rewrite(i), ko_main()), kreps)
+            sp, gap = span_launches(plan, lambda i: (rewrite(i), ko_main()), kreps)
+            regimes["rewritten_inputs"] = dict(pair_us=t_pair, rewrite_alone_us=t_rw, events_upper_bound_us=t_pair - t_rw,
+                                               wg_span_us=sp)
         if only in ("", "rotating_sets"):
             R = max(2, a.rotating_sets)
-            sets = [(xf.clone(), uf.clone(), torch.empty_like(gx_s), torch.empty_like(gu_s)) for _ in range(R)]
-            t_rot, _ = time_launches(lambda i: kernel_only(sets[i % R]))
-            regimes["rotating_sets"] = dict(kernel_us=t_rot, sets=R,
+            sets = [(xf.clone(), uf.clone(), torch.empty_like(ko_main.gx), torch.empty_like(ko_main.gu)) for _ in range(R)]
+            t_rot, rot_regions = time_launches(lambda i: ko_main(sets[i % R]), kreps)
+            sp, gap = span_launches(plan, lambda i: ko_main(sets[i % R]), kreps)
+            regimes["rotating_sets"] = dict(kernel_us=t_rot, kernel_us_regions=[round(v, 3) for v in rot_regions], wg_span_us=sp,
+                                            launch_gap_us=gap, sets=R,
                                             working_set_mb=round(R * 4 * xf.numel() * 8 / 2 ** 20 + plan.stats["device_bytes"] / 2 ** 20, 1))
             del sets
     if only:
         if rank == 0:
             print(json.dumps(dict(only_regime=only, kernel_us=k_us, regimes=regimes)), flush=True)
         return None
-    # algorithmic bytes of ONE launch on this rank: its home elements and owned nodes
-    ne_launch = int(td[lo:hi, 1].sum()) if world > 1 else ne      # (halo elements are not algorithmic work)
-    if world > 1:
-        ne_launch = int(sum(int(plan.tile_elements(t)[2].sum()) for t in range(lo, hi)))
-    nn_launch = int(td[lo:hi, 4].sum())
-    alg_bytes = 12 * ne_launch + 64 * nn_launch + 8
-    achieved = alg_bytes / (k_us * 1e-6) / 1e9
-    # HBM traffic per launch: PMC numbers cannot be collected from inside this process; they come from the
-    # committed rocprofv3 passes of the SAME kernel/workload (profiles/r02_hbm_traffic_T1M.json, scripts/prof_regimes.sh),
-    # else null; likewise the profiler's own per-kernel average of every regime (profiles/r02/regimes_rocprof.json)
-    traffic, rocprof_us = None, {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_T1M.json")) as f:
-            tr = json.load(f)
-        if world == 1 and tr["workload"] == dict(elements=ne, nodes=nn, tiles=plan.stats["n_tiles"]):
-            traffic = tr["traffic_bytes_per_launch"]
-        with open(os.path.join(ROOT, "profiles", "r02", "regimes_rocprof.json")) as f:
-            rp = json.load(f)
-        if world == 1 and rp["workload"] == dict(elements=ne, nodes=nn, tiles=plan.stats["n_tiles"]):
-            rocprof_us = {k: v["avg_us"] for k, v in rp["regimes"].items()}
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="tri3_energy_pair_kernel" if plan.is_paired() else "tri3_energy_fast_kernel", kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
-                    alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
+
+    ne_launch, nn_launch, alg_bytes = range_work(plan, lo, hi)
+    # Counter traffic and the profiler's own per-kernel averages cannot be collected from inside this process: they come from
+    # the committed rocprofv3 passes of the SAME kernel / workload (scripts/prof_regimes.sh, scripts/prof_extras.sh), keyed by
+    # the workload's shape, else null.  FETCH_SIZE / WRITE_SIZE sit on the L2's fabric side: requests served by the Infinity
+    # Cache are counted, so `traffic` is an UPPER bound on HBM bytes in the cache-resident regimes.
+    prof = {}
+    for fn in ("regimes_rocprof.json", "traffic.json"):
+        try:
+            with open(os.path.join(PROFILE_DIR, fn)) as f:
+                prof[fn] = json.load(f)
+        except (OSError, ValueError):
+            prof[fn] = {}
+    shape_key = f"{ne}/{nn}/{plan.stats['n_tiles']}"
+    traffic_tab = prof["traffic.json"].get("workloads", {})
+    traffic = traffic_tab.get("T1M", {}).get("traffic_bytes_per_launch") if world == 1 and traffic_tab.get("T1M", {}).get("shape") == shape_key else None
+    rp = prof["regimes_rocprof.json"]
+    rocprof_us = {k: v["avg_us"] for k, v in rp.get("regimes", {}).items()} if world == 1 and rp.get("shape") == shape_key else {}
+    # in-run estimate of a regime's launch time from the kernel's own stamps: its span + the launch ramp that the replayed
+    # leg shows between span and events time (dispatch of 1024 workgroups + the tail the stamps do not see)
+    ramp = None
+    if regimes.get("replayed", {}).get("wg_span_us"):
+        ramp = regimes["replayed"]["kernel_us"] - regimes["replayed"]["wg_span_us"]
     for name, r in regimes.items():
+        if name == "rewritten_inputs":
+            if r.get("wg_span_us") and ramp is not None:
+                r["kernel_us"] = r["wg_span_us"] + ramp
+                r["kernel_us_source"] = ("in-run: the kernel's own span stamps inside the (rewrite, energy) sequence + the launch ramp "
+                                         f"of the replayed leg ({ramp:.2f} us = events - span there)")
+            else:
+                r["kernel_us"] = r["events_upper_bound_us"]
+                r["kernel_us_source"] = "HIP events, (rewrite + energy) - (rewrite alone): an upper bound"
         r["achieved"] = alg_bytes / (r["kernel_us"] * 1e-6) / 1e9
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
-    if regimes:
-        roofline["regimes"] = dict(replayed=dict(kernel_us=k_us, achieved=achieved, frac=achieved / HBM_PEAK_GBS), **regimes)
-        if "rewritten_inputs" in regimes:
-            regimes["rewritten_inputs"]["note"] = (
-                "kernel_us = (rewrite + energy) - (rewrite alone): an UPPER bound -- the two rewrite kernels themselves "
-                "slow down inside the pair (rocprofv3: 5.7 us each vs 3.5 us alone); the profiler's own duration of the "
-                "energy kernel in this sequence is rocprof_kernel_us")
-        for name, r in roofline["regimes"].items():      # the profiler's per-kernel average of the same leg (committed run)
-            if name in rocprof_us:
-                r["rocprof_kernel_us"] = rocprof_us[name]
-                r["rocprof_frac"] = alg_bytes / (rocprof_us[name] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        if name in rocprof_us:                      # committed profiler run of the same leg, never the in-run figure
+            r["rocprof_kernel_us"] = rocprof_us[name]
+            r["rocprof_frac"] = alg_bytes / (rocprof_us[name] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    kname = "tri3_energy_pair_kernel" if plan.is_paired() else "tri3_energy_fast_kernel"
+    top = regimes.get("rotating_sets")
+    if top is not None:
+        roofline = dict(bound="hbm", achieved=top["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=top["frac"], traffic=traffic,
+                        traffic_kind="FETCH_SIZE x2 + WRITE_SIZE of the committed rocprofv3 --pmc passes: requests on the L2's fabric "
+                                     "side (Infinity-Cache hits included); identical in the replayed and rotating regimes",
+                        kernel=kname, kernel_us=top["kernel_us"], kernel_us_regions=top.get("kernel_us_regions"),
+                        regime="rotating_sets: 10 parameter / gradient sets, 313 MB > the 256 MB Infinity Cache -- reads of x, u and "
+                               "the gradient lines go to HBM (the cache-resident leg the timed step runs in is regimes.replayed)",
+                        alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch, regimes=regimes)
+    else:
+        achieved = alg_bytes / (k_us * 1e-6) / 1e9
+        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        kernel=kname, kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
+                        regime="replayed: the same buffers every launch (cache-resident working set)" + ("" if world == 1 else
+                               "; this rank's tile range of the weak-scaling mesh"),
+                        alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
 
     # ---- config.extra (N = 1): the other readings of "1 M quad elements" and BASELINE config 5, kernel only, each with
     #      its own roofline figures (algorithmic bytes of ITS element type over ITS kernel's average launch time):
-    #        Q1M   10^6 QUAD4-iso elements (the extension element; parity unpinned by the reference, SURVEY F11)
-    #        T2M   the same 10^6 quads split in two: 2 x 10^6 TRI3 (reference-pinned element)
-    #        cfg5  4 x 10^6 TRI3, structured split with random diagonals + random element / node permutation
-    #        cfg5u 4.1 x 10^6 TRI3, genuinely unstructured: Delaunay of graded random points, plate with three holes
+    #        Q1M      10^6 QUAD4-iso elements (the extension element; parity unpinned by the reference)
+    #        T2M      the same 10^6 quads split in two: 2 x 10^6 TRI3 (reference-pinned element)
+    #        cfg5     4 x 10^6 TRI3, random diagonals + random element / node permutation, rows stored as given (reorder="off")
+    #        cfg5auto the same mesh through the plain model API (reorder="auto": rows stored along the locality curve)
+    #        cfg5r    the same after mesh.reorder_for_locality (explicit renumbering by the caller)
+    #        cfg5u    4.1 x 10^6 TRI3, genuinely unstructured: Delaunay of graded random points, plate with three holes
     extras = []
-    if world == 1 and not a.no_extra and not only:
-        from hidenn_fem_amd.mesh import structured_quad_mesh, unstructured_tri_mesh
+    if world == 1 and (not a.no_extra or a.only_extra):
+        from hidenn_fem_amd.mesh import reorder_for_locality, structured_quad_mesh, unstructured_tri_mesh
 
-        def extra(name, mesh, quad=False):
+        def extra(key, name, mesh, quad=False, model_kw=None):
+            if a.only_extra and a.only_extra != key:
+                return
             c_, cn_, g_, b_, _, e_ = mesh
             torch.manual_seed(0)
-            m_ = PiecewiseLinearShapeNN2D(c_, cn_, boundary_mask=g_, dirichlet_mask=b_, u_fixed=0.0, neumann_edges=e_).to(dev)
+            m_ = PiecewiseLinearShapeNN2D(c_, cn_, boundary_mask=g_, dirichlet_mask=b_, u_fixed=0.0, neumann_edges=e_,
+                                          **(model_kw or {})).to(dev)
             lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64)
             pl = m_.tile_plan(0)
             x_, u_ = m_.node_coords_free.detach(), m_.u_free.detach()
@@ -475,58 +650,75 @@ def main():
             gx_, gu_ = torch.empty_like(x_), torch.empty_like(u_)
             ls_ = torch.zeros((), dtype=f64, device=dev)
             _, Tc_ = lf_._traction(m_, None)
-            Tcv = dv(Tc_)
+            Tcv, mat_ = dv(Tc_), dv(lf_._mat)
 
             def launch(i):
                 if quad:
                     _lib.check(L.hfem_quad4_energy_plan(pl.handle, x_.data_ptr(), xfx.data_ptr(), u_.data_ptr(), ufx.data_ptr(),
-                                                        mat, None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(), gu_.data_ptr(),
-                                                        8, stream.cuda_stream))
+                                                        mat_, None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(), gu_.data_ptr(),
+                                                        8, stream_box[0].cuda_stream))
                 else:
                     _lib.check(L.hfem_tri3_energy_plan(pl.handle, x_.data_ptr(), xfx.data_ptr(), u_.data_ptr(), ufx.data_ptr(),
-                                                       mat, W, Bk, None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(),
-                                                       gu_.data_ptr(), 8, stream.cuda_stream))
-            us, _ = time_launches(launch)
+                                                       mat_, lf_._W, dv([0.0] * 6), None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(),
+                                                       gu_.data_ptr(), 8, stream_box[0].cuda_stream))
+            us, _ = time_launches(launch, min(kreps, 60))
             ne_, nn_ = cn_.shape[0], c_.shape[0]
             ab = (16 if quad else 12) * ne_ + 64 * nn_ + 8
             st_ = pl.stats
-            extras.append(dict(name=name, element="QUAD4" if quad else "TRI3", elements=ne_, nodes=nn_, tiles=st_["n_tiles"],
+            tr_ = traffic_tab.get(key, {})
+            tr_ok = tr_.get("shape") == f"{ne_}/{nn_}/{st_['n_tiles']}"
+            extras.append(dict(key=key, name=name, element="QUAD4" if quad else "TRI3", elements=ne_, nodes=nn_, tiles=st_["n_tiles"],
                                halo_elem_factor=st_["tile_elem_total"] / ne_, halo_node_factor=st_["tile_node_total"] / nn_,
+                               row_order=getattr(m_, "row_order", "as given"), row_line_factor=getattr(m_, "row_line_factor", None),
                                kernel_us=us, element_evals_per_s=ne_ / (us * 1e-6), alg_bytes_per_launch=ab,
-                               achieved=ab / (us * 1e-6) / 1e9, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS))
+                               achieved=ab / (us * 1e-6) / 1e9, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               traffic=tr_.get("traffic_bytes_per_launch") if tr_ok else None,
+                               traffic_over_alg=(tr_["traffic_bytes_per_launch"] / ab) if tr_ok else None))
             del m_, pl
 
-        keep = kreps
-        kreps = min(kreps, 60)
-        extra("Q1M: 10^6 QUAD4-iso (1001 x 1001 nodes), parity unpinned by the reference",
+        extra("Q1M", "Q1M: 10^6 QUAD4-iso (1001 x 1001 nodes), parity unpinned by the reference",
               structured_quad_mesh(1001, 1001, length=2.0, height=2.0, jitter=0.2, seed=0, dtype=f64), quad=True)
-        extra("T2M: the same 10^6 quads split in two (2 x 10^6 TRI3)",
+        extra("T2M", "T2M: the same 10^6 quads split in two (2 x 10^6 TRI3)",
               structured_tri_mesh(1001, 1001, length=2.0, height=2.0, jitter=0.2, seed=0, dtype=f64))
-        extra("cfg5: 4 x 10^6 TRI3, random diagonals, random element + node permutation",
-              structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=f64))
-        from hidenn_fem_amd.mesh import reorder_for_locality
-        extra("cfg5r: cfg5 after mesh.reorder_for_locality (Hilbert node renumbering, the host mesh pipeline's step)",
-              reorder_for_locality(structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True,
-                                                       dtype=f64))[0])
-        extra("cfg5u: genuinely unstructured (Delaunay, plate with three holes, graded), ~4.1 x 10^6 TRI3",
+        cfg5 = structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=f64)
+        extra("cfg5", "cfg5: 4 x 10^6 TRI3, random diagonals, random element + node permutation, rows stored as the mesher "
+              "numbered them (reorder='off')", cfg5, model_kw=dict(reorder="off"))
+        extra("cfg5auto", "cfg5auto: the same mesh through the plain model API (reorder='auto')", cfg5)
+        extra("cfg5r", "cfg5r: cfg5 after mesh.reorder_for_locality (Hilbert node renumbering by the caller)",
+              reorder_for_locality(cfg5)[0])
+        del cfg5
+        extra("cfg5u", "cfg5u: genuinely unstructured (Delaunay, plate with three holes, graded), ~4.1 x 10^6 TRI3",
               unstructured_tri_mesh(2_050_000, seed=2, dtype=f64))
-        kreps = keep
+    if a.only_extra:
+        if rank == 0:
+            print(json.dumps(dict(only_extra=a.only_extra, extras=extras)), flush=True)
+        return None
+
+    # ---- config.strong_scaling_emulated (N = 1): BASELINE configs[3] AS STATED on one GPU -- the FIXED 10^6-element mesh
+    #      sharded N ways by a plan prepared for N ranks (shard-aware tile policy), kernel only over the tile range of the
+    #      first, a middle and the last rank; the max is what a strong-scaling step waits for
+    strong_emu = None
+    if world == 1 and not a.no_extra:
+        strong_emu = []
+        for n_ in (2, 4, 8):
+            r_ = shard_kernel_leg(model, loss_fn, n_, sorted({0, n_ // 2, n_ - 1}), kreps)
+            r_["workload"] = "T1M fixed"
+            r_["speedup_vs_1gpu_kernel"] = regimes.get("replayed", {}).get("kernel_us", k_us) / r_["kernel_us_max"]
+            strong_emu.append(r_)
 
     # ---- config.train_step_1gpu (N = 1): the hot path INSIDE an optimiser loop on T1M -- what a training iteration costs
-    #      when the kernel's inputs are what the optimiser just wrote.  (i) energy launch + FusedAdam launch (the
-    #      reference's `loss.backward(); optimizer.step()`), (ii) one launch: the tiles apply Adam to the rows they own
+    #      when the kernel's inputs are what the optimiser just wrote.  (i) energy launch + ONE multi-tensor FusedAdam launch
+    #      (the reference's `loss.backward(); optimizer.step()`), (ii) one launch: the tiles apply Adam to the rows they own
     #      (hfem_tri3_energy_adam_step).  K iterations in one hipGraph each; lr tiny so the mesh stays valid.
     train1 = None
-    if world == 1 and not a.no_extra and not only:
+    if world == 1 and not a.no_extra:
         try:
             from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
             from hidenn_fem_amd.graphed import GraphedTraining
             res = {}
             K = max(2, (a.steps // 2) * 2)
             for mode in ("two_launch", "one_launch"):
-                torch.manual_seed(0)
-                m_ = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
-                                              neumann_edges=edges).to(dev)
+                m_ = build_model(mesh6)
                 lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
                 if mode == "two_launch":
                     opt = FusedAdam([dict(params=[m_.node_coords_free], lr=1e-9), dict(params=[m_.u_free], lr=1e-12)],
@@ -554,18 +746,17 @@ def main():
                 res[mode] = dict(us_per_iteration=it * 1e6, element_evals_per_s=ne / it)
                 del gt, m_
             train1 = dict(workload="T1M, Adam on node_coords_free and u_free, K iterations per hipGraph", **res)
-        except Exception as e:  # pragma: no cover
-            print(f"[bench] train_step_1gpu leg failed: {e}", file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            note(f"train_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
 
     out = None
     if rank == 0:
         cpu = None
-        if not a.no_cpu_baseline:
-            if world == 1:
-                cpu, loss_cpu = cpu_baseline(mesh6, model.u_free.detach().cpu(), a.cpu_evals)
-                rel = abs(loss_cpu - loss_gpu) / abs(loss_cpu)
-                assert rel <= 1e-12, f"GPU loss {loss_gpu!r} != oracle loss {loss_cpu!r} (rel {rel:.2e})"
-                cpu["loss_rel_err_vs_gpu"] = rel
+        if not a.no_cpu_baseline and world == 1:
+            cpu, loss_cpu = cpu_baseline(mesh6, model.to_caller_order(model.u_free.detach(), "u").cpu(), a.cpu_evals)
+            rel = abs(loss_cpu - loss_gpu) / abs(loss_cpu)
+            assert rel <= 1e-12, f"GPU loss {loss_gpu!r} != oracle loss {loss_cpu!r} (rel {rel:.2e})"
+            cpu["loss_rel_err_vs_gpu"] = rel
         st = plan.stats
         out = dict(
             metric="element-evals/sec (fwd+bwd energy) + achieved HBM GB/s, 2D quad mesh",
@@ -577,28 +768,40 @@ def main():
                                  f"Neumann edges {edges.shape[0]}, fwd+bwd (loss + dX + dU)",
                         elements=ne, nodes=nn, elements_per_gpu=ne // world, tiles=st["n_tiles"],
                         tile_elems=st["tile_elems"], element_order="paired slots" if plan.is_paired() else "one element per slot",
+                        threads_per_tile=st["threads_per_tile"],
                         halo_elem_factor=sum(len(plan.tile_elements(t)[0]) for t in range(st["n_tiles"])) / max(ne, 1),
-                        lds_bytes=st["lds_bytes"], launch="hipgraph" if graph is not None else "eager",
+                        lds_bytes=st["lds_bytes"], launch=launch,
+                        timed_region=f"one hipGraph of {a.steps} steps; median of {len(regions)} replays",
+                        ms_per_step_replays=[round(r / a.steps * 1e3, 6) for r in regions],
                         loss_sum=("by an extra workgroup of the next launch (HFEM_FLAG_SUM_PREVIOUS) + one trailing "
                                   "1-block launch" if lagged else "1-block launch after every energy kernel"),
                         exchange="none" if world == 1 else
                         f"owner-sharded: gradient rows stay with the rank whose tiles own the node; one all_gather per "
                         f"step of interface parameter rows + partial energy ({sh.interface_stats['payload_bytes']} B "
-                        f"per rank), " + ("in-library RCCL (hfem_mg_allgather) on the kernel stream" if comm is not None
-                                          else f"torch.distributed {a.backend}"),
+                        f"per rank), {comm_state}",
                         loss=loss_gpu),
             roofline=roofline,
         )
+        if world > 1:
+            out["config"]["collectives"] = comm_state
         if extras:
             out["config"]["extra"] = extras
         if inline_step is not None:
             out["config"]["inline_loss_step"] = inline_step
         if train1 is not None:
             out["config"]["train_step_1gpu"] = train1
+        if strong_emu is not None:
+            out["config"]["strong_scaling_emulated"] = strong_emu
         if alt is not None:
             out["config"]["alt_exchange"] = alt
         if train is not None:
             out["config"]["train_step"] = train
+        if train_ov is not None:
+            out["config"]["train_step_overlap"] = train_ov
+        if strong is not None:
+            out["config"]["strong_scaling"] = strong
+        if notes:
+            out["config"]["notes"] = notes
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -25,6 +25,33 @@ def _np_mask(t):
     return t.detach().cpu().numpy().astype(bool)
 
 
+ROW_LINE_THRESHOLD = 2.0      # reorder="auto": store the parameter rows along the locality curve above this figure
+ROW_REORDER_MIN_NODES = 4096  # ... and only for meshes big enough for it to matter (smaller ones live in the caches)
+
+
+def row_line_factor(rows_along_curve: np.ndarray, chunk: int = 512, rows_per_line: int = 8) -> float:
+    """Locality figure of a row numbering: walk the rows in the order of the locality curve (the order in which tiles
+    gather them) in chunks of ``chunk`` and count the distinct 128-byte lines (8 rows of 16 bytes) a chunk touches,
+    relative to the minimum ``chunk / 8``.  1.0 = rows stored along the curve; ~1.4 = row-major structured numbering;
+    8.0 = random numbering (every 16-byte row gather pulls its own 128-byte line)."""
+    n = (len(rows_along_curve) // chunk) * chunk
+    if n == 0:
+        return 1.0
+    lines = np.sort((rows_along_curve[:n] // rows_per_line).reshape(-1, chunk), axis=1)
+    distinct = 1 + (np.diff(lines, axis=1) != 0).sum(axis=1)
+    return float(distinct.mean() / (chunk / rows_per_line))
+
+
+def ordered_row_maps(mask: np.ndarray, idx_free: np.ndarray):
+    """int32 map node -> row: ``idx_free[j]`` (node id) lives in row ``j`` of the free array; masked-out nodes map to
+    ``-1 - k`` with ``k`` their rank among the masked-out nodes in the caller's numbering (``plan.row_maps`` when
+    ``idx_free`` is ascending)."""
+    src = np.empty(mask.shape[0], dtype=np.int32)
+    src[idx_free] = np.arange(len(idx_free), dtype=np.int32)
+    src[~mask] = -1 - np.arange(int((~mask).sum()), dtype=np.int32)
+    return src
+
+
 # ============================================================================ 1D
 class PiecewiseLinearShapeNN(nn.Module):
     """Nodes on a line, hat functions, optional r-adaptivity through positive increments
@@ -216,8 +243,18 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
     (r-adaptivity) and free nodal values as parameters (reference ``models.py:241-376``)."""
 
     def __init__(self, node_coords, connectivity, boundary_mask=None, dirichlet_mask=None, u_fixed=None,
-                 neumann_edges=None):
+                 neumann_edges=None, reorder="auto"):
+        """Reference signature (models.py:242-251) plus ``reorder``: how the rows of the two parameter tensors are
+        STORED.  The reference hands over whatever numbering the mesher produced (mesh.py:136-144); a tile gathers
+        16-byte rows, so a numbering without locality costs up to 8x the read traffic.  ``"auto"`` (default) measures
+        the numbering (``row_line_factor``) and, when it is poor on a mesh of >= 4096 nodes, stores
+        ``node_coords_free`` / ``u_free`` along the Hilbert curve of the initial coordinates; ``"hilbert"`` always
+        does, ``"off"`` never.  Node numbering, ``connectivity``, masks, ``coords``, ``u_full``, ``forward`` and
+        ``state_dict()`` stay in the CALLER's numbering either way; only the raw parameter tensors (and hence
+        ``.grad`` and optimiser state) are in storage order -- ``to_caller_order`` / ``from_caller_order`` convert."""
         super().__init__()
+        if reorder not in ("auto", "hilbert", "off"):
+            raise ValueError("reorder must be 'auto', 'hilbert' or 'off'")
         self.scale = 1e-5
         self.dim_u = 2
         # opt-in (SURVEY F4): "reference" = dN_dx = Jinv * dN_dxi exactly as models.py:351; "physical" = Jinv^T
@@ -232,14 +269,31 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
             dirichlet_mask = torch.zeros(self.Nnodes, dtype=torch.bool, device=node_coords.device)
         self.register_buffer("boundary_mask", boundary_mask.clone())
         free_mask = ~boundary_mask
-        self.node_coords_free = nn.Parameter(node_coords[free_mask].clone())
+        u_free_mask = ~dirichlet_mask
+        fm, um = _np_mask(free_mask), _np_mask(u_free_mask)
+        # ---- storage order of the parameter rows (see the docstring): node ids of the free rows, in row order
+        idx_free, idx_ufree = np.nonzero(fm)[0], np.nonzero(um)[0]
+        self.row_order, self.row_line_factor = "as given", None
+        if reorder != "off" and self.Nnodes >= 2:
+            from .mesh import _hilbert_keys
+            curve = np.argsort(_hilbert_keys(node_coords.detach().cpu().double().numpy()), kind="stable")   # node ids along the curve
+            cf, cu = curve[fm[curve]], curve[um[curve]]
+            caller_row_x = np.cumsum(fm) - 1                     # row of node n in the caller's numbering
+            self.row_line_factor = row_line_factor(caller_row_x[cf])
+            if reorder == "hilbert" or (self.row_line_factor > ROW_LINE_THRESHOLD and self.Nnodes >= ROW_REORDER_MIN_NODES):
+                idx_free, idx_ufree = cf, cu
+                self.row_order = "hilbert"
+        t_free = torch.from_numpy(idx_free).to(node_coords.device)
+        self.node_coords_free = nn.Parameter(node_coords[t_free].clone())
         self.register_buffer("node_coords_fixed", node_coords[boundary_mask].clone())
         self.register_buffer("free_mask", free_mask)
         self.register_buffer("dirichlet_mask", dirichlet_mask.clone())
-        u_free_mask = ~dirichlet_mask
         self.register_buffer("u_free_mask", u_free_mask)
-        # same RNG call as upstream (models.py:274): identical u_free for an identical seed
+        # same RNG call as upstream (models.py:274): identical u_free for an identical seed -- drawn in the caller's row
+        # order, then stored in storage order
         u0 = self.scale * torch.randn(int(u_free_mask.sum().item()), self.dim_u)
+        if self.row_order != "as given":
+            u0 = u0[torch.from_numpy((np.cumsum(um) - 1)[idx_ufree])]
         self.u_free = nn.Parameter(u0.to(device=node_coords.device, dtype=node_coords.dtype))
         if u_fixed is not None:
             self.register_buffer("u_fixed", torch.as_tensor(u_fixed).to(node_coords.device))
@@ -251,14 +305,21 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
         else:
             self.neumann_edges = None
             self.N_edges = 0
-        # int32 index lists / maps (derived from the masks; not part of the state dict)
-        fm, um = _np_mask(free_mask), _np_mask(u_free_mask)
-        self._x_src, self._u_src = row_maps(fm), row_maps(um)
+        # int32 index lists / maps (derived from the masks and the storage order; not part of the state dict)
+        self._x_src, self._u_src = ordered_row_maps(fm, idx_free), ordered_row_maps(um, idx_ufree)
         i32 = dict(dtype=torch.int32)
-        self.register_buffer("_idx_free", torch.tensor(np.nonzero(fm)[0], **i32), persistent=False)
+        self.register_buffer("_idx_free", torch.tensor(idx_free, **i32), persistent=False)
         self.register_buffer("_idx_fixed", torch.tensor(np.nonzero(~fm)[0], **i32), persistent=False)
-        self.register_buffer("_idx_ufree", torch.tensor(np.nonzero(um)[0], **i32), persistent=False)
+        self.register_buffer("_idx_ufree", torch.tensor(idx_ufree, **i32), persistent=False)
         self.register_buffer("_idx_udir", torch.tensor(np.nonzero(~um)[0], **i32), persistent=False)
+        # storage row j <-> caller row perm[j] (None: the same order); state_dict() speaks the caller's order
+        if self.row_order != "as given":
+            self.register_buffer("_perm_x", torch.from_numpy((np.cumsum(fm) - 1)[idx_free]), persistent=False)
+            self.register_buffer("_perm_u", torch.from_numpy((np.cumsum(um) - 1)[idx_ufree]), persistent=False)
+            self.register_state_dict_post_hook(TriangularShapeNN2D._state_to_caller_order)
+            self.register_load_state_dict_pre_hook(TriangularShapeNN2D._state_from_caller_order)
+        else:
+            self._perm_x = self._perm_u = None
         self.register_buffer("_conn32", connectivity.to(torch.int32).contiguous(), persistent=False)
         e32 = (neumann_edges if neumann_edges is not None else torch.zeros((0, 2), dtype=torch.long))
         self.register_buffer("_edges32", e32.to(torch.int32).contiguous(), persistent=False)
@@ -275,6 +336,36 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
     def __setstate__(self, state):
         super().__setstate__(state)
         self.__dict__.setdefault("_plans", {})
+
+    # -- storage order of the parameter rows <-> the caller's numbering ----------------------
+    def to_caller_order(self, t: torch.Tensor, which: str = "x") -> torch.Tensor:
+        """A ``[rows, ...]`` tensor in the storage order of ``node_coords_free`` (``which="x"``) or ``u_free`` (``"u"``)
+        -- the parameter itself, its ``.grad``, an optimiser moment -- as the reference would index it: row ``k`` = the
+        ``k``-th free node in the caller's numbering (``node_coords[free_mask]`` order, models.py:260)."""
+        p = self._perm_x if which == "x" else self._perm_u
+        if p is None:
+            return t
+        out = torch.empty_like(t)
+        out[p.to(t.device)] = t
+        return out
+
+    def from_caller_order(self, t: torch.Tensor, which: str = "x") -> torch.Tensor:
+        """Inverse of ``to_caller_order``: rows in the caller's order -> storage order."""
+        p = self._perm_x if which == "x" else self._perm_u
+        return t if p is None else t[p.to(t.device)]
+
+    @staticmethod
+    def _state_to_caller_order(module, state_dict, prefix, local_metadata):
+        for name, which in (("node_coords_free", "x"), ("u_free", "u")):
+            if prefix + name in state_dict:
+                state_dict[prefix + name] = module.to_caller_order(state_dict[prefix + name], which)
+
+    @staticmethod
+    def _state_from_caller_order(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name, which in (("node_coords_free", "x"), ("u_free", "u")):
+            key = prefix + name
+            if key in state_dict and state_dict[key].shape == getattr(module, name).shape:
+                state_dict[key] = module.from_caller_order(state_dict[key], which)
 
     # -- reference attribute surface ------------------------------------------------------
     @property

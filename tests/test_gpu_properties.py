@@ -221,3 +221,60 @@ def test_cfg5_genuinely_unstructured_4m_elements_vs_oracle():
     assert np.abs(gu - gU_ref[~bc.numpy()]).max() <= 1e-10 * np.abs(gU_ref).max()
     print(f"[unstructured 4M] elements {ne} nodes {nn} tiles {st['n_tiles']} halo elems x{st['tile_elem_total'] / ne:.3f} "
           f"nodes x{st['tile_node_total'] / nn:.3f} max valence {valence.max()}")
+
+
+@pytest.mark.gpu
+def test_cfg5_as_specified_through_the_plain_model_api_reorders_rows_and_matches_oracle():
+    """BASELINE config 5 exactly as SURVEY specifies it -- 4 x 10^6 TRI3, random diagonals, random element permutation AND
+    random global node renumbering -- through the reference's construction API, nothing else: the model notices the
+    numbering (row_line_factor ~ 8) and stores its parameter rows along the locality curve (reorder="auto").  Loss and
+    every gradient row against the C oracle on the CALLER's numbering; coords / u_full / state_dict in the caller's
+    numbering; same numbers as the same model with reorder="off"."""
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from oracle import closed_form as CF
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random",
+                                                            permute=True, dtype=F64)
+    kw = dict(boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges)
+    torch.manual_seed(7)
+    m = PiecewiseLinearShapeNN2D(coords, conn, **kw).to(d)
+    assert m.row_order == "hilbert" and m.row_line_factor > 6.0
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    loss = lf(m)
+    loss.backward()
+    # oracle on the caller's numbering
+    g_np, b_np = geom.numpy(), bc.numpy()
+    X = coords.numpy().copy()
+    U = np.zeros_like(X)
+    U[~b_np] = m.to_caller_order(m.u_free.detach(), "u").cpu().numpy()
+    mat, W = CF.plane_stress(), 0.25
+    Tc = np.array([lf._ci * 1e5, 0.0, lf._cj * 1e5, 0.0])
+    e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn.numpy(), mat, W)
+    e_ref -= CF.edge2_energy(X, U, edges.numpy(), Tconst=Tc, gX=gX_ref, gU=gU_ref)
+    assert abs(loss.item() - e_ref) <= 1e-12 * abs(e_ref)
+    gx = m.to_caller_order(m.node_coords_free.grad, "x").cpu().numpy()
+    gu = m.to_caller_order(m.u_free.grad, "u").cpu().numpy()
+    assert np.abs(gx - gX_ref[~g_np]).max() <= 1e-10 * np.abs(gX_ref).max()
+    assert np.abs(gu - gU_ref[~b_np]).max() <= 1e-10 * np.abs(gU_ref).max()
+    # the assembled fields are in the caller's numbering
+    assert torch.equal(m.coords.detach().cpu(), coords)
+    assert torch.equal(m.u_full.detach().cpu()[~bc], torch.from_numpy(U[~b_np]))
+    sd = m.state_dict()
+    assert torch.equal(sd["node_coords_free"].cpu(), coords[~geom])
+    # same model, rows stored as given: the same energy (the locality of the row gathers is all that differs)
+    torch.manual_seed(7)
+    m_off = PiecewiseLinearShapeNN2D(coords, conn, reorder="off", **kw).to(d)
+    assert m_off.row_order == "as given" and torch.equal(m_off.state_dict()["u_free"], sd["u_free"])
+    l_off = lf(m_off)
+    assert abs(l_off.item() - loss.item()) <= 1e-13 * abs(loss.item())
+    # the plan's row maps of the reordered model are local: a tile's rows touch few 128-byte lines
+    ns, td = m.tile_plan(0).export("node_src"), m.tile_plan(0).export("tile_desc")
+    ns_off = m_off.tile_plan(0).export("node_src")
+
+    def lines_per_tile(ns_, t):
+        rows = ns_[td[t, 2]:td[t, 2] + td[t, 3], 0]
+        return len(np.unique(rows[rows >= 0] // 8))
+    mid = td.shape[0] // 2
+    assert lines_per_tile(ns, mid) * 4 < lines_per_tile(ns_off, mid)

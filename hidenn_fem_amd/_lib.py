@@ -34,6 +34,12 @@ class PlanStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class AdamTensor(C.Structure):
+    """``hfem_adam_tensor`` (include/hidenn_fem.h): one entry of the multi-tensor Adam table."""
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("n", _i64), ("lr", _f64), ("beta1", _f64),
+                ("beta2", _f64), ("eps", _f64), ("dtype", _i32), ("block_begin", _i32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/hidenn_fem.h declares
 PROTOTYPES = {
     "hfem_version": (C.c_int, []),
@@ -60,6 +66,7 @@ PROTOTYPES = {
     "hfem_adam_step_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i32, C.c_double, C.c_double, C.c_double,
                                      C.c_double, _vp, _vp]),
     "hfem_counter_add": (C.c_int, [C.c_int, _vp, _i64, _vp]),
+    "hfem_adam_multi_dev": (C.c_int, [C.c_int, _vp, _i32, _i32, _i64, _vp, _i64, _vp, _vp]),
     "hfem_lbfgs_create": (C.c_int, [C.c_int, _i64, _i32, _i32, C.POINTER(_vp)]),
     "hfem_lbfgs_destroy": (C.c_int, [_vp]),
     "hfem_lbfgs_check": (C.c_int, [_vp, _vp, _vp, _i32, C.c_double, C.c_double, _vp, _vp]),
@@ -70,6 +77,8 @@ PROTOTYPES = {
     "hfem_line2_slopes": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hfem_tri3_energy_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i32, _vp]),
+    "hfem_tri3_energy_adam_step_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i32, _vp]),
     "hfem_adam_prep": (C.c_int, [C.c_int, _vp, _f64, _f64, _vp, _vp]),
     "hfem_plan_loss_sum": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "hfem_iface_pack": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),

@@ -29,11 +29,33 @@ struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgr
 
 
 struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
-    double2 *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows); must not alias the inputs
-    double2 *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows, updated in place
+    void *x_out = nullptr, *u_out = nullptr;   // new parameter rows (free rows, the kernel's row type V2); must not alias the inputs
+    void *mx = nullptr, *vx = nullptr, *mu = nullptr, *vu = nullptr;   // Adam moments, free rows of the same type, updated in place
     const double *bc = nullptr;                  // device {1 - b1^step, sqrt(1 - b2^step)} of this step (hfem_adam_prep)
     double lr_x = 0, lr_u = 0, b1 = 0.9, b2 = 0.999, eps = 1e-8;
 };
+
+// The fused write-out of one owned row (c = 0: coordinates, 1: displacements): torch.optim.Adam's update in the row type's
+// own arithmetic -- operation for operation optim.hip's adam_one<T> (fp64 rows: fp64; fp32 rows, the reference's default
+// dtype: the gradient is rounded to float once, as the float-row kernel would store it, then torch's fp32 arithmetic).
+// m, v are read and written in place, the NEW row goes to the other parameter buffer (ping-pong).
+template <typename V2>
+__device__ __forceinline__ void adam_fused_row(const AdamFuse &af, int c, int row, double gx, double gy, double2 p64,
+                                               double bc1, double sqrt_bc2) {
+    typedef decltype(V2().x) T;
+    V2 *mp = reinterpret_cast<V2 *>(c ? af.mu : af.mx) + row, *vp = reinterpret_cast<V2 *>(c ? af.vu : af.vx) + row;
+    const V2 m = *mp, v = *vp;
+    const T w1 = (T)(1.0 - af.b1), w2 = (T)(1.0 - af.b2), b2 = (T)af.b2, eps = (T)af.eps;
+    const T ss = (T)((c ? af.lr_u : af.lr_x) / bc1), sb = (T)sqrt_bc2;
+    const T g0 = (T)gx, g1 = (T)gy, p0 = (T)p64.x, p1 = (T)p64.y;
+    V2 mn, vn, pn;
+    mn.x = m.x + w1 * (g0 - m.x); mn.y = m.y + w1 * (g1 - m.y);
+    vn.x = v.x * b2 + w2 * (g0 * g0); vn.y = v.y * b2 + w2 * (g1 * g1);
+    pn.x = p0 - ss * (mn.x / ((T)sqrt((double)vn.x) / sb + eps));
+    pn.y = p1 - ss * (mn.y / ((T)sqrt((double)vn.y) / sb + eps));
+    *mp = mn; *vp = vn;
+    reinterpret_cast<V2 *>(c ? af.u_out : af.x_out)[row] = pn;
+}
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
 // L2).  Map block -> tile so that each XCD walks one contiguous run of the

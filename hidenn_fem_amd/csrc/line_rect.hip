@@ -264,8 +264,9 @@ struct Hat {   // one axis of the hat-function pair, models.py:84-85
     int e;
     double N1, N2, h, raw, ui, uj;
 };
-// T = row type of the caller's arrays (double, or float for the reference's default dtype: widened on load, rounded once on
-// store / atomic add, fp64 arithmetic in between -- as the TRI3 fp32-row kernel does)
+// T = row type of the caller's arrays (double, or float for the reference's default dtype: widened on load, fp64 arithmetic
+// in between, per-point outputs rounded once on store; ACCUMULATED outputs -- grid / nodal-value gradients, the loss --
+// are atomics of type T, so a float caller gets one rounding per contribution, in varying order)
 template <typename T>
 __device__ __forceinline__ Hat hat_eval(const T *__restrict__ grid, int n, double x) {
     Hat t;

@@ -6,8 +6,9 @@
 // plain sum over elements, /root/reference/src/loss.py:85-88).
 //
 // RCCL is bound at run time (dlopen): the library loads and every other entry point works where RCCL is absent;
-// hfem_mg_* then return an error.  Preference: a librccl already in the process (the one torch.distributed loaded),
-// then the path given to hfem_mg_load / $HFEM_RCCL_PATH, then the ROCm installation.  No HIP kernel in this file.
+// hfem_mg_* then return an error.  Load order (ensure_loaded): the explicit path given to hfem_mg_load (hidenn_fem_amd
+// passes the librccl.so bundled with torch, so that both use ONE RCCL instance), then $HFEM_RCCL_PATH, then a librccl
+// already mapped into the process (RTLD_NOLOAD), then the ROCm installation.  No HIP kernel in this file.
 #include <dlfcn.h>
 
 #include <cstdlib>

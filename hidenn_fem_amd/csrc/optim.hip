@@ -131,6 +131,64 @@ __global__ __launch_bounds__(256) void adam_step_rows2_dev_kernel(double2 *__res
     m[r] = mi; v[r] = vi; p[r] = pi;
 }
 
+// ---- multi-tensor form: ONE launch for every parameter tensor of the optimiser.  table[t] (device memory) describes tensor
+// t and the first block that works on it; block b finds its tensor by a scan of the (few) table entries and updates one
+// contiguous chunk of 16-byte vectors.  The step count: step_dev[0] holds the number of COMPLETED steps, every block reads
+// it when it starts and uses step_dev[0] + step_offset; when step_dev is given the LAST block to finish (ticket counter)
+// bumps it -- strictly after every block's read, so no separate counter launch and no race.
+template <typename T>
+__device__ __forceinline__ void adam_chunk(const hfem_adam_tensor &e, int64_t chunk_vecs, int64_t b, double step_size,
+                                           double sqrt_bc2) {
+    typedef typename AdamVec<T>::type V;
+    constexpr int N = AdamVec<T>::N;
+    T *p = (T *)e.p, *m = (T *)e.m, *v = (T *)e.v;
+    const T *g = (const T *)e.g;
+    const double w1 = 1.0 - e.beta1, w2 = 1.0 - e.beta2;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int64_t nv = aligned ? e.n / N : 0;
+    V *pv = reinterpret_cast<V *>(p), *mv = reinterpret_cast<V *>(m), *vv = reinterpret_cast<V *>(v);
+    const V *gv = reinterpret_cast<const V *>(g);
+    const int64_t hi = min(nv, (b + 1) * chunk_vecs);
+    for (int64_t i = b * chunk_vecs + threadIdx.x; i < hi; i += 256) {
+        V P = pv[i], M = mv[i], Vv = vv[i];
+        const V G = gv[i];
+        T *pp = reinterpret_cast<T *>(&P), *mm = reinterpret_cast<T *>(&M), *vx = reinterpret_cast<T *>(&Vv);
+        const T *gg = reinterpret_cast<const T *>(&G);
+#pragma unroll
+        for (int k = 0; k < N; ++k) adam_one<T>(pp[k], gg[k], mm[k], vx[k], w1, e.beta2, w2, step_size, sqrt_bc2, e.eps);
+        mv[i] = M;
+        vv[i] = Vv;
+        pv[i] = P;
+    }
+    if (b == 0)                                             // tail / unaligned views: the tensor's first block
+        for (int64_t t = nv * N + threadIdx.x; t < e.n; t += 256)
+            adam_one<T>(p[t], g[t], m[t], v[t], w1, e.beta2, w2, step_size, sqrt_bc2, e.eps);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const hfem_adam_tensor *__restrict__ table, int n_tensors,
+                                                             int64_t chunk_vecs, int64_t *__restrict__ step_dev,
+                                                             int64_t step_offset, int32_t *__restrict__ ticket) {
+    int t = 0;
+    while (t + 1 < n_tensors && (int)blockIdx.x >= table[t + 1].block_begin) ++t;
+    const hfem_adam_tensor e = table[t];
+    const double step = (double)((step_dev ? step_dev[0] : 0) + step_offset);
+    const double bc1 = 1.0 - pow(e.beta1, step), bc2 = 1.0 - pow(e.beta2, step);
+    const int64_t b = (int64_t)blockIdx.x - e.block_begin;
+    if (e.dtype == 0) adam_chunk<double>(e, chunk_vecs, b, e.lr / bc1, sqrt(bc2));
+    else adam_chunk<float>(e, chunk_vecs, b, e.lr / bc1, sqrt(bc2));
+    if (step_dev) {
+        __syncthreads();                                    // every thread of this block has read the step
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {   // the last block to finish: all blocks have read it
+                ticket[0] = 0;
+                step_dev[0] += 1;
+            }
+        }
+    }
+}
+
 __global__ void counter_add_kernel(int64_t *c, int64_t inc) { c[0] += inc; }
 
 // step += 1; bc = {1 - b1^step, sqrt(1 - b2^step)}: the scalars of one Adam step, for kernels that fuse the update
@@ -218,6 +276,20 @@ extern "C" int hfem_adam_step_rows2_dev(int device, double *px, const double *gx
                        (const double2 *)gu, (double2 *)mu, (double2 *)vu, rows_u, n_u, lr_u, beta1, beta2, eps, step_dev,
                        step_offset);
     return launch_status("hfem_adam_step_rows2_dev");
+}
+
+extern "C" int hfem_adam_multi_dev(int device, const hfem_adam_tensor *table_dev, int32_t n_tensors, int32_t n_blocks,
+                                   int64_t chunk_vecs, int64_t *step_dev, int64_t step_offset, int32_t *ticket_dev,
+                                   void *stream) {
+    HFEM_ARG_CHECK(n_tensors >= 0 && n_blocks >= 0 && chunk_vecs >= 1, "bad sizes");
+    if (n_tensors == 0 || n_blocks == 0) return 0;
+    HFEM_ARG_CHECK(table_dev, "null table");
+    HFEM_ARG_CHECK(!step_dev || ticket_dev, "a device step counter needs a ticket counter");
+    HFEM_ARG_CHECK(step_dev || step_offset >= 1, "need a device step counter or a host step >= 1");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n_tensors,
+                       chunk_vecs, step_dev, step_offset, ticket_dev);
+    return launch_status("hfem_adam_multi_dev");
 }
 
 extern "C" int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream) {

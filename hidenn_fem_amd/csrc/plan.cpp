@@ -25,6 +25,7 @@
 // energy depends on it): pairing only chooses WHICH elements share a slot.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <unordered_map>
 #include <cstring>
 #include <limits>
@@ -65,22 +66,22 @@ inline uint32_t hilbert16(uint32_t x, uint32_t y) {
     return d;
 }
 
-static int g_curve = 1;   // 0 Morton, 1 Hilbert
+static std::atomic<int> g_curve{1};   // 0 Morton, 1 Hilbert (process-wide defaults below: atomics, read once per plan build)
 void set_locality_curve(int c) { g_curve = c; }
 // Tile cuts snap to coarse cells of the locality curve: when the node cap ends a tile, the cut moves back (by at most
 // g_snap percent of the tile) to the boundary between the two consecutive elements whose curve codes differ in the highest
 // bit -- the edge of the coarsest curve cell in reach.  Tiles become unions of whole cells (straight, axis-aligned sides)
 // instead of ending mid-cell on a staircase: fewer halo elements and nodes per tile.  0 = off.
-static int g_hw_window = 2;       // rows examined as partner of a row (pack_slot_halfwaves); > 100: exhaustive split search (lab)
-static int g_halfwave_all = 1;    // also for one-element-per-slot TRI3 / QUAD4 records (plan_read_pack >= 1000: paired plans only)
-static int g_halfwave_pack = 1;   // paired slots packed for ds_read_b128's lane groups too (pack_slot_halfwaves); 0: atomics only
+static std::atomic<int> g_hw_window{2};       // rows examined as partner of a row (pack_slot_halfwaves); > 100: exhaustive split search (lab)
+static std::atomic<int> g_halfwave_all{1};    // also for one-element-per-slot TRI3 / QUAD4 records (plan_read_pack >= 1000: paired plans only)
+static std::atomic<int> g_halfwave_pack{1};   // paired slots packed for ds_read_b128's lane groups too (pack_slot_halfwaves); 0: atomics only
 void set_halfwave_pack(int v) {
     g_halfwave_all = v < 1000;
     if (v >= 1000) v -= 1000;
     g_halfwave_pack = v ? 1 : 0;
     if (v > 1) g_hw_window = v;
 }
-static int g_snap = 0;
+static std::atomic<int> g_snap{0};
 void set_tile_snap(int percent) { g_snap = percent < 0 ? 0 : (percent > 50 ? 50 : percent); }
 static thread_local std::vector<uint32_t> g_codes;   // curve code of every element, in sorted order (empty: no coordinates)
 
@@ -261,8 +262,9 @@ void pack_slot_groups(const std::vector<std::array<int32_t, 4>> &items, int32_t 
 void pack_slot_halfwaves(const std::vector<std::array<int32_t, 4>> &items, int32_t n_owned, std::vector<int32_t> &out) {
     static const int kCellLane[4][8] = {{0, 1, 2, 3, 12, 13, 14, 15}, {4, 5, 6, 7, 8, 9, 10, 11},
                                         {20, 21, 22, 23, 24, 25, 26, 27}, {16, 17, 18, 19, 28, 29, 30, 31}};
-    const int kPartnerWindow = g_hw_window > 100 ? g_hw_window - 100 : g_hw_window;
-    const bool kFull = g_hw_window > 100;                 // exhaustive split search + local search (slow: lab comparison only)
+    const int hw_window = g_hw_window.load();
+    const int kPartnerWindow = hw_window > 100 ? hw_window - 100 : hw_window;
+    const bool kFull = hw_window > 100;                 // exhaustive split search + local search (slow: lab comparison only)
     // step 1: atomic rows -- groups of 16 slots whose owned ids are distinct mod 16 at every position (pack_slot_groups)
     std::vector<int32_t> o;
     pack_slot_groups(items, n_owned, o);
@@ -622,6 +624,18 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
     P.elem_gid.reserve(ne + ne / 4);
     P.node_src.reserve(2 * (nn + nn / 3));
 
+    // Local node order inside a tile.  By node id -- unless the caller stores its parameter rows in ANOTHER order than it
+    // numbers its nodes (x_src not increasing over the free nodes: a model that keeps a badly numbered mesh's rows along the
+    // locality curve, hidenn_fem_amd/models.py reorder="auto"): then by ROW, so that the 64 lanes of a gather instruction
+    // read neighbouring rows (a few 128-byte lines per wave instead of one line per lane).  Fixed rows go last.
+    bool by_row = false;
+    if (x_src) {
+        int32_t last = -1;
+        for (int64_t n = 0; n < nn && !by_row; ++n)
+            if (x_src[n] >= 0) { by_row = x_src[n] < last; last = x_src[n]; }
+    }
+    auto row_key = [&](int32_t n) -> int64_t { return x_src[n] >= 0 ? (int64_t)x_src[n] : ((int64_t)1 << 32) + (int64_t)(~x_src[n]); };
+    auto by_row_less = [&](int32_t a, int32_t b) { return row_key(a) < row_key(b); };
     std::vector<int32_t> stamp_e(ne, -1), stamp_n(nn, -1), lid(nn, 0);
     std::vector<int32_t> first_use_stamp(elem_order == 4 ? nn : 0, -1), first_use(elem_order == 4 ? nn : 0, 0);
     std::vector<int32_t> telems, halo, own_order_buf;
@@ -647,6 +661,7 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
         const bool chunked = elem_order == 4 && npe == 3;
         std::vector<int32_t> &own_order = own_order_buf;       // this tile's owned nodes in local-id order
         own_order.assign(own.begin() + o0, own.begin() + o1);
+        if (by_row) std::sort(own_order.begin(), own_order.end(), by_row_less);
         int32_t nloc = 0;
         for (int32_t n : own_order) { stamp_n[n] = t; lid[n] = nloc++; }
         d.n_owned = nloc;
@@ -660,7 +675,8 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
                 const int32_t n = (int32_t)edges[2 * (int64_t)tedge[i] + k];
                 if (stamp_n[n] != t) { stamp_n[n] = t; halo.push_back(n); }
             }
-        std::sort(halo.begin(), halo.end());
+        if (by_row) std::sort(halo.begin(), halo.end(), by_row_less);
+        else std::sort(halo.begin(), halo.end());
         if (d.n_owned + (int32_t)halo.size() > kMaxLocal) return 1;
         if (shards > 1)
             for (int32_t n : halo)

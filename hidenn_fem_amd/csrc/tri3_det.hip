@@ -110,9 +110,26 @@ static int det_upload(T **dst, const std::vector<T> &src, size_t min_count = 1) 
     return 0;
 }
 
-static int det_prepare(hfem_plan *plan) {
+static int det_prepare_impl(hfem_plan *plan);
+
+// First deterministic launch on a plan: build and upload the node -> element adjacency (hipMalloc + synchronous copies).
+// Never inside a stream capture (the copies would invalidate it): a capturing caller gets an error and runs ONE eager
+// deterministic evaluation first.  A failure part-way releases what was allocated.
+static int det_prepare(hfem_plan *plan, hipStream_t s) {
+    if (plan->det.ready) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("HFEM_FLAG_DETERMINISTIC: the first deterministic launch on a plan allocates and uploads its adjacency and "
+                  "cannot run inside a hipGraph capture; evaluate once eagerly before capturing");
+        return -1;
+    }
+    const int rc = det_prepare_impl(plan);
+    if (rc) free_tri3_det(plan);
+    return rc;
+}
+
+static int det_prepare_impl(hfem_plan *plan) {
     hfem_plan::Det &D = plan->det;
-    if (D.ready) return 0;
     const HostPlan &h = plan->host;
     HFEM_ARG_CHECK(h.npe == 3, "deterministic path: TRI3 plans only");
     const int64_t ne = h.ne, nn = h.nn, ned = h.ned;
@@ -153,7 +170,7 @@ void free_tri3_det(hfem_plan *plan) {
 int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed, const double *u_free,
                     const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,
                     double *gx_free, double *gu_free, int skip_edges, bool phys, hipStream_t s) {
-    if (int rc = det_prepare(plan)) return rc;
+    if (int rc = det_prepare(plan, s)) return rc;
     const hfem_plan::Det &D = plan->det;
     const HostPlan &h = plan->host;
     const int32_t nn = (int32_t)h.nn, ne = (int32_t)h.ne, ned = skip_edges ? 0 : (int32_t)h.ned;

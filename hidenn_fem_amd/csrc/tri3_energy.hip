@@ -381,29 +381,13 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         // OTHER parameter buffer (tiles still gathering this launch must keep seeing the old one: ping-pong), and the
         // gradient never goes to memory.  Arithmetic = optim.hip's adam_step_dev_kernel, operation for operation.
         const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];   // 1 - b1^step, sqrt(1 - b2^step): hfem_adam_prep (no pow() in here)
-        const double w1 = 1.0 - af.b1, w2 = 1.0 - af.b2;
 #pragma unroll
         for (int j = 0; j < NPT; ++j) {
             const int l = tid + j * BLOCK;
             if (l < n_owned) {
                 const int2 rows = src[l];                  // re-read (L2 hit) rather than kept: the element stage has no VGPR to spare
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {              // c = 0: coordinates, 1: displacements
-                    const int row = c ? rows.y : rows.x;
-                    if (row < 0) continue;
-                    const double2 g = c ? make_double2(acc2[l], acc3[l]) : make_double2(acc0[l], acc1[l]);
-                    const double2 p = c ? nd_uv[l] : nd_xy[l];
-                    double2 *mp = (c ? af.mu : af.mx) + row, *vp = (c ? af.vu : af.vx) + row;
-                    const double2 m = *mp, v = *vp;
-                    const double ss = (c ? af.lr_u : af.lr_x) / bc1;
-                    double2 mn, vn, pn;
-                    mn.x = m.x + w1 * (g.x - m.x); mn.y = m.y + w1 * (g.y - m.y);
-                    vn.x = v.x * af.b2 + w2 * (g.x * g.x); vn.y = v.y * af.b2 + w2 * (g.y * g.y);
-                    pn.x = p.x - ss * (mn.x / (sqrt(vn.x) / sqrt_bc2 + af.eps));
-                    pn.y = p.y - ss * (mn.y / (sqrt(vn.y) / sqrt_bc2 + af.eps));
-                    *mp = mn; *vp = vn;
-                    (c ? af.u_out : af.x_out)[row] = pn;
-                }
+                if (rows.x >= 0) adam_fused_row<V2>(af, 0, rows.x, acc0[l], acc1[l], nd_xy[l], bc1, sqrt_bc2);
+                if (rows.y >= 0) adam_fused_row<V2>(af, 1, rows.y, acc2[l], acc3[l], nd_uv[l], bc1, sqrt_bc2);
             }
         }
     } else {
@@ -1268,7 +1252,23 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
                                           double *m_x, double *v_x, double *m_u, double *v_u, double lr_x, double lr_u,
                                           double beta1, double beta2, double eps, const double *bc_dev,
                                           double *loss_out, int32_t flags, void *stream) {
+    return hfem_tri3_energy_adam_step_ex(plan, 0, x_free, x_fixed, u_free, u_fixed, mat, W, nullptr, T_edge, Tconst, x_out,
+                                         u_out, m_x, v_x, m_u, v_u, lr_x, lr_u, beta1, beta2, eps, bc_dev, loss_out, flags,
+                                         stream);
+}
+
+// General form: dtype 0 = fp64 rows, 1 = fp32 rows (parameters, fixed rows, moments and new rows all float: an fp32 model,
+// the reference's default dtype, trains in one launch per iteration without widening copies; element arithmetic and the
+// loss stay fp64, the update is torch's fp32 arithmetic); Bk = the body-force table of hfem_tri3_energy_plan (NULL / zeros:
+// none).
+extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, const void *x_free, const void *x_fixed,
+                                             const void *u_free, const void *u_fixed, const double mat[4], double W,
+                                             const double Bk[6], const double *T_edge, const double Tconst[4], void *x_out,
+                                             void *u_out, void *m_x, void *v_x, void *m_u, void *v_u, double lr_x,
+                                             double lr_u, double beta1, double beta2, double eps, const double *bc_dev,
+                                             double *loss_out, int32_t flags, void *stream) {
     HFEM_ARG_CHECK(plan && mat && loss_out && x_free && u_free, "null pointer");
+    HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64 rows, 1 = fp32 rows");
     HFEM_ARG_CHECK(x_out && u_out && m_x && v_x && m_u && v_u && bc_dev, "null optimiser buffer");
     HFEM_ARG_CHECK(x_out != x_free && u_out != u_free, "x_out / u_out must not alias the input parameters (ping-pong)");
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
@@ -1278,7 +1278,9 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
     HFEM_ARG_CHECK(h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
                    "fused Adam step: needs tiles of <= 1024 nodes / 2048 element slots");
     HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_GX | HFEM_FLAG_NO_GU)), "fused Adam step updates both parameter tensors");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC)), "fused Adam step: reference convention, atomic accumulation");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SAME_BANK)), "fused Adam step: reference convention, atomic accumulation, whole plan");
+    bool hasb = false;
+    for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
     if (int rc = use_device(plan->device)) return rc;
     PlanLock lock(plan);
     hipStream_t s = (hipStream_t)stream;
@@ -1288,6 +1290,7 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
     HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
     HFEM_ARG_CHECK(!lag_consume || plan->prev_stream == stream,
                    "HFEM_FLAG_SUM_PREVIOUS: the previous unsummed launch went to another stream (one plan = one stream)");
+    HFEM_ARG_CHECK(!lag_consume || !hasb, "HFEM_FLAG_SUM_PREVIOUS: zero body force only");
     const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
     double *pbase = plan->d_partials + (size_t)wbank * nt;
     LagSum lag;
@@ -1298,13 +1301,13 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
     }
     if (n > 0) {
         AdamFuse af;
-        af.x_out = (double2 *)x_out; af.u_out = (double2 *)u_out;
-        af.mx = (double2 *)m_x; af.vx = (double2 *)v_x; af.mu = (double2 *)m_u; af.vu = (double2 *)v_u;
+        af.x_out = x_out; af.u_out = u_out;
+        af.mx = m_x; af.vx = v_x; af.mu = m_u; af.vu = v_u;
         af.bc = bc_dev; af.lr_x = lr_x; af.lr_u = lr_u; af.b1 = beta1; af.b2 = beta2; af.eps = eps;
         Tri3Launch A;
         A.pd = plan_dev(plan); A.tile_begin = 0;
         A.x_free = x_free; A.x_fixed = x_fixed; A.u_free = u_free; A.u_fixed = u_fixed;
-        A.k = make_consts(mat, W, nullptr); A.T_edge = (const double4 *)T_edge;
+        A.k = make_consts(mat, W, hasb ? Bk : nullptr); A.T_edge = (const double4 *)T_edge;
         A.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
         A.partials = pbase;
         A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
@@ -1315,10 +1318,22 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
             P.grid = grid; P.tile_begin = 0;
             P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
             P.k = A.k; P.T_edge = A.T_edge; P.tc = A.tc; P.partials = pbase; P.skip_edges = A.skip_edges; P.s = s;
-            HFEM_ARG_CHECK(launch_tri3_pair(plan, P, 3, false, false, lag, af) == 1,
+            HFEM_ARG_CHECK(launch_tri3_pair(plan, P, dtype == 0 ? 3 : 4, hasb, false, lag, af) == 1,
                            "paired plan: tile shape outside the pair kernel's instances");
-        } else if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, double2, 0, true, false>(A, grid, af, lag);
-        else launch_fast<512, 2, 4, false, 16, double2, 0, true, false>(A, grid, af, lag);
+        } else {
+            // one element per slot (meshes whose elements do not pair): one general instance per row type and force
+            const bool e3 = h.max_elems <= 3 * 512;
+#define HFEM_ADAM_FAST(HB, V)                                                                            \
+    {                                                                                                    \
+        if (e3) launch_fast<512, 2, 3, HB, 16, V, 0, true, false>(A, grid, af, lag);                     \
+        else launch_fast<512, 2, 4, HB, 16, V, 0, true, false>(A, grid, af, lag);                        \
+    }
+            if (dtype == 0 && !hasb) HFEM_ADAM_FAST(false, double2)
+            else if (dtype == 0) HFEM_ADAM_FAST(true, double2)
+            else if (!hasb) HFEM_ADAM_FAST(false, float2)
+            else HFEM_ADAM_FAST(true, float2)
+#undef HFEM_ADAM_FAST
+        }
         if (int rc = launch_status("hfem_tri3_energy_adam_step")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) {

@@ -265,28 +265,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         // the NEW row to the OTHER parameter buffer (tiles still gathering must see the old one: ping-pong); the gradient
         // never goes to memory.  Arithmetic = optim.hip's adam_step_dev_kernel, operation for operation.
         const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];
-        const double w1 = 1.0 - af.b1, w2 = 1.0 - af.b2;
 #pragma unroll
         for (int j = 0; j < NPT; ++j) {
             const int l = tid + j * BLOCK;
             if (l < n_owned) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {              // c = 0: coordinates, 1: displacements
-                    const int row = c ? s[j].y : s[j].x;
-                    if (row < 0) continue;
-                    const double2 g = c ? make_double2(acc2[l], acc3[l]) : make_double2(acc0[l], acc1[l]);
-                    const double2 p = c ? nd_uv[l] : nd_xy[l];
-                    double2 *mp = (c ? af.mu : af.mx) + row, *vp = (c ? af.vu : af.vx) + row;
-                    const double2 m = *mp, v = *vp;
-                    const double ss = (c ? af.lr_u : af.lr_x) / bc1;
-                    double2 mn, vn, pn;
-                    mn.x = m.x + w1 * (g.x - m.x); mn.y = m.y + w1 * (g.y - m.y);
-                    vn.x = v.x * af.b2 + w2 * (g.x * g.x); vn.y = v.y * af.b2 + w2 * (g.y * g.y);
-                    pn.x = p.x - ss * (mn.x / (sqrt(vn.x) / sqrt_bc2 + af.eps));
-                    pn.y = p.y - ss * (mn.y / (sqrt(vn.y) / sqrt_bc2 + af.eps));
-                    *mp = mn; *vp = vn;
-                    (c ? af.u_out : af.x_out)[row] = pn;
-                }
+                if (s[j].x >= 0) adam_fused_row<V2>(af, 0, s[j].x, acc0[l], acc1[l], nd_xy[l], bc1, sqrt_bc2);
+                if (s[j].y >= 0) adam_fused_row<V2>(af, 1, s[j].y, acc2[l], acc3[l], nd_uv[l], bc1, sqrt_bc2);
             }
         }
     } else {
@@ -346,7 +330,7 @@ static void launch_pair_inst(const PairLaunch &A, const LagSum &lag, const AdamF
 
 // Launch on a paired plan: picks the instance that holds the plan's tile shape.  1 = launched, 0 = none does.
 // mode: 0 fp64 reference convention (zero body force), 1 general fp64 (body force and / or physical convention),
-//       2 fp32 rows, 3 fused Adam write-out.
+//       2 fp32 rows, 3 fused Adam write-out on fp64 rows, 4 the same on fp32 rows (3, 4: hasb selects the body-force instance).
 int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
                      const AdamFuse &af) {
     const HostPlan &h = plan->host;
@@ -371,7 +355,16 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
             return 1;
         }
         if (mode == 2) { launch_pair_inst2<512, 2, 2, 0, false, false, float2, false, false>(A, lag, af); return 1; }
-        if (mode == 3) { launch_pair_inst2<512, 2, 2, 0, false, false, double2, true, false>(A, lag, af); return 1; }
+        if (mode == 3) {
+            if (hasb) launch_pair_inst2<512, 2, 2, 0, true, false, double2, true, false>(A, lag, af);
+            else launch_pair_inst2<512, 2, 2, 0, false, false, double2, true, false>(A, lag, af);
+            return 1;
+        }
+        if (mode == 4) {
+            if (hasb) launch_pair_inst2<512, 2, 2, 0, true, false, float2, true, false>(A, lag, af);
+            else launch_pair_inst2<512, 2, 2, 0, false, false, float2, true, false>(A, lag, af);
+            return 1;
+        }
         return 0;
     }
     const bool cc = h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN;   // (656 + 560) * 32 + 128 = 39040 B: four workgroups per CU
@@ -397,9 +390,14 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     } else if (mode == 2) {
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, false)
         HFEM_PAIR_EPT(4, 0, false, false, float2, false)
-    } else if (mode == 3) {
+    } else if (mode == 3) {                      // fused Adam write-out: fp64 rows
+        if (hasb) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, double2, true) HFEM_PAIR_EPT(4, 0, true, false, double2, true) }
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, true)
         HFEM_PAIR_EPT(4, 0, false, false, double2, true)
+    } else if (mode == 4) {                      // fused Adam write-out: fp32 rows (parameters, moments, new rows all float)
+        if (hasb) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, float2, true) HFEM_PAIR_EPT(4, 0, true, false, float2, true) }
+        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, true)
+        HFEM_PAIR_EPT(4, 0, false, false, float2, true)
     }
 #undef HFEM_PAIR_EPT
     return 0;

@@ -187,9 +187,11 @@ class EnergyLoss2D:
         # cached per (model, dtype, device): only host-side constants and the static loss tensor.  The fixed rows are
         # re-derived on every call -- `u_fixed_rows()` tracks `u_fixed._version`, `.to()` is a no-op when nothing
         # changed -- so `model.to(device)` or an in-place edit of `u_fixed` / `node_coords_fixed` is never stale.
-        key = (id(model), xf.dtype, xf.device)
+        import weakref
         cache = getattr(self, "_direct_cache", None)
-        if cache is None or cache[0] != key:
+        key = (xf.dtype, xf.device)
+        if cache is None or cache[0][0]() is not model or cache[0][1:] != key:     # weak reference: an id() can be reused
+            key = (weakref.ref(model),) + key
             _, Tconst = self._traction(model, None)
             dv = lambda v: (C.c_double * len(v))(*v)
             cache = self._direct_cache = (key, dv(self._mat), dv([0.0] * 6), dv(Tconst),

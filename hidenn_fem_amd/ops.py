@@ -3,9 +3,12 @@
 PyTorch tensors are only the container (device memory, streams, autograd
 bookkeeping); every number is produced by a hand-written gfx950 kernel.  All
 kernels compute in fp64.  fp32 callers (the reference's default dtype) use the
-float-row entry points where they exist -- the tiled TRI3 energy and every 1D /
-structured op: rows are widened on load and rounded once on store, no copies --
-and are widened on the way in / narrowed on the way out elsewhere.  Nothing here
+float-row entry points where they exist -- the tiled TRI3 energy (rows widened on
+load, gradient rows rounded ONCE on store) and every 1D / structured op (inputs
+widened on load, per-point outputs rounded once; their gradient accumulators and
+loss scalars are float atomics, i.e. one rounding per contribution, as torch's own
+fp32 index_add / sum would) -- no copies; elsewhere they are widened on the way in
+/ narrowed on the way out.  Nothing here
 runs on CPU tensors.
 """
 from __future__ import annotations
@@ -49,9 +52,10 @@ def _as(t, name, dtype):
 
 def _rows(*pairs):
     """-> (ABI suffix, working dtype, tensors) for the 1D / structured ops: when every tensor is float32 (the
-    reference's default dtype, src/models.py:36-40, 142) the float-row entry points (``*_f32``: widened on load,
-    rounded once on store, fp64 arithmetic inside) take them as they are -- no widening copies; any other mix goes
-    through the fp64 entry points."""
+    reference's default dtype, src/models.py:36-40, 142) the float-row entry points (``*_f32``: widened on load, fp64
+    arithmetic inside, per-point outputs rounded once on store; gradient accumulators and the loss are float atomics --
+    one rounding per contribution, order-dependent in the last bits) take them as they are -- no widening copies; any
+    other mix goes through the fp64 entry points."""
     ts = [t for t, _ in pairs if t is not None]
     if ts and all(t.dtype == F32 for t in ts):
         return "_f32", F32, [_as(t, name, F32) for t, name in pairs]

@@ -34,11 +34,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_dev = None
 
     def init_state(self):
-        """Allocate moments and the step counter of every parameter now (idempotent)."""
+        """Allocate moments, the step counter of every parameter and the pointer-table buffers now (idempotent)."""
+        dev = None
         for group in self.param_groups:
             for p in group["params"]:
                 if p.requires_grad:
                     self._state_of(p)
+                    dev = p.device if p.is_cuda else dev
+        if dev is not None:
+            self._alloc_tables(dev, sum(len(g["params"]) for g in self.param_groups))
         return self
 
     def _state_of(self, p):
@@ -58,8 +62,13 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def load_state_dict(self, state_dict):
+        """The device step counter keeps its ADDRESS across a load (a hipGraph captured earlier reads and bumps that
+        very tensor): the loaded count is copied into it in place.  The moments are new tensors, as in torch -- a graph
+        captured before the load must be re-captured to see them."""
+        keep = self._step_dev
         super().load_state_dict(state_dict)
         self._step_dev = None
+        self._tabs = None
         for st in self.state.values():               # re-share one device counter (each entry was loaded as its own copy)
             if "step" not in st:
                 continue
@@ -68,10 +77,72 @@ class FusedAdam(torch.optim.Optimizer):
                     dev = st["exp_avg"].device
                     st["step"] = torch.full((1,), int(st["step"]), dtype=torch.int64, device=dev)
                 if self._step_dev is None:
-                    self._step_dev = st["step"].to(torch.int64).reshape(1).contiguous()
+                    loaded = st["step"].to(torch.int64).reshape(1)
+                    if keep is not None and keep.device == loaded.device:
+                        keep.copy_(loaded)
+                        self._step_dev = keep
+                    else:
+                        self._step_dev = loaded.contiguous()
                 st["step"] = self._step_dev
             elif torch.is_tensor(st["step"]):
                 st["step"] = int(st["step"].item())
+
+    # ---- multi-tensor launch: one device table for all parameter tensors.  The table is rebuilt only when a pointer or a
+    #      hyper-parameter changes; its upload is an asynchronous copy from a PINNED host buffer allocated by init_state(),
+    #      so it is legal inside a hipGraph capture too (autograd allocates the .grad tensors of a warm-up-less capture
+    #      during the capture: their addresses are not known before) -- the copy node simply replays with the graph.
+    _TAB_SLOTS = 4
+
+    def _alloc_tables(self, dev, n_params):
+        if getattr(self, "_tabs", None) is not None and self._tabs["n"] >= n_params and self._tabs["dev"] == dev:
+            return
+        import ctypes as C
+        nbytes = max(1, n_params) * C.sizeof(_lib.AdamTensor)
+        self._tabs = dict(n=n_params, dev=dev, used={},
+                          free=[(torch.zeros(nbytes, dtype=torch.uint8).pin_memory(), torch.zeros(nbytes, dtype=torch.uint8, device=dev))
+                                for _ in range(self._TAB_SLOTS)])
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def _table(self, todo):
+        import ctypes as C
+        key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                     float(group["lr"]), tuple(group["betas"]), float(group["eps"]), p.dtype) for group, p, g, st in todo)
+        dev = todo[0][1].device
+        capturing = torch.cuda.is_current_stream_capturing()
+        tabs = getattr(self, "_tabs", None)
+        if tabs is None or tabs["dev"] != dev or tabs["n"] < len(todo):
+            if capturing:
+                raise RuntimeError("FusedAdam: call init_state() before capturing (the pointer table's buffers cannot be "
+                                   "allocated inside a hipGraph capture)")
+            self._alloc_tables(dev, sum(len(g["params"]) for g in self.param_groups))
+            tabs = self._tabs
+        if key in tabs["used"]:
+            return tabs["used"][key]
+        if not tabs["free"]:
+            if capturing:
+                raise RuntimeError("FusedAdam: more than %d distinct (parameter, gradient) address sets inside one hipGraph "
+                                   "capture" % self._TAB_SLOTS)
+            torch.cuda.current_stream(dev).synchronize()       # no table upload is in flight: recycle every slot
+            tabs["free"] = [v[4] for v in tabs["used"].values()]
+            tabs["used"] = {}
+        host, tab_dev = tabs["free"].pop()
+        total_vecs = sum((p.numel() + (1 if p.dtype == torch.float64 else 3)) // (2 if p.dtype == torch.float64 else 4)
+                         for _, p, _, _ in todo)
+        chunk = max(256, -(-total_vecs // 4096))                   # <= ~4096 blocks, each a contiguous run of 16-byte vectors
+        chunk = -(-chunk // 256) * 256
+        tab = (_lib.AdamTensor * len(todo))()
+        blk = 0
+        for e, (group, p, g, st) in zip(tab, todo):
+            nvec = p.numel() // (2 if p.dtype == torch.float64 else 4)
+            e.p, e.g, e.m, e.v, e.n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            e.lr, (e.beta1, e.beta2), e.eps = float(group["lr"]), group["betas"], float(group["eps"])
+            e.dtype, e.block_begin = (0 if p.dtype == torch.float64 else 1), blk
+            blk += max(1, -(-nvec // chunk))
+        raw = bytes(tab)
+        host[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        tab_dev.copy_(host, non_blocking=True)                     # stream-ordered before the launch that reads it
+        tabs["used"][key] = (tab_dev, len(todo), blk, chunk, (host, tab_dev))
+        return tabs["used"][key]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -88,16 +159,33 @@ class FusedAdam(torch.optim.Optimizer):
                 require_gpu_tensor(p.data, "parameter", dtype=None)
                 if p.dtype not in (torch.float64, torch.float32):
                     raise RuntimeError("FusedAdam supports fp64 / fp32 parameters")
-                todo.append((group, p, self._state_of(p)))
-        if self.capturable and todo:
-            p0 = todo[0][1]
-            check(L.hfem_counter_add(dev_index(p0.device), ptr(self._step_dev), 1, stream_ptr(p0.device)),
-                  "hfem_counter_add")
-        for group, p, st in todo:
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if g.dtype != p.dtype:
+                    g = g.to(p.dtype)
+                todo.append((group, p, g, self._state_of(p)))
+        if not todo:
+            return loss
+        dev = todo[0][1].device
+        one_device = all(p.device == dev for _, p, _, _ in todo)
+        if self.capturable and one_device:
+            # ONE launch: every tensor, and the step counter bumped by the last block to finish (no hfem_counter_add)
+            tab_dev, n, blocks, chunk, _ = self._table(todo)
+            check(L.hfem_adam_multi_dev(dev_index(dev), ptr(tab_dev), n, blocks, chunk, ptr(self._step_dev), 1,
+                                        ptr(self._ticket), stream_ptr(dev)), "hfem_adam_multi_dev")
+            return loss
+        steps = {int(st["step"]) for _, _, _, st in todo} if not self.capturable else set()
+        if not self.capturable and one_device and len(steps) == 1 and len(todo) > 1:
+            # host-side step count shared by all tensors (the usual case): the same single launch
+            for _, _, _, st in todo:
+                st["step"] += 1
+            tab_dev, n, blocks, chunk, _ = self._table(todo)
+            check(L.hfem_adam_multi_dev(dev_index(dev), ptr(tab_dev), n, blocks, chunk, None, steps.pop() + 1, None,
+                                        stream_ptr(dev)), "hfem_adam_multi_dev")
+            return loss
+        if self.capturable:
+            check(L.hfem_counter_add(dev_index(dev), ptr(self._step_dev), 1, stream_ptr(dev)), "hfem_counter_add")
+        for group, p, g, st in todo:
             b1, b2 = group["betas"]
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            if g.dtype != p.dtype:
-                g = g.to(p.dtype)
             if self.capturable:
                 check(L.hfem_adam_step_dev(dev_index(p.device), ptr(p.data), ptr(g), ptr(st["exp_avg"]),
                                            ptr(st["exp_avg_sq"]), p.numel(), 0 if p.dtype == torch.float64 else 1,
@@ -236,16 +324,22 @@ class EnergyAdamStep:
     The new parameter rows go to a second buffer (tiles that are still gathering must see the old ones); ``step()``
     swaps ``param.data`` between the two after every launch.  Same arithmetic as ``FusedAdam`` / ``torch.optim.Adam``
     (betas, eps, bias correction; one learning rate per tensor: ``lr_x`` for ``node_coords_free``, ``lr_u`` for
-    ``u_free``).  fp64 TRI3 models, default forces, whole mesh on one GPU.  Capture-safe: use
+    ``u_free``).  TRI3 models in fp64 or fp32, optional body force, constant traction, whole mesh on one GPU.  Capture-safe: use
     ``GraphedTraining(trainer.step, None, steps_per_replay=<even>, direct=True)``."""
 
-    def __init__(self, model, loss_fn, lr_x, lr_u, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, loss_fn, lr_x, lr_u, betas=(0.9, 0.999), eps=1e-8, b_force=None):
+        """``b_force``: body force callable as ``EnergyLoss2D.__call__`` takes it (evaluated at the reference Gauss points,
+        src/loss.py:60,80) -- its table is fixed at construction.  fp64 and fp32 models (an fp32 model keeps fp32
+        parameters and moments, as ``torch.optim.Adam`` would; element arithmetic and the loss are fp64)."""
         import ctypes as C
         if getattr(model, "nodes_per_element", 3) != 3:
             raise NotImplementedError("EnergyAdamStep: TRI3 models")
         xf, uf = model.node_coords_free, model.u_free
-        require_gpu_tensor(xf.data, "node_coords_free", torch.float64)
-        require_gpu_tensor(uf.data, "u_free", torch.float64)
+        if xf.dtype != uf.dtype or xf.dtype not in (torch.float64, torch.float32):
+            raise RuntimeError("EnergyAdamStep: parameters must both be fp64 or both fp32")
+        require_gpu_tensor(xf.data, "node_coords_free", xf.dtype)
+        require_gpu_tensor(uf.data, "u_free", uf.dtype)
+        self._dtype = 0 if xf.dtype == torch.float64 else 1
         self.model, self.loss_fn = model, loss_fn
         self.plan = model.tile_plan(loss_fn.tile_elems)
         self.lr_x, self.lr_u, self.betas, self.eps = float(lr_x), float(lr_u), (float(betas[0]), float(betas[1])), float(eps)
@@ -260,8 +354,9 @@ class EnergyAdamStep:
         _, Tconst = loss_fn._traction(model, None)
         dv = lambda v: (C.c_double * len(v))(*v)
         self._mat, self._Tc = dv(loss_fn._mat), dv(Tconst)
-        self._xfix = model.node_coords_fixed.to(torch.float64).contiguous()
-        self._ufix = model.u_fixed_rows().to(torch.float64).contiguous()
+        self._Bk = dv(loss_fn._body_table(b_force)) if b_force is not None else None
+        self._xfix = model.node_coords_fixed.to(xf.dtype).contiguous()
+        self._ufix = model.u_fixed_rows().to(xf.dtype).contiguous()
         self._flags = 0 if model.N_edges else 4          # HFEM_FLAG_NO_EDGES
         self.k = 0
 
@@ -273,6 +368,8 @@ class EnergyAdamStep:
         """``step()`` whose returned tensor holds the loss of the PREVIOUS iteration of the sequence (nothing new on the
         first); ``flush_loss()`` delivers the last one.  Use as ``GraphedTraining(tr.step_lagged, None, ...,
         direct=True, begin=tr.begin_lagged, end=tr.flush_loss)``."""
+        if self._Bk is not None:
+            raise NotImplementedError("EnergyAdamStep.step_lagged: zero body force only (use step())")
         flags = 8 | (32 if getattr(self, "_lag_on", False) else 0)
         self._lag_on = True
         return self.step(_extra_flags=flags)
@@ -290,9 +387,9 @@ class EnergyAdamStep:
         i, o = self.k & 1, (self.k + 1) & 1
         sp = stream_ptr(dev)
         check(L.hfem_adam_prep(dev_index(dev), ptr(st["step"]), self.betas[0], self.betas[1], ptr(self._bc), sp), "hfem_adam_prep")
-        check(L.hfem_tri3_energy_adam_step(
-            self.plan.handle, ptr(self._x[i]), ptr(self._xfix) if self._xfix.numel() else None, ptr(self._u[i]),
-            ptr(self._ufix) if self._ufix.numel() else None, self._mat, float(self.loss_fn._W), None, self._Tc,
+        check(L.hfem_tri3_energy_adam_step_ex(
+            self.plan.handle, self._dtype, ptr(self._x[i]), ptr(self._xfix) if self._xfix.numel() else None, ptr(self._u[i]),
+            ptr(self._ufix) if self._ufix.numel() else None, self._mat, float(self.loss_fn._W), self._Bk, None, self._Tc,
             ptr(self._x[o]), ptr(self._u[o]), ptr(st["exp_avg_x"]), ptr(st["exp_avg_sq_x"]), ptr(st["exp_avg_u"]),
             ptr(st["exp_avg_sq_u"]), self.lr_x, self.lr_u, self.betas[0], self.betas[1], self.eps, ptr(self._bc),
             ptr(self.loss), self._flags | _extra_flags, sp), "hfem_tri3_energy_adam_step")

@@ -70,7 +70,7 @@ int hfem_edge2_energy_atomic(int device, const double *X, const double *U,
  * that touch its owned nodes, with node data staged in LDS and gradients
  * accumulated in LDS, so each gradient row is written exactly once with a plain
  * store (no global atomics, no zero fill).  TRI3 plans whose elements pair up
- * along shared fan edges (>= 90 % of them: structured splits, Delaunay meshes)
+ * along shared fan edges (about 62 % of them or more: structured splits with fixed or random diagonals)
  * store two elements per slot, A = (n,b,c) and B = (n,c,d), each in its own
  * local node order, and run the paired-slot kernel (16 instead of 24 LDS
  * atomics per pair); other meshes keep one element per slot.  The choice is
@@ -182,6 +182,16 @@ int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free, const doub
                                double *m_x, double *v_x, double *m_u, double *v_u, double lr_x, double lr_u,
                                double beta1, double beta2, double eps, const double *bc_dev,
                                double *loss_out, int32_t flags, void *stream);
+/* General form.  dtype: 0 = fp64 rows, 1 = fp32 rows -- x / u / fixed rows, moments and new rows all float (an fp32 model, the
+ * reference's default dtype src/loss.py:16, src/models.py:274, trains in one launch per iteration with no widening copy;
+ * element arithmetic and loss_out stay fp64, the update is torch.optim.Adam's fp32 arithmetic on the once-rounded
+ * gradient).  Bk [3][2]: body-force table as in hfem_tri3_energy_plan (NULL / zeros: none; not with SUM_PREVIOUS).      */
+int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, const void *x_free, const void *x_fixed,
+                                  const void *u_free, const void *u_fixed, const double mat[4], double W,
+                                  const double Bk[6], const double *T_edge, const double Tconst[4], void *x_out,
+                                  void *u_out, void *m_x, void *v_x, void *m_u, void *v_u, double lr_x, double lr_u,
+                                  double beta1, double beta2, double eps, const double *bc_dev, double *loss_out,
+                                  int32_t flags, void *stream);
 int hfem_adam_prep(int device, int64_t *step_dev, double beta1, double beta2, double *bc_dev, void *stream);
 /* loss_out[0] = sum, in tile order, of the per-tile partial energies that a launch with
  * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
@@ -198,12 +208,15 @@ int hfem_plan_set_span_stamps(hfem_plan *plan, uint64_t *dev_buf, int64_t n_slot
 /* Process-wide DEFAULTS (atomics) that hfem_plan_create captures into the plan it builds; changing one
  * never affects an existing plan, and launches on different plans may run from different threads (a plan
  * serialises its own launches with a mutex).  Product knobs: "tiled_block" (threads per tile of the
- * one-element-per-slot kernels: 256, 512, 1024), "store_policy", "tiled_fast", "fast_const_caps",
- * "quad4_const_caps", "plan_elem_order" (-1 auto, 3 one element per slot, 5 paired slots), "plan_node_cap",
- * "plan_chunk_cap", "plan_curve" (0 Morton, 1 Hilbert), "plan_snap" (tile cuts snap back to coarse curve cells by up
- * to that percentage of a tile; 0 = off), "plan_elem_order" 6 = paired slots chained into strips (optional), "plan_read_pack" (paired slots also packed against
- * ds_read_b128 bank conflicts: number of partner rows examined, default 2; 0 = off).  The ablation / stamp / pipeline knobs exist only in
- * the lab build (libhidenn_hip_lab.so, hfem_get_option("lab_build") == 1); the product library rejects them.
+ * one-element-per-slot kernels: 256, 512, 1024), "store_policy", "tiled_fast", "fast_const_caps", "quad4_const_caps",
+ * "plan_elem_order" (-1 auto, 3 one element per slot, 5 paired slots, 6 paired slots chained into strips), "plan_node_cap"
+ * (home nodes per tile; -1 = the shard-aware policy), "plan_shards" (ranks the tiles will be split over: tiles are sized
+ * for the elements PER RANK and every rank's boundary tiles come first in its range), "plan_pair_block" (threads per tile
+ * of a paired plan: -1 auto, 256, 512), "plan_chunk_cap", "plan_curve" (0 Morton, 1 Hilbert), "plan_snap" (tile cuts snap
+ * back to coarse curve cells by up to that percentage of a tile; 0 = off), "plan_read_pack" (paired slots also packed
+ * against ds_read_b128 bank conflicts: number of partner rows examined, default 2; 0 = off).  The ablation / stamp /
+ * pipeline knobs exist only in the lab build (libhidenn_hip_lab.so, hfem_get_option("lab_build") == 1); the product
+ * library rejects them.
  * hfem_get_option returns the value or -1.                                     */
 int hfem_set_option(const char *name, int value);
 int hfem_get_option(const char *name);
@@ -290,6 +303,21 @@ int hfem_adam_step_dev(int device, void *p, const void *g, void *m, void *v, int
                        double lr, double beta1, double beta2, double eps, const int64_t *step_dev,
                        void *stream);
 int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream);
+/* Multi-tensor form: EVERY parameter tensor of the optimiser in ONE launch (the reference's models have 1-3 parameter
+ * tensors, examples/example4.py:54-64; per-tensor launches cost a kernel boundary each).  table_dev[n_tensors] lives in
+ * DEVICE memory; tensor t is updated by blocks [block_begin_t, block_begin_{t+1}) of 256 threads, block b of a tensor taking
+ * the 16-byte vectors [b * chunk_vecs, (b + 1) * chunk_vecs); n_blocks = total.  dtype per tensor: 0 fp64, 1 fp32.
+ * Step count: step_dev (may be NULL) holds the number of COMPLETED steps; the update uses step_dev[0] + step_offset
+ * (step_offset alone when step_dev is NULL: a host-side count).  With step_dev the kernel itself bumps the counter once
+ * all blocks have read it (ticket_dev: an int32 in device memory, zero before the first call) -- no hfem_counter_add.   */
+typedef struct hfem_adam_tensor {
+    void *p; const void *g; void *m; void *v;
+    int64_t n;
+    double lr, beta1, beta2, eps;
+    int32_t dtype, block_begin;
+} hfem_adam_tensor;
+int hfem_adam_multi_dev(int device, const hfem_adam_tensor *table_dev, int32_t n_tensors, int32_t n_blocks,
+                        int64_t chunk_vecs, int64_t *step_dev, int64_t step_offset, int32_t *ticket_dev, void *stream);
 
 /* ------------------------------------------------------------------ row gather/scatter
  * src/models.py:292-305 as index lists instead of bool-mask index_put (which
@@ -355,8 +383,8 @@ int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, 
  * then calls hfem_mg_comm_create.  The collectives only ENQUEUE on the caller's stream -- in stream order right
  * after the energy kernel -- so a whole multi-GPU step can be captured into one hipGraph.  fp64, sum.
  * hfem_mg_allgather: recv = [rank 0's `count` doubles | rank 1's | ...].  send == recv + rank * count is allowed.
- * RCCL is bound at run time (dlopen: the librccl already in the process, else hfem_mg_load(path) /
- * $HFEM_RCCL_PATH, else the ROCm installation); without it these calls return an error, the rest works.      */
+ * RCCL is bound at run time (dlopen, in this order: the path given to hfem_mg_load, $HFEM_RCCL_PATH, a librccl already
+ * mapped into the process, the ROCm installation); without it these calls return an error, the rest works.   */
 typedef struct hfem_mg_comm hfem_mg_comm;
 int hfem_mg_load(const char *librccl_path);
 int hfem_mg_unique_id(void *id_out_128_bytes);
@@ -443,8 +471,10 @@ int hfem_rectq4_mse(int device, const double *gx, int64_t nx, const double *gy, 
 
 /* Float-row twins of the 1D / structured entry points above, for models in the reference's default dtype
  * (torch.float32: src/models.py:36-40, 142; examples 1-3 as shipped): every array argument is float -- parameters,
- * points, targets, per-point outputs, gradient accumulators (float atomics) and the loss scalar; rows are widened on
- * load and rounded once on store, the arithmetic in between is fp64, exactly as hfem_tri3_energy_plan_f32 does.
+ * points, targets, per-point outputs, gradient accumulators and the loss scalar.  Inputs are widened on load, the
+ * arithmetic in between is fp64, per-point outputs are rounded once on store.  The ACCUMULATED outputs (ggrid, gu, ggx,
+ * ggy, loss_acc) are float atomics: every contribution is rounded when it is added and the order varies -- the last
+ * bits are not reproducible (unlike hfem_tri3_energy_plan_f32, whose gradient rows are summed in fp64 and rounded once).
  * No widening copies on either side of the call.  The scratch of the *_ws forms (cum, ws) stays fp64.           */
 int hfem_grid_param_fwd_f32(int device, const float *p, int64_t n, double x0, double xN, const uint8_t *mask,
                             const float *initial, float *grid, void *stream);

@@ -197,3 +197,163 @@ def test_fused_energy_adam_step_matches_the_two_launch_loop():
     tr3.step(); tr3.step()
     for pa, pe in zip(a.parameters(), e.parameters()):
         assert (pa - pe).abs().max().item() <= 1e-11 * pa.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_multi_tensor_fused_adam_one_launch_matches_torch_and_survives_a_checkpoint_restore():
+    """FusedAdam updates ALL parameter tensors in one launch (hfem_adam_multi_dev: device pointer table, the step counter
+    bumped by the last block to finish).  Mixed dtypes, odd lengths, per-group learning rates, eager (host count and
+    device count) and captured -- against torch.optim.Adam.  load_state_dict keeps the device counter's address, so a
+    graph captured before a restore goes on with the restored count."""
+    from hidenn_fem_amd.optim import FusedAdam
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [((70001, 2), F64), ((333,), torch.float32), ((4097, 2), F64), ((5,), F64)]
+    p0 = [torch.randn(s, generator=g, dtype=dt) for s, dt in shapes]
+    n_steps = 12
+    grads = [[torch.randn(t.shape, generator=g, dtype=t.dtype) * 10 ** float(k % 5 - 2) for t in p0] for k in range(n_steps)]
+    lrs = [3e-3, 1e-2, 5e-4, 1e-3]
+
+    def params():
+        return [t.clone().to(d).requires_grad_(True) for t in p0]
+
+    def groups(ps):
+        return [dict(params=[p], lr=lr) for p, lr in zip(ps, lrs)]
+    pa = params()
+    oa = torch.optim.Adam(groups(pa))
+    for gs in grads:
+        for a, gi in zip(pa, gs):
+            a.grad = gi.to(d).clone()
+        oa.step()
+
+    def close(ps, what):
+        for a, b in zip(pa, ps):
+            tol = 1e-13 if a.dtype == F64 else 3e-6
+            err = (a - b).abs().max().item() / a.abs().max().item()
+            assert err <= tol, (what, a.dtype, err)
+    for capturable in (False, True):
+        pb = params()
+        ob = FusedAdam(groups(pb), capturable=capturable)
+        for gs in grads:
+            for b, gi in zip(pb, gs):
+                b.grad = gi.to(d).clone()
+            ob.step()
+        close(pb, f"eager capturable={capturable}")
+        assert int(ob.state[pb[0]]["step"]) == n_steps
+    # captured: static gradient buffers refilled between replays; checkpoint restore in the middle
+    pc = params()
+    for c in pc:
+        c.grad = torch.zeros_like(c)
+    oc = FusedAdam(groups(pc), capturable=True).init_state()
+
+    def load(k):
+        for c, gi in zip(pc, grads[k]):
+            c.grad.copy_(gi.to(d))
+    load(0)
+    oc.step()                                                # eager warm-up step = step 1
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        oc.step()
+    counter_addr = oc._step_dev.data_ptr()
+    for k in range(1, 6):
+        load(k)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert int(oc._step_dev.item()) == 6
+    saved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in ((i, t.detach().clone()) for i, t in enumerate(pc))}
+    ck = oc.state_dict()
+    ck = dict(state={k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in ck["state"].items()},
+              param_groups=ck["param_groups"])
+    for k in range(6, 9):                                    # go on, then rewind to the checkpoint
+        load(k)
+        graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for i, c in enumerate(pc):
+            c.copy_(saved[i])
+    moments_before = [oc.state[c]["exp_avg"].data_ptr() for c in pc]
+    oc.load_state_dict(ck)
+    assert oc._step_dev.data_ptr() == counter_addr and int(oc._step_dev.item()) == 6
+    # the moments are new tensors after a load (as in torch): re-capture, the counter is still the same tensor
+    assert [oc.state[c]["exp_avg"].data_ptr() for c in pc] != moments_before
+    graph2 = torch.cuda.CUDAGraph()
+    load(6)
+    oc.step()                                                # eager step 7 (rebuilds the pointer table outside the capture)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph2):
+        oc.step()
+    for k in range(7, n_steps):
+        load(k)
+        graph2.replay()
+    torch.cuda.synchronize()
+    assert int(oc._step_dev.item()) == n_steps
+    close(pc, "captured + restored")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_kw", [dict(), dict(diagonal="zigzag")], ids=["paired", "one_per_slot"])
+def test_fused_energy_adam_step_fp32_rows_and_body_force(mesh_kw):
+    """EnergyAdamStep instances beyond fp64 / zero body force: an fp32 model -- the reference's default
+    dtype, /root/reference/src/loss.py:16, src/models.py:274 -- keeps fp32 parameters and moments and trains in one launch
+    per iteration; a body force enters through the B_k table.  Each against the two-launch loop on the same kernels'
+    gradient path (value_and_grad_ / autograd + FusedAdam), on a paired plan and on a one-element-per-slot plan."""
+    import copy
+    from conftest import b_force_fn
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
+    d = torch.device("cuda:0")
+    lr_x, lr_u, n_steps = 1e-8, 1e-7, 8
+    # ---- fp64 + body force
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(121, 81, jitter=0.2, seed=3, dtype=F64, **mesh_kw)
+    torch.manual_seed(2)
+    base = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    lf = EnergyLoss2D(device=d, dtype=F64)
+    assert base.tile_plan(0).is_paired() == (not mesh_kw)
+    a = copy.deepcopy(base)
+    opt = FusedAdam([dict(params=[a.node_coords_free], lr=lr_x), dict(params=[a.u_free], lr=lr_u)])
+    ref = []
+    for _ in range(n_steps):
+        opt.zero_grad()
+        loss = lf(a, b_force=b_force_fn)
+        loss.backward()
+        ref.append(loss.item())
+        opt.step()
+    b = copy.deepcopy(base)
+    tr = EnergyAdamStep(b, lf, lr_x=lr_x, lr_u=lr_u, b_force=b_force_fn)
+    got = [tr.step().item() for _ in range(n_steps)]
+    np.testing.assert_allclose(got, ref, rtol=1e-11)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert (pa - pb).abs().max().item() <= 1e-11 * pa.abs().max().item()
+    l0 = lf(base).item()
+    assert abs(got[0] - l0) > 1e-6 * abs(l0), "the body force changes the energy"
+    # ---- fp32 rows (zero body force, then with one)
+    coords32 = coords.float()
+    torch.manual_seed(2)
+    base32 = PiecewiseLinearShapeNN2D(coords32, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    assert base32.u_free.dtype == torch.float32
+    lf32 = EnergyLoss2D(device=d, dtype=torch.float32)
+    for bf in (None, b_force_fn):
+        a32 = copy.deepcopy(base32)
+        o32 = FusedAdam([dict(params=[a32.node_coords_free], lr=lr_x), dict(params=[a32.u_free], lr=lr_u)])
+        ref32 = []
+        for _ in range(n_steps):
+            o32.zero_grad()
+            loss = lf32(a32, b_force=bf)
+            loss.backward()
+            ref32.append(loss.double().item())
+            o32.step()
+        b32 = copy.deepcopy(base32)
+        tr32 = EnergyAdamStep(b32, lf32, lr_x=lr_x, lr_u=lr_u, b_force=bf)
+        got32 = [tr32.step().item() for _ in range(n_steps)]
+        assert b32.u_free.dtype == torch.float32 and tr32.state["exp_avg_u"].dtype == torch.float32
+        np.testing.assert_allclose(got32, ref32, rtol=2e-6)              # the reference loop rounds its loss to fp32
+        for pa, pb in zip(a32.parameters(), b32.parameters()):
+            # same fp32 update on the same once-rounded gradient; a last-bit flip of an fp64 LDS sum can move a rounding
+            assert (pa - pb).abs().max().item() <= 4 * torch.finfo(torch.float32).eps * pa.abs().max().item()
+            assert (pa == pb).float().mean().item() > 0.98
+        assert (b32.u_free - base32.u_free).abs().max().item() > 0

@@ -523,3 +523,35 @@ def test_shard_aware_tile_policy_sizes_tiles_for_elements_per_rank():
     big = TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges)
     assert big.stats["threads_per_tile"] == 512 and big.stats["slot_rows"] == 2 and big.stats["max_tile_owned"] <= 560
     check_invariants(conn.numpy(), edges.numpy(), coords.shape[0], TilePlan(conn, coords.shape[0], coords_hint=coords, edges=edges, shards=4))
+
+
+def test_tile_local_nodes_follow_the_row_order_when_rows_are_stored_along_the_curve():
+    """A model that stores a badly numbered mesh's parameter rows along the locality curve (reorder='auto') hands the plan
+    row maps that are NOT increasing in the node id; the plan then orders every tile's local nodes by ROW (owned part and
+    halo part each ascending), so neighbouring lanes gather neighbouring rows.  Increasing maps keep the node-id order."""
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    mesh = structured_tri_mesh(129, 65, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=torch.float64)
+    c, conn, g, b, mn, e = mesh
+    kw = dict(boundary_mask=g, dirichlet_mask=b, u_fixed=0.0, neumann_edges=e)
+    for reorder, sorted_by_row in (("auto", True), ("off", False)):
+        m = PiecewiseLinearShapeNN2D(c, conn, reorder=reorder, **kw)
+        plan = TilePlan(conn, c.shape[0], coords_hint=c, x_src=m._x_src, u_src=m._u_src, edges=e)
+        td, ns = plan.export("tile_desc"), plan.export("node_src")
+        inv = np.empty(c.shape[0], dtype=np.int64)            # row map -> node id (free rows >= 0, fixed rows < 0)
+        lines, n_sorted = [], 0
+        for (_, _, no, nno, nown, _, _, _) in td:
+            for part in (ns[no:no + nown, 0], ns[no + nown:no + nno, 0]):
+                free = part[part >= 0]
+                n_sorted += int((np.diff(free) > 0).all()) if len(free) > 1 else 1
+                if sorted_by_row:
+                    assert (part[np.argmax(part < 0):] < 0).all() or (part >= 0).all(), "fixed rows come last in each part"
+            rows = ns[no:no + nno, 0]
+            lines.append(len(np.unique(rows[rows >= 0] // 8)) / max(1, (rows >= 0).sum() / 8))
+        if sorted_by_row:
+            assert n_sorted == 2 * td.shape[0]
+            assert np.mean(lines) < 2.0                        # a tile's rows sit in few 128-byte lines
+        else:
+            assert np.mean(lines) > 4.0                        # as given: nearly one line per row
+        # the partition invariants do not depend on the local order
+        own = np.concatenate([ns[no:no + nown] for (_, _, no, nno, nown, _, _, _) in td])
+        assert len(np.unique(own[own[:, 0] >= 0, 0])) == int((~g).sum())

@@ -96,6 +96,7 @@ PROTOTYPES = {
                                            _f64, _f64, _f64, _vp, _i64, _vp]),
     "hfem_quad4_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_energy_plan_body": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "hfem_quad4_energy_plan_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_eval_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hfem_quad4_eval_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hfem_adam_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _i64, _vp]),

@@ -153,6 +153,7 @@ int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed
                     const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,
                     double *gx_free, double *gu_free, int skip_edges, bool phys, hipStream_t s);
 void free_tri3_det(hfem_plan *plan);
+int det_prepare(hfem_plan *plan, hipStream_t s);   // adjacency of the fixed-order kernels (TRI3 and QUAD4), built on first use
 // exchange.hip: interface pack + tile-energy sum + step-counter bump in one launch (hfem_plan_iface_pack)
 int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
                           int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, hipStream_t s);

@@ -90,7 +90,10 @@ __device__ __forceinline__ void shape_derivs(double xi, double eta, double (&D0)
 // gradients (the node-by-node D_N form above costs ~490).
 // HASB: body force b(xi_q) at the four Gauss points (k.Bk... is the TRI3 table; QUAD4 takes Bq[q] = b at point q):
 // e -= sum_q |det_q| u_h(q).b_q, dU_k -= sum_q |det_q| N_k(q) b_q, and the |det_q| dependence through jac_point.
-template <bool GRAD, bool HASB = false>
+// PHYS: the opt-in physical gradient convention, grad_u = G Jinv instead of the reference's G Jinv^T.  As for
+// TRI3 (hfem_device.h), E_phys(a, b, c, d) = E_ref(a, c, b, d): b and c swap on the way into jac_point and their cotangents
+// swap on the way out.
+template <bool GRAD, bool HASB = false, bool PHYS = false>
 __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const double2 (&Un)[4], const Tri3Consts &k,
                                                 double2 (&gx)[4], double2 (&gu)[4], const double2 *Bq = nullptr) {
     const double gp = 0.57735026918962576451;   // 1/sqrt(3)
@@ -129,7 +132,7 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
                 uhy += nk[j] * Un[j].y;
             }
             const double2 bq = Bq[q];
-            e += jac_point<GRAD>(a, b, c, d, g0, g1, 0.0625, k, o, 0.0625 * (uhx * bq.x + uhy * bq.y), &A16);
+            e += jac_point<GRAD>(a, PHYS ? c : b, PHYS ? b : c, d, g0, g1, 0.0625, k, o, 0.0625 * (uhx * bq.x + uhy * bq.y), &A16);
             if (GRAD) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -138,11 +141,11 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
                 }
             }
         } else {
-            e += jac_point<GRAD>(a, b, c, d, g0, g1, 0.0625, k, o);
+            e += jac_point<GRAD>(a, PHYS ? c : b, PHYS ? b : c, d, g0, g1, 0.0625, k, o);
         }
         if (GRAD) {
-            U[q][0] = o.da; U[q][1] = o.dc; U[q][2] = o.dg0.x; U[q][3] = o.dg0.y;
-            V[q][0] = o.db; V[q][1] = o.dd; V[q][2] = o.dg1.x; V[q][3] = o.dg1.y;
+            U[q][0] = o.da; U[q][1] = PHYS ? o.db : o.dc; U[q][2] = o.dg0.x; U[q][3] = o.dg0.y;
+            V[q][0] = PHYS ? o.dc : o.db; V[q][1] = o.dd; V[q][2] = o.dg1.x; V[q][3] = o.dg1.y;
         }
     }
     if (GRAD) {
@@ -311,12 +314,14 @@ __global__ __launch_bounds__(kBlockQ) void quad4_eval_bwd_kernel(
 // CAPO > 0: compile-time stride of the four accumulator arrays (their LDS addresses become one scaled id + immediate).
 struct Quad4Body { double2 b[4]; };      // body force at the 2x2 Gauss points (reference coordinates)
 
-template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false, int CAPN = 0>
+// V2: row storage type (double2, or float2 for fp32 models -- the reference's default dtype: widened on load, gradient rows
+// rounded once on store, fp64 arithmetic); PHYS: the opt-in physical gradient convention.
+template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false, int CAPN = 0, typename V2 = double2, bool PHYS = false>
 __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
-    PlanDev pd, int tile_begin, const double2 *__restrict__ x_free, const double2 *__restrict__ x_fixed,
-    const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed, Tri3Consts k,
+    PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
+    const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
-    double2 *__restrict__ gx_free, double2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
+    V2 *__restrict__ gx_free, V2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
     int stagger_ticks, int stagger_shift, unsigned long long *__restrict__ stamps, Quad4Body body) {
 #define HFEM_QSTAMP(I)                                                                              \
     if ((ABL & 4) && threadIdx.x == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
@@ -362,9 +367,9 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     double vxx[NPT], vxy[NPT], vux[NPT], vuy[NPT];      // plain doubles (double2 arrays end up in scratch)
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-        const double2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
-        const double2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
-        const double2 tx = *px, tu = *pu;
+        const V2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
+        const V2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
+        const V2 tx = *px, tu = *pu;
         vxx[j] = tx.x; vxy[j] = tx.y; vux[j] = tu.x; vuy[j] = tu.y;
     }
     __builtin_amdgcn_sched_barrier(0);                  // all gather loads are issued before the first is waited for
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { gx[j] = Xn[j]; gu[j] = Un[j]; }
             } else {
-                e = HASB ? quad4_element<true, true>(Xn, Un, k, gx, gu, body.b) : quad4_element<true>(Xn, Un, k, gx, gu);
+                e = HASB ? quad4_element<true, true, PHYS>(Xn, Un, k, gx, gu, body.b) : quad4_element<true, false, PHYS>(Xn, Un, k, gx, gu);
             }
             if (ABL & 2) {          // lab: no LDS atomics (keep the math live)
 #pragma unroll
@@ -444,6 +449,8 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     HFEM_QSTAMP(5)
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr bool kWide = sizeof(V2) == 16;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
     __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
@@ -451,12 +458,16 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
         const int l = tid + j * BLOCK;
         if (l < n_owned) {
             if (gx_free && s[j].x >= 0) {
-                const double2 v = make_double2(acc0[l], acc1[l]);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, 16);
+                V2 v;
+                v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, 16);
             }
             if (gu_free && s[j].y >= 0) {
-                const double2 v = make_double2(acc2[l], acc3[l]);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, 16);
+                V2 v;
+                v.x = acc2[l]; v.y = acc3[l];
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, 16);
             }
         }
     }
@@ -678,6 +689,88 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_pipe_kernel(
 #endif  // HFEM_LAB
 
 
+// ------------------------------------------------------------------ deterministic (fixed-order) QUAD4
+// HFEM_FLAG_DETERMINISTIC on a QUAD4 plan: the node-centric cross-check of tri3_det.hip for the extension element.  One
+// thread per NODE walks the node -> (element, corner) adjacency in ascending element id, re-evaluates every adjacent element
+// (quad4_element, all four corners -- 4x the flops, no atomics) and keeps its own corner's rows, then its Neumann edges,
+// then ONE store per row; the loss is one thread per element / edge, shuffle-tree + wave-order block sums and a one-block
+// sum.  Bit-identical run to run.  A checker, several times slower than the tiled kernel.
+__device__ __forceinline__ double2 q4_row(const double2 *__restrict__ free_rows, const double2 *__restrict__ fixed_rows, int32_t src) {
+    return src >= 0 ? free_rows[src] : fixed_rows[~src];
+}
+
+template <bool PHYS>
+__global__ __launch_bounds__(256) void quad4_det_grad_kernel(
+    int32_t nn, const int32_t *__restrict__ conn, const int32_t *__restrict__ x_src, const int32_t *__restrict__ u_src,
+    const int32_t *__restrict__ adj_ptr, const int32_t *__restrict__ adj, const int32_t *__restrict__ edges,
+    const int32_t *__restrict__ eadj_ptr, const int32_t *__restrict__ eadj, const double2 *__restrict__ x_free,
+    const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed,
+    Tri3Consts k, Quad4Body body, const double4 *__restrict__ T_edge, double4 Tconst, int skip_edges,
+    double2 *__restrict__ gx_free, double2 *__restrict__ gu_free) {
+    const int32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= nn) return;
+    double2 sx = make_double2(0.0, 0.0), su = make_double2(0.0, 0.0);
+    for (int32_t i = adj_ptr[n]; i < adj_ptr[n + 1]; ++i) {
+        const int32_t ec = adj[i], e = ec >> 2, c = ec & 3;
+        double2 Xn[4], Un[4], gx[4], gu[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t nj = conn[4 * (int64_t)e + j];
+            Xn[j] = q4_row(x_free, x_fixed, x_src[nj]);
+            Un[j] = q4_row(u_free, u_fixed, u_src[nj]);
+        }
+        quad4_element<true, true, PHYS>(Xn, Un, k, gx, gu, body.b);
+        const double2 px = c == 0 ? gx[0] : (c == 1 ? gx[1] : (c == 2 ? gx[2] : gx[3]));
+        const double2 pu = c == 0 ? gu[0] : (c == 1 ? gu[1] : (c == 2 ? gu[2] : gu[3]));
+        sx.x += px.x; sx.y += px.y;
+        su.x += pu.x; su.y += pu.y;
+    }
+    if (!skip_edges)
+        for (int32_t i = eadj_ptr[n]; i < eadj_ptr[n + 1]; ++i) {
+            const int32_t ge = eadj[i], g = ge >> 1, end = ge & 1;
+            const int32_t ni = edges[2 * (int64_t)g], nj = edges[2 * (int64_t)g + 1];
+            const double4 tt = T_edge ? T_edge[g] : Tconst;
+            double2 gx[2], gu[2];
+            edge2_element<true>(q4_row(x_free, x_fixed, x_src[ni]), q4_row(x_free, x_fixed, x_src[nj]),
+                                q4_row(u_free, u_fixed, u_src[ni]), q4_row(u_free, u_fixed, u_src[nj]), tt, gx, gu);
+            sx.x += gx[end].x; sx.y += gx[end].y;
+            su.x += gu[end].x; su.y += gu[end].y;
+        }
+    const int32_t rx = x_src[n], ru = u_src[n];
+    if (gx_free && rx >= 0) gx_free[rx] = sx;
+    if (gu_free && ru >= 0) gu_free[ru] = su;
+}
+
+template <bool PHYS>
+__global__ __launch_bounds__(256) void quad4_det_loss_kernel(
+    int32_t ne, int32_t ned, const int32_t *__restrict__ conn, const int32_t *__restrict__ x_src,
+    const int32_t *__restrict__ u_src, const int32_t *__restrict__ edges, const double2 *__restrict__ x_free,
+    const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free, const double2 *__restrict__ u_fixed,
+    Tri3Consts k, Quad4Body body, const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials) {
+    __shared__ double red[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (i < ne) {
+        double2 Xn[4], Un[4], gx[4], gu[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t nj = conn[4 * i + j];
+            Xn[j] = q4_row(x_free, x_fixed, x_src[nj]);
+            Un[j] = q4_row(u_free, u_fixed, u_src[nj]);
+        }
+        v = quad4_element<false, true, PHYS>(Xn, Un, k, gx, gu, body.b);
+    } else if (i < (int64_t)ne + ned) {
+        const int64_t g = i - ne;
+        const int32_t ni = edges[2 * g], nj = edges[2 * g + 1];
+        double2 ex[2], eu[2];
+        v = -edge2_element<false>(q4_row(x_free, x_fixed, x_src[ni]), q4_row(x_free, x_fixed, x_src[nj]),
+                                  q4_row(u_free, u_fixed, u_src[ni]), q4_row(u_free, u_fixed, u_src[nj]),
+                                  T_edge ? T_edge[g] : Tconst, ex, eu);
+    }
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(256) void quad4_sum_partials_kernel(const double *__restrict__ partials, int n,
                                                                  double *__restrict__ out) {
     __shared__ double red[4];
@@ -745,8 +838,8 @@ extern "C" int hfem_quad4_energy_plan(hfem_plan *plan, const double *x_free, con
                                       const double *T_edge, const double Tconst[4], int32_t tile_begin,
                                       int32_t tile_end, double *loss_out, double *gx_free, double *gu_free,
                                       int32_t flags, void *stream) {
-    return hfem_quad4_energy_plan_body(plan, x_free, x_fixed, u_free, u_fixed, mat, nullptr, T_edge, Tconst, tile_begin,
-                                       tile_end, loss_out, gx_free, gu_free, flags, stream);
+    return hfem_quad4_energy_plan_ex(plan, 0, x_free, x_fixed, u_free, u_fixed, mat, nullptr, T_edge, Tconst, tile_begin,
+                                     tile_end, loss_out, gx_free, gu_free, flags, stream);
 }
 
 extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free, const double *x_fixed,
@@ -754,9 +847,21 @@ extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free
                                            const double Bq[8], const double *T_edge, const double Tconst[4],
                                            int32_t tile_begin, int32_t tile_end, double *loss_out, double *gx_free,
                                            double *gu_free, int32_t flags, void *stream) {
+    return hfem_quad4_energy_plan_ex(plan, 0, x_free, x_fixed, u_free, u_fixed, mat, Bq, T_edge, Tconst, tile_begin, tile_end,
+                                     loss_out, gx_free, gu_free, flags, stream);
+}
+
+// General form: dtype 0 = fp64 rows, 1 = fp32 rows (an fp32 model -- the reference's default dtype -- without widening copies:
+// rows widened on load, gradient rows rounded once on store, arithmetic and loss_out fp64); flags may carry
+// HFEM_FLAG_PHYSICAL_GRAD (grad_u = G Jinv) and, for fp64 rows on the whole plan, HFEM_FLAG_DETERMINISTIC.
+extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const void *x_free, const void *x_fixed,
+                                         const void *u_free, const void *u_fixed, const double mat[4], const double Bq[8],
+                                         const double *T_edge, const double Tconst[4], int32_t tile_begin,
+                                         int32_t tile_end, double *loss_out, void *gx_free, void *gu_free, int32_t flags,
+                                         void *stream) {
     HFEM_ARG_CHECK(plan && mat && loss_out, "null pointer");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS)),
-                   "QUAD4 extension: reference convention, atomic accumulation, inline loss sum");
+    HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64 rows, 1 = fp32 rows");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_SUM_PREVIOUS | HFEM_FLAG_SAME_BANK)), "QUAD4 extension: inline or deferred loss sum only");
     Quad4Body body;
     bool hasb = false;
     for (int q = 0; q < 4; ++q) {
@@ -775,20 +880,53 @@ extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free
     if (int rc = use_device(plan->device)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
+    const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+    Tri3Consts k = make_consts(mat, 1.0, nullptr);
+    const bool phys = (flags & HFEM_FLAG_PHYSICAL_GRAD) != 0;
+    const int skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
+    void *gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free, *gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
+    if (flags & HFEM_FLAG_DETERMINISTIC) {
+        HFEM_ARG_CHECK(dtype == 0, "HFEM_FLAG_DETERMINISTIC: fp64 rows");
+        HFEM_ARG_CHECK(tile_begin == 0 && tile_end == nt, "HFEM_FLAG_DETERMINISTIC: whole plan only");
+        HFEM_ARG_CHECK(!(flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_DETERMINISTIC always delivers the loss");
+        if (int rc = det_prepare(plan, s)) return rc;
+        const hfem_plan::Det &D = plan->det;
+        const int32_t nn = (int32_t)h.nn, ne = (int32_t)h.ne, ned = skip_edges ? 0 : (int32_t)h.ned;
+        if (nn > 0 && (gx || gu)) {
+#define HFEM_Q4_DET_GRAD(P)                                                                                                 \
+    hipLaunchKernelGGL((quad4_det_grad_kernel<P>), dim3((nn + 255) / 256), dim3(256), 0, s, nn, D.conn, D.x_src, D.u_src,     \
+                       D.adj_ptr, D.adj, D.edges, D.eadj_ptr, D.eadj, (const double2 *)x_free, (const double2 *)x_fixed,     \
+                       (const double2 *)u_free, (const double2 *)u_fixed, k, body, (const double4 *)T_edge, tc, skip_edges, \
+                       (double2 *)gx, (double2 *)gu)
+            if (phys) HFEM_Q4_DET_GRAD(true); else HFEM_Q4_DET_GRAD(false);
+#undef HFEM_Q4_DET_GRAD
+            if (int rc = launch_status("hfem_quad4_energy_plan(deterministic gradients)")) return rc;
+        }
+        const int nb = (int)(((int64_t)ne + ned + 255) / 256);
+        if (nb > 0) {
+#define HFEM_Q4_DET_LOSS(P)                                                                                                 \
+    hipLaunchKernelGGL((quad4_det_loss_kernel<P>), dim3(nb), dim3(256), 0, s, ne, ned, D.conn, D.x_src, D.u_src, D.edges,    \
+                       (const double2 *)x_free, (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed, \
+                       k, body, (const double4 *)T_edge, tc, D.partials)
+            if (phys) HFEM_Q4_DET_LOSS(true); else HFEM_Q4_DET_LOSS(false);
+#undef HFEM_Q4_DET_LOSS
+        }
+        hipLaunchKernelGGL(quad4_sum_partials_kernel, dim3(1), dim3(256), 0, s, D.partials, nb, loss_out);
+        return launch_status("hfem_quad4_energy_plan(deterministic loss)");
+    }
     if (n > 0) {
-        const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
-        Tri3Consts k = make_consts(mat, 1.0, nullptr);
-#define HFEM_LAUNCH_Q4(NPT, EPT, ...)                                                                       \
-    hipLaunchKernelGGL((quad4_energy_fast_kernel<256, NPT, EPT, __VA_ARGS__>), dim3(n), dim3(256), (size_t)plan->lds_bytes, s, \
-                       plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,  \
-                       (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,   \
-                       plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free, \
-                       (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned,  \
-                       (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger, g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps, body)
+        const int sshift = g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8);
+        // generic launch of one instance (NPT, EPT, ABL, CAPO, HASB, CAPN, V2, PHYS) with the plan's runtime LDS strides
+#define HFEM_LAUNCH_Q4V(V, ...)                                                                                              \
+    hipLaunchKernelGGL((quad4_energy_fast_kernel<256, __VA_ARGS__>), dim3(n), dim3(256), (size_t)plan->lds_bytes, s,          \
+                       plan_dev(plan), (int)tile_begin, (const V *)x_free, (const V *)x_fixed, (const V *)u_free,            \
+                       (const V *)u_fixed, k, (const double4 *)T_edge, tc, plan->d_partials + tile_begin, (V *)gx, (V *)gu,   \
+                       h.max_nodes, h.max_owned, skip_edges, stagger, sshift, plan->d_stamps, body)
+#define HFEM_LAUNCH_Q4(NPT, EPT, ...) HFEM_LAUNCH_Q4V(double2, NPT, EPT, __VA_ARGS__)
 #ifdef HFEM_LAB
         const int abl = g_quad4_ablate;
         const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
-        if (g_quad4_pipe > 0 && abl == 0 && h.max_nodes <= 3 * 256 && h.max_elems <= 4 * 256 &&
+        if (dtype == 0 && !phys && g_quad4_pipe > 0 && abl == 0 && h.max_nodes <= 3 * 256 && h.max_elems <= 4 * 256 &&
             plan->lds_bytes_pipe <= 64 * 1024) {
             int G = g_quad4_pipe * 256;
             if (G > n) G = n;
@@ -797,32 +935,37 @@ extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free
             hipLaunchKernelGGL((quad4_energy_pipe_kernel<256, 3, 4>), dim3(G), dim3(256), (size_t)plan->lds_bytes_pipe, s,
                                plan_dev(plan), (int)tile_begin, n, (const double2 *)x_free, (const double2 *)x_fixed,
                                (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
-                               plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
-                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, h.max_owned, cap_elems,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0);
+                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, h.max_nodes, h.max_owned, cap_elems,
+                               skip_edges);
             if (int rc = launch_status("hfem_quad4_energy_plan(pipe)")) return rc;
             if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
             hipLaunchKernelGGL(quad4_sum_partials_kernel, dim3(1), dim3(256), 0, s, plan->d_partials + tile_begin, G, loss_out);
             return launch_status("hfem_quad4_energy_plan(sum)");
         }
-        if (abl == 1) HFEM_LAUNCH_Q4(4, 4, 1);                       // lab instances (hfem_set_option("quad4_ablate"))
-        else if (abl == 2) HFEM_LAUNCH_Q4(4, 4, 2);
-        else if (abl == 3) HFEM_LAUNCH_Q4(4, 4, 3);
-        else if (abl == 4) HFEM_LAUNCH_Q4(4, 4, 4);                  // s_memrealtime phase stamps (scripts/stamps.py)
+        if (dtype == 0 && !phys && abl == 1) HFEM_LAUNCH_Q4(4, 4, 1);        // lab instances (hfem_set_option("quad4_ablate"))
+        else if (dtype == 0 && !phys && abl == 2) HFEM_LAUNCH_Q4(4, 4, 2);
+        else if (dtype == 0 && !phys && abl == 3) HFEM_LAUNCH_Q4(4, 4, 3);
+        else if (dtype == 0 && !phys && abl == 4) HFEM_LAUNCH_Q4(4, 4, 4);   // s_memrealtime phase stamps (scripts/stamps.py)
         else
 #else
         const int stagger = 0;
 #endif
-        if (hasb) HFEM_LAUNCH_Q4(4, 4, 0, 0, true);                  // body force: general instance (runtime strides)
+        if (dtype == 1) {                                                // fp32 rows: general instances (runtime strides)
+            if (phys && hasb) HFEM_LAUNCH_Q4V(float2, 4, 4, 0, 0, true, 0, float2, true);
+            else if (phys) HFEM_LAUNCH_Q4V(float2, 4, 4, 0, 0, false, 0, float2, true);
+            else if (hasb) HFEM_LAUNCH_Q4V(float2, 4, 4, 0, 0, true, 0, float2, false);
+            else HFEM_LAUNCH_Q4V(float2, 4, 4, 0, 0, false, 0, float2, false);
+        } else if (phys) {                                               // opt-in physical convention: general instances
+            if (hasb) HFEM_LAUNCH_Q4V(double2, 4, 4, 0, 0, true, 0, double2, true);
+            else HFEM_LAUNCH_Q4V(double2, 4, 4, 0, 0, false, 0, double2, true);
+        } else if (hasb) HFEM_LAUNCH_Q4(4, 4, 0, 0, true);               // body force: general instance (runtime strides)
         else if (g_quad4_const_caps && h.max_nodes <= 672 && h.max_owned <= 560 && h.max_elems <= 3 * 256) {
             // default tile shape (557 owned nodes): compile-time LDS strides, (672 + 560) * 32 + 128 = 39552 B: 4 workgroups per CU
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 3, 3, 0, 560, false, 672>), dim3(n), dim3(256), (size_t)39552, s,
                                plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,
                                (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
-                               plan->d_partials + tile_begin, (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
-                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, 672, 560,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger,
-                               g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps, body);
+                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, 672, 560, skip_edges, stagger, sshift,
+                               plan->d_stamps, body);
         } else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
         else if (g_quad4_const_caps && h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 40960) {
             // default tile shape: compile-time accumulator stride (launched with the matching LDS size)
@@ -830,12 +973,10 @@ extern "C" int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free
                                (size_t)(h.max_nodes * 32 + 560 * 32 + 128), s, plan_dev(plan), (int)tile_begin,
                                (const double2 *)x_free, (const double2 *)x_fixed, (const double2 *)u_free,
                                (const double2 *)u_fixed, k, (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
-                               (flags & HFEM_FLAG_NO_GX) ? nullptr : (double2 *)gx_free,
-                               (flags & HFEM_FLAG_NO_GU) ? nullptr : (double2 *)gu_free, h.max_nodes, 560,
-                               (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, stagger,
-                               g_quad4_stagger_shift | ((g_quad4_stagger_groups - 1) << 8), plan->d_stamps, body);
+                               (double2 *)gx, (double2 *)gu, h.max_nodes, 560, skip_edges, stagger, sshift, plan->d_stamps, body);
         } else HFEM_LAUNCH_Q4(4, 4, 0);
 #undef HFEM_LAUNCH_Q4
+#undef HFEM_LAUNCH_Q4V
         if (int rc = launch_status("hfem_quad4_energy_plan")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;

@@ -112,10 +112,10 @@ static int det_upload(T **dst, const std::vector<T> &src, size_t min_count = 1) 
 
 static int det_prepare_impl(hfem_plan *plan);
 
-// First deterministic launch on a plan: build and upload the node -> element adjacency (hipMalloc + synchronous copies).
+// First deterministic launch on a plan (TRI3 or QUAD4): build and upload the node -> element adjacency (hipMalloc + synchronous copies).
 // Never inside a stream capture (the copies would invalidate it): a capturing caller gets an error and runs ONE eager
 // deterministic evaluation first.  A failure part-way releases what was allocated.
-static int det_prepare(hfem_plan *plan, hipStream_t s) {
+int det_prepare(hfem_plan *plan, hipStream_t s) {
     if (plan->det.ready) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
@@ -131,17 +131,18 @@ static int det_prepare(hfem_plan *plan, hipStream_t s) {
 static int det_prepare_impl(hfem_plan *plan) {
     hfem_plan::Det &D = plan->det;
     const HostPlan &h = plan->host;
-    HFEM_ARG_CHECK(h.npe == 3, "deterministic path: TRI3 plans only");
     const int64_t ne = h.ne, nn = h.nn, ned = h.ned;
+    const int npe = h.npe;
+    HFEM_ARG_CHECK(ne < (1 << 29), "deterministic path: fewer than 2^29 elements");
     // node -> (element, corner) and node -> (edge, end) adjacency, ascending element / edge id: the fixed order
-    std::vector<int32_t> aptr(nn + 1, 0), adj(3 * ne), eptr(nn + 1, 0), eadj(2 * ned);
-    for (int64_t i = 0; i < 3 * ne; ++i) aptr[h.conn32[i] + 1]++;
+    std::vector<int32_t> aptr(nn + 1, 0), adj(npe * ne), eptr(nn + 1, 0), eadj(2 * ned);
+    for (int64_t i = 0; i < npe * ne; ++i) aptr[h.conn32[i] + 1]++;
     for (int64_t i = 0; i < 2 * ned; ++i) eptr[h.edges32[i] + 1]++;
     for (int64_t n = 0; n < nn; ++n) { aptr[n + 1] += aptr[n]; eptr[n + 1] += eptr[n]; }
     {
         std::vector<int32_t> f(aptr.begin(), aptr.end() - 1), fe(eptr.begin(), eptr.end() - 1);
         for (int64_t e = 0; e < ne; ++e)
-            for (int c = 0; c < 3; ++c) adj[f[h.conn32[3 * e + c]]++] = (int32_t)(e << 2 | c);
+            for (int c = 0; c < npe; ++c) adj[f[h.conn32[npe * e + c]]++] = (int32_t)(e << 2 | c);
         for (int64_t g = 0; g < ned; ++g)
             for (int c = 0; c < 2; ++c) eadj[fe[h.edges32[2 * g + c]]++] = (int32_t)(g << 1 | c);
     }
@@ -170,6 +171,7 @@ void free_tri3_det(hfem_plan *plan) {
 int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed, const double *u_free,
                     const double *u_fixed, const Tri3Consts &kc, const double *T_edge, double4 tc, double *loss_out,
                     double *gx_free, double *gu_free, int skip_edges, bool phys, hipStream_t s) {
+    HFEM_ARG_CHECK(plan->host.npe == 3, "launch_tri3_det: TRI3 plans");
     if (int rc = det_prepare(plan, s)) return rc;
     const hfem_plan::Det &D = plan->det;
     const HostPlan &h = plan->host;

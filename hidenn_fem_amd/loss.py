@@ -143,11 +143,12 @@ class EnergyLoss2D:
         """QUAD4 extension: 2x2 Gauss (``gauss_order`` is a triangle-rule setting and does not apply); body force at the
         reference Gauss points, traction as on triangles (constant table, per-edge table, or -- when the traction
         depends on points that move with free nodes -- autograd through ``t_force`` on the unfused edge path)."""
-        if self._mode_flags(model):
-            raise NotImplementedError("QUAD4 extension: grad_convention='physical' / deterministic are TRI3 switches")
+        mode = self._mode_flags(model)            # physical convention / deterministic: instances of the tiled QUAD4 path
         Bq = self._quad4_body(b_force)
         no_edges = model.neumann_edges is None or model.N_edges == 0
         if self.quad4_planless:                                    # cross-check path: fp64 global atomics
+            if mode:
+                raise NotImplementedError("QUAD4 planless cross-check kernel: reference convention, atomic accumulation")
             if b_force is not None or t_force is not None:
                 raise NotImplementedError("QUAD4 planless cross-check kernel: default forces only")
             _, Tconst = self._traction(model, None)
@@ -157,24 +158,22 @@ class EnergyLoss2D:
         args = (model.node_coords_free, model.u_free, model.node_coords_fixed.to(model.dtype), model.u_fixed_rows(), plan,
                 self._mat)
         if no_edges:
-            return ops.Quad4PlanEnergyFn.apply(*args, [0.0] * 4, Bq, None, HFEM_FLAG_NO_EDGES)
+            return ops.Quad4PlanEnergyFn.apply(*args, [0.0] * 4, Bq, None, HFEM_FLAG_NO_EDGES | mode)
         if t_force is not None and model.node_coords_free.requires_grad and self._edge_nodes_free(model):
-            return ops.Quad4PlanEnergyFn.apply(*args, [0.0] * 4, Bq, None, HFEM_FLAG_NO_EDGES) - self.edge_energy(model, t_force)
+            return ops.Quad4PlanEnergyFn.apply(*args, [0.0] * 4, Bq, None, HFEM_FLAG_NO_EDGES | mode) - self.edge_energy(model, t_force)
         T_edge, Tconst = self._traction(model, t_force)
-        return ops.Quad4PlanEnergyFn.apply(*args, Tconst, Bq, T_edge, 0)
+        return ops.Quad4PlanEnergyFn.apply(*args, Tconst, Bq, T_edge, mode)
 
     def value_and_grad_(self, model) -> torch.Tensor:
         """Autograd-free fast path: ONE launch writes the total potential's gradients straight into
         ``model.node_coords_free.grad`` and ``model.u_free.grad`` (overwritten -- every free row is owned by exactly
         one tile, so no ``zero_grad`` is needed) and returns the loss (0-d, fp64).  Default forces only (zero body
-        force, constant traction); TRI3 models (fp64 or fp32 rows) and fp64 QUAD4 models.  An optimiser can step right after it; under
+        force, constant traction); TRI3 and QUAD4 models, fp64 or fp32 rows.  An optimiser can step right after it; under
         ``GraphedTraining(..., direct=True)`` a whole iteration is this launch plus the optimiser's."""
         import ctypes as C
         from . import _lib
         quad = getattr(model, "nodes_per_element", 3) == 4
         xf, uf = model.node_coords_free, model.u_free
-        if quad and xf.dtype != torch.float64:
-            raise RuntimeError("value_and_grad_: QUAD4 models must be fp64 (model.double())")
         if xf.dtype != uf.dtype or xf.dtype not in (torch.float64, torch.float32):
             raise RuntimeError("value_and_grad_: parameters must both be fp64 or both fp32")
         for p in (xf, uf):
@@ -200,12 +199,14 @@ class EnergyLoss2D:
         xfix = model.node_coords_fixed.to(device=xf.device, dtype=xf.dtype).contiguous()
         ufix = model.u_fixed_rows().to(device=xf.device, dtype=xf.dtype).contiguous()
         flags = (0 if model.N_edges else HFEM_FLAG_NO_EDGES) | self._mode_flags(model)
-        if flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC) and (quad or f32):
-            raise NotImplementedError("grad_convention='physical' / deterministic: fp64 TRI3 models")
+        if flags & HFEM_FLAG_DETERMINISTIC and f32:
+            raise NotImplementedError("deterministic: fp64 models (model.double())")
+        if flags & HFEM_FLAG_PHYSICAL_GRAD and f32 and not quad:
+            raise NotImplementedError("grad_convention='physical' on fp32 rows: QUAD4 models, or model.double()")
         if quad:                                     # QUAD4-iso extension: same contract, tiled QUAD4 kernel
-            _lib.check(_lib.lib().hfem_quad4_energy_plan(
-                plan.handle, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),
-                ufix.data_ptr() if ufix.numel() else None, mat, None, Tc, 0, -1, loss.data_ptr(), xf.grad.data_ptr(),
+            _lib.check(_lib.lib().hfem_quad4_energy_plan_ex(
+                plan.handle, 1 if f32 else 0, xf.data_ptr(), xfix.data_ptr() if xfix.numel() else None, uf.data_ptr(),
+                ufix.data_ptr() if ufix.numel() else None, mat, None, None, Tc, 0, -1, loss.data_ptr(), xf.grad.data_ptr(),
                 uf.grad.data_ptr(), flags, _lib.stream_ptr(xf.device)), "hfem_quad4_energy_plan")
             return loss
         fn = _lib.lib().hfem_tri3_energy_plan_f32 if f32 else _lib.lib().hfem_tri3_energy_plan

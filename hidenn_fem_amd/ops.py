@@ -490,23 +490,26 @@ class Quad4EvalFn(torch.autograd.Function):
 
 
 class Quad4PlanEnergyFn(torch.autograd.Function):
-    """Tiled QUAD4 energy + Neumann work (plan with nodes_per_elem = 4): one launch, loss + unit gradients."""
+    """Tiled QUAD4 energy + Neumann work (plan with nodes_per_elem = 4): one launch, loss + unit gradients.  fp32 models take
+    the float-row instance (no widening copies); ``flags`` may carry the physical convention / deterministic switches."""
 
     @staticmethod
     def forward(ctx, x_free, u_free, x_fixed, u_fixed, plan, mat, Tconst, Bq=None, T_edge=None, flags=0):
         dev = x_free.device
-        xf, uf = _f64(x_free, "node_coords_free"), _f64(u_free, "u_free")
-        xfix, ufix = _f64(x_fixed, "node_coords_fixed"), _f64(u_fixed, "u_fixed")
+        f32 = x_free.dtype == F32 and u_free.dtype == F32 and not (int(flags) & 128)      # deterministic: fp64 rows
+        rt = F32 if f32 else F64
+        xf, uf = _as(x_free, "node_coords_free", rt), _as(u_free, "u_free", rt)
+        xfix, ufix = _as(x_fixed, "node_coords_fixed", rt), _as(u_fixed, "u_fixed", rt)
         need_gx, need_gu = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         loss = torch.empty((), dtype=F64, device=dev)
         gx = torch.empty_like(xf) if need_gx else None
         gu = torch.empty_like(uf) if need_gu else None
         fl = int(flags) | (0 if need_gx else 1) | (0 if need_gu else 2)
         te = _f64(T_edge, "T_edge")
-        check(_lib.lib().hfem_quad4_energy_plan_body(plan.handle, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix), _dvec(mat),
-                                                     None if Bq is None else _dvec(Bq), ptr(te),
-                                                     None if Tconst is None else _dvec(Tconst), 0, -1, ptr(loss), ptr(gx),
-                                                     ptr(gu), fl, stream_ptr(dev)),
+        check(_lib.lib().hfem_quad4_energy_plan_ex(plan.handle, 1 if f32 else 0, ptr(xf), ptr(xfix), ptr(uf), ptr(ufix),
+                                                   _dvec(mat), None if Bq is None else _dvec(Bq), ptr(te),
+                                                   None if Tconst is None else _dvec(Tconst), 0, -1, ptr(loss), ptr(gx),
+                                                   ptr(gu), fl, stream_ptr(dev)),
               "hfem_quad4_energy_plan")
         ctx.unit, ctx.dtypes = (gx, gu), (x_free.dtype, u_free.dtype)
         return loss.to(x_free.dtype) if x_free.dtype != F64 else loss
@@ -515,6 +518,5 @@ class Quad4PlanEnergyFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         gx, gu = ctx.unit
-        g64 = g.to(F64)
-        return (None if gx is None else (gx * g64).to(ctx.dtypes[0]),
-                None if gu is None else (gu * g64).to(ctx.dtypes[1])) + (None,) * 8
+        return (None if gx is None else (gx * g.to(gx.dtype)).to(ctx.dtypes[0]),
+                None if gu is None else (gu * g.to(gu.dtype)).to(ctx.dtypes[1])) + (None,) * 8

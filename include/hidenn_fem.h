@@ -280,6 +280,15 @@ int hfem_quad4_energy_plan_body(hfem_plan *plan, const double *x_free, const dou
                                 const double Bq[8], const double *T_edge, const double Tconst[4],
                                 int32_t tile_begin, int32_t tile_end, double *loss_out, double *gx_free,
                                 double *gu_free, int32_t flags, void *stream);
+/* General form.  dtype: 0 = fp64 rows, 1 = fp32 rows (x / u / fixed rows and the gradient rows are float [rows][2]: an
+ * fp32 model, the reference's default dtype src/loss.py:16, without widening copies -- widened on load, rounded once on
+ * store, arithmetic and loss_out fp64).  flags additionally accept HFEM_FLAG_PHYSICAL_GRAD (grad_u = G Jinv instead of the
+ * reference convention's G Jinv^T) and, for fp64 rows on the whole plan, HFEM_FLAG_DETERMINISTIC (node-centric fixed-order
+ * kernel: bit-identical run to run, several times slower).  Bq as hfem_quad4_energy_plan_body (NULL: none).           */
+int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const void *x_free, const void *x_fixed,
+                              const void *u_free, const void *u_fixed, const double mat[4], const double Bq[8],
+                              const double *T_edge, const double Tconst[4], int32_t tile_begin, int32_t tile_end,
+                              double *loss_out, void *gx_free, void *gu_free, int32_t flags, void *stream);
 /* Per-point forward/backward with the (x_ref, element_id) contract of src/models.py:316:
  * x_eval [M][2] in [-1,1]^2 -> u_h [M][2], detJ [M], grad_u [M][2][2]; backward ACCUMULATES gX,gU. */
 int hfem_quad4_eval_fwd(int device, const double *X, const double *U, const int32_t *conn4,

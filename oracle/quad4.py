@@ -14,8 +14,10 @@ XI = torch.tensor([-1.0, 1.0, 1.0, -1.0])      # local nodes CCW from (-1,-1)
 ETA = torch.tensor([-1.0, -1.0, 1.0, 1.0])
 
 
-def quad4_forward(coords, u_full, conn4, x_eval, elem_id):
-    """-> u_h [M,2], detJ [M], grad_u [M,2,2] at (xi, eta) in [-1,1]^2."""
+def quad4_forward(coords, u_full, conn4, x_eval, elem_id, convention="reference"):
+    """-> u_h [M,2], detJ [M], grad_u [M,2,2] at (xi, eta) in [-1,1]^2.  ``convention="physical"`` is the OPT-IN
+    switch of the build (dN_dx = Jinv^T dN_dxi) -- not the reference's formula -- so that the
+    physical-convention QUAD4 kernels have an autograd checker too."""
     dt = coords.dtype
     xi, eta = x_eval[:, 0:1], x_eval[:, 1:2]
     xk, ek = XI.to(dt)[None, :], ETA.to(dt)[None, :]
@@ -27,7 +29,10 @@ def quad4_forward(coords, u_full, conn4, x_eval, elem_id):
     Jmat = torch.einsum("mki,mjk->mij", nodes, dN_dxi)                # J[i][j] = sum_k x_k[i] D_N[j][k]
     detJ = torch.linalg.det(Jmat)
     Jinv = torch.linalg.inv(Jmat)
-    dN_dx = torch.einsum("mij,mjk->mik", Jinv, dN_dxi)                # reference convention (F4)
+    if convention == "physical":
+        dN_dx = torch.einsum("mji,mjk->mik", Jinv, dN_dxi)            # Jinv^T: the physical gradient (opt-in)
+    else:
+        dN_dx = torch.einsum("mij,mjk->mik", Jinv, dN_dxi)            # reference convention (F4)
     grad_u = torch.einsum("mai,mja->mij", u_nodes, dN_dx)
     return u_h, detJ, grad_u
 
@@ -38,7 +43,7 @@ def gauss_2x2(dtype=torch.float64):
     return torch.stack([torch.stack([-g, -g]), torch.stack([g, -g]), torch.stack([-g, g]), torch.stack([g, g])])
 
 
-def quad4_domain_energy(coords, u_full, conn4, C, b_force=None):
+def quad4_domain_energy(coords, u_full, conn4, C, b_force=None, convention="reference"):
     """sum_e sum_{2x2 Gauss} w |detJ| (psi - b(xi_q).u_h)  (weights 1, points +-1/sqrt(3)); ``b_force`` receives
     the REFERENCE points, as the reference's triangle path does (loss.py:60,80)."""
     dt = coords.dtype
@@ -47,7 +52,7 @@ def quad4_domain_energy(coords, u_full, conn4, C, b_force=None):
     ne = conn4.shape[0]
     x_eval = pts.unsqueeze(0).expand(ne, 4, 2).reshape(-1, 2)
     elem_id = torch.arange(ne).unsqueeze(1).repeat(1, 4).reshape(-1)
-    u_eval, detJ, grad_u = quad4_forward(coords, u_full, conn4, x_eval, elem_id)
+    u_eval, detJ, grad_u = quad4_forward(coords, u_full, conn4, x_eval, elem_id, convention)
     gx, gy = grad_u[:, 0, :], grad_u[:, 1, :]
     eps = torch.stack([gx[:, 0], gy[:, 1], 2 * (0.5 * (gx[:, 1] + gy[:, 0]))], dim=1)
     sig = eps @ C.T

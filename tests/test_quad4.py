@@ -198,3 +198,86 @@ def test_quad4_one_million_elements_runs_and_matches_sampled_oracle():
     assert abs(loss.item() - e_ref) <= 1e-12 * abs(e_ref)
     assert np.abs(gx.cpu().numpy() - gX_ref[~geom.numpy()]).max() <= 1e-10 * np.abs(gX_ref).max()
     assert np.abs(gu.cpu().numpy() - gU_ref[~bc.numpy()]).max() <= 1e-10 * np.abs(gU_ref).max()
+
+
+@pytest.mark.gpu
+def test_quad4_fp32_rows_physical_convention_and_deterministic_instances():
+    """The QUAD4 extension at TRI3's feature level: float-row instance for fp32 models (the reference's
+    default dtype, /root/reference/src/loss.py:16: rows widened on load, gradients rounded once, fp64 arithmetic),
+    grad_convention="physical" (G Jinv) and deterministic=True (node-centric fixed-order kernel, bit-identical run to run),
+    each with and without a body force, against the autograd restatement oracle/quad4.py.
+    PARITY UNPINNED BY THE REFERENCE (it has no QUAD4 element)."""
+    import copy
+    from oracle import quad4 as Q, ref_chain as R
+    from hidenn_fem_amd.mesh import structured_quad_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from conftest import b_force_fn
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_quad_mesh(61, 45, jitter=0.25, seed=4, dtype=F64)
+    torch.manual_seed(1)
+    m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+    with torch.no_grad():
+        m.u_free.mul_(50.0)
+    bf_gpu = lambda x: b_force_fn(x.cpu()).to(d)
+
+    def oracle(convention, bf):
+        xf = m.node_coords_free.detach().cpu().clone().requires_grad_(True)
+        uf = m.u_free.detach().cpu().clone().requires_grad_(True)
+        X = R.assemble_coords(coords.shape[0], ~geom, xf, geom, coords[geom])
+        U = R.assemble_u(coords.shape[0], ~bc, uf, bc, torch.tensor(0.0, dtype=F64))
+        ref = Q.quad4_domain_energy(X, U, conn, R.plane_stress_C(), bf, convention) - \
+            R.edge_energy(X, U, edges, *R.interval_gauss(2))
+        ref.backward()
+        return ref.item(), xf.grad, uf.grad
+
+    def run(lf, model, bf):
+        model.zero_grad()
+        loss = lf(model, b_force=bf)
+        loss.backward()
+        return loss.item(), model.node_coords_free.grad.detach().cpu().double(), model.u_free.grad.detach().cpu().double()
+    refs = {}
+    for conv in ("reference", "physical"):
+        for has_b in (False, True):
+            refs[(conv, has_b)] = oracle(conv, b_force_fn if has_b else None)
+            e_ref, gx_ref, gu_ref = refs[(conv, has_b)]
+            for det in (False, True):
+                lf = EnergyLoss2D(device=d, dtype=F64, grad_convention=conv, deterministic=det)
+                e, gx, gu = run(lf, m, bf_gpu if has_b else None)
+                assert abs(e - e_ref) <= 1e-12 * abs(e_ref), (conv, has_b, det)
+                assert (gx - gx_ref).abs().max() <= 1e-10 * gx_ref.abs().max(), (conv, has_b, det)
+                assert (gu - gu_ref).abs().max() <= 1e-10 * gu_ref.abs().max(), (conv, has_b, det)
+                if det:                                     # fixed order: the same bits again
+                    e2, gx2, gu2 = run(lf, m, bf_gpu if has_b else None)
+                    assert e2 == e and torch.equal(gx2, gx) and torch.equal(gu2, gu)
+    assert abs(refs[("physical", False)][0] - refs[("reference", False)][0]) > 1e-6 * abs(refs[("reference", False)][0]), \
+        "on a skewed mesh the two conventions differ"
+    # value_and_grad_ (the autograd-free path) takes the switches too
+    lf = EnergyLoss2D(device=d, dtype=F64, grad_convention="physical", deterministic=True)
+    assert abs(lf.value_and_grad_(m).item() - refs[("physical", False)][0]) <= 1e-12 * abs(refs[("physical", False)][0])
+    assert (m.u_free.grad.cpu() - refs[("physical", False)][2]).abs().max() <= 1e-10 * refs[("physical", False)][2].abs().max()
+    # ---- fp32 rows: the same values as the fp64 path on the same float numbers, rounded once
+    torch.manual_seed(1)
+    m32 = PiecewiseLinearShapeNN2D(coords.float(), conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                   neumann_edges=edges).to(d)
+    with torch.no_grad():
+        m32.u_free.mul_(50.0)
+    m64 = copy.deepcopy(m32).double()
+    for conv in ("reference", "physical"):
+        for has_b in (False, True):
+            lf32 = EnergyLoss2D(device=d, dtype=torch.float32, grad_convention=conv)
+            lf64 = EnergyLoss2D(device=d, dtype=F64, grad_convention=conv)
+            lf64._mat, lf64._W, lf64._ci, lf64._cj = lf32._mat, lf32._W, lf32._ci, lf32._cj   # the fp32 object's rounded constants
+            bf = (lambda x: b_force_fn(x.cpu().double()).to(d)) if has_b else None
+            l32, gx32, gu32 = run(lf32, m32, bf)
+            l64, gx64, gu64 = run(lf64, m64, bf)
+            assert m32.u_free.grad.dtype == torch.float32
+            assert abs(l32 - l64) <= 2e-7 * abs(l64)
+            for a, b in ((gx32, gx64), (gu32, gu64)):
+                want = b.float().double()
+                ulp = torch.finfo(torch.float32).eps * want.abs().clamp_min(1e-30)
+                assert ((a - want).abs() <= 1.01 * ulp).all(), (conv, has_b)
+    # autograd-free fp32 path
+    lf32 = EnergyLoss2D(device=d, dtype=torch.float32)
+    lv = lf32.value_and_grad_(m32)
+    assert m32.u_free.grad.dtype == torch.float32 and abs(lv.item() - run(lf32, copy.deepcopy(m32), None)[0]) <= 2e-7 * abs(lv.item())

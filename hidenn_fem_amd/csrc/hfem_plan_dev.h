@@ -146,6 +146,11 @@ struct PairLaunch {
 };
 int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
                      const AdamFuse &af);
+#ifdef HFEM_LAB
+// tri3_pair_lab.hip (lab build only): the instrumented copy of the paired-slot kernel (ablation bits, forced slot loops)
+int launch_tri3_pair_lab(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
+                         const AdamFuse &af);
+#endif
 // tri3_pair_pipe.hip: the same pass with tpw tiles per workgroup, software-pipelined; 1 = launched, 0 = no instance
 int launch_tri3_pair_pipe(const hfem_plan *plan, PairLaunch A, int n_tiles, int tpw, const LagSum &lag);
 // tri3_det.hip: fixed-order (bit-reproducible) energy + gradients; phys: the physical gradient convention

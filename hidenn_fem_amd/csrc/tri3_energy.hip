@@ -22,6 +22,15 @@
 #include "hfem_device.h"
 #include "hfem_plan_dev.h"
 
+#ifdef HFEM_LAB
+#define HFEM_LAB_SECTION 0           // in-kernel lab hooks (start staggers)
+#include "tri3_energy_lab.inc"
+#undef HFEM_LAB_SECTION
+#else
+#define HFEM_LAB_TILED_STAGGER(stagger_ticks, stagger_mode)
+#define HFEM_LAB_FAST_STAGGER(stagger_ticks, stagger_cfg)
+#endif
+
 namespace hfem {
 
 constexpr int kBlock = 256;   // 4 wavefronts
@@ -112,20 +121,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 #define HFEM_STAMP(I)                                                                              \
     if ((ABL & 64) && tid == 0) stamps[16 * (size_t)blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
     HFEM_STAMP(0)
-#ifdef HFEM_LAB
-    // Stagger the start of co-resident workgroups: all resident tiles otherwise gather at the same
-    // time and then compute at the same time (HBM idle while the VALU/LDS work, and vice versa).
-    if (stagger_ticks > 0) {
-        const unsigned b = blockIdx.x;
-        unsigned frac;   // 0..255
-        if (stagger_mode == 0) frac = ((b >> 8) * 37u) & 255u;                    // by dispatch round of 256
-        else if (stagger_mode == 1) frac = (b * 2654435761u) >> 24;              // hash
-        else frac = ((b >> 11) * 32u + ((b >> 8) & 7u) * 4u) & 255u;             // rounds of 2048, then 256
-        const long long wait = ((long long)stagger_ticks * frac) >> 8;           // 10 ns ticks (100 MHz)
-        const long long t_start = __builtin_amdgcn_s_memrealtime();
-        while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
-    }
-#endif
+    HFEM_LAB_TILED_STAGGER(stagger_ticks, stagger_mode)
     const TileDesc d = pd.tiles[tile_begin + slot];
     if ((ABL & 64) && tid == 0 && d.n_node >= 0) stamps[16 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
@@ -272,16 +268,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         return;
     }
     const int slot = xcd_tile(blockIdx.x, n_launch);
-#ifdef HFEM_LAB
-    // lab (hfem_set_option("fast_stagger")): phase offset between groups of co-resident workgroups, so that one
-    // group gathers while another is in its element stage.  stagger_cfg = bit | (groups - 1) << 8.
-    if (stagger_ticks > 0) {
-        const int grp = (blockIdx.x >> (stagger_cfg & 31)) & (stagger_cfg >> 8);
-        const long long wait = (long long)stagger_ticks * grp / (stagger_cfg >> 8);
-        const long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz: 10 ns ticks
-        while ((long long)__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(2);
-    }
-#endif
+    HFEM_LAB_FAST_STAGGER(stagger_ticks, stagger_cfg)
     // ---- row maps and element records from the tile index alone (uniform node / slot strides, plan.cpp), in flight together
     //      with the descriptor; unguarded loads (padding = valid rows / skip records), then the gather, all issued back to back.
     //      Round-2 ISA reading: guarded loads are basic blocks of their own and made desc -> maps -> rows three dependent trips.
@@ -432,226 +419,10 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
 }
 
 #ifdef HFEM_LAB
-// ------------------------------------------------------------------ persistent, pipelined
-// Same tile algorithm, but a workgroup walks a contiguous run of tiles and overlaps the HBM
-// phase of tile t+1 with the VALU/LDS phase of tile t (register-staged prefetch): the gather of
-// tile t+1 is issued right after the barrier that starts tile t's element loop and lands in VGPRs
-// while the loop runs; it is written to LDS when tile t's gradients have left.  The element loop
-// itself touches no VMEM-loaded register (its packed records are staged through LDS as well), so
-// the compiler places no vmcnt wait inside it and the prefetch really stays in flight.  Row-map
-// loads run two tiles ahead (three register sets) so that no gather waits on its own index load.
-// One partial energy per workgroup.
-//   NPT >= ceil(max nodes per tile / BLOCK), EPT >= ceil(max elements per tile / BLOCK).
-// LDS: xy[cap_nodes] double2 | uv[cap_nodes] double2 | acc[4][cap_owned] double | red[16] | pk[cap_elems] u32
-
-template <int BLOCK, int NPT, int EPT>
-__global__ __launch_bounds__(BLOCK) void tri3_energy_pipe_kernel(
-    PlanDev pd, int tile_begin, int n_tiles, const double2 *__restrict__ x_free,
-    const double2 *__restrict__ x_fixed, const double2 *__restrict__ u_free,
-    const double2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
-    double4 Tconst, double *__restrict__ partials, double2 *__restrict__ gx_free,
-    double2 *__restrict__ gu_free, int cap_nodes, int cap_owned, int skip_edges) {
-    extern __shared__ double2 lds[];
-    double2 *nd_xy = lds;
-    double2 *nd_uv = lds + cap_nodes;
-    double *acc0 = reinterpret_cast<double *>(lds + 2 * cap_nodes);
-    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
-    double *red = acc3 + cap_owned;
-    int *ldesc = reinterpret_cast<int *>(red + 16);                      // [kPipeMaxTiles][8]
-    uint32_t *lpk = reinterpret_cast<uint32_t *>(ldesc + 8 * kPipeMaxTiles);
-
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
-    const int tid = threadIdx.x;
-    const int G = gridDim.x;
-    const int w = xcd_tile(blockIdx.x, G);           // consecutive w share an XCD (L2 reuse of halos)
-    const int t0 = (int)(((long long)w * n_tiles) / G), t1 = (int)(((long long)(w + 1) * n_tiles) / G);
-    double e_loc = 0.0;
-
-    // this workgroup's tile descriptors -> LDS once (the loop then reads them with LDS loads, which
-    // the vmcnt counter -- and hence the in-flight prefetch -- does not see)
-    if (tid < 8 * (t1 - t0)) ldesc[tid] = reinterpret_cast<const int *>(pd.tiles + tile_begin + t0)[tid];
-    __syncthreads();
-#define HFEM_DESC(T, F) __builtin_amdgcn_readfirstlane(ldesc[8 * ((T) - t0) + (F)])
-    // TileDesc fields: 0 elem_off 1 n_elem 2 node_off 3 n_node 4 n_owned 5 edge_off 6 n_edge
-
-    if (t0 < t1) {
-        // tile descriptors are wave-uniform scalars (SGPRs).
-        // d_: tile t (staged in LDS)   q_: tile t+1 (gather target)   row maps: s = t, s1 = t+1, s2 = t+2
-        // Every prefetch load below is STRAIGHT-LINE code: lanes without work clamp to row 0 and
-        // "no next tile" is a zero-sized sentinel tile.  hipcc can then count the loads in flight and
-        // emits exact vmcnt(N) waits instead of draining the queue with vmcnt(0) (which it does as
-        // soon as a VMEM op sits under a branch).
-        int d_n_node, d_n_owned, d_n_elem, d_edge_off, d_n_edge;
-        int q_n_node, q_n_owned, q_elem_off, q_n_elem, q_edge_off, q_n_edge;
-        int2 s[NPT], s1[NPT], s2[NPT];
-        static_assert(NPT <= 4, "prefetch registers are named scalars (double2 arrays end up in scratch)");
-        double2 xy0, xy1, xy2, xy3, uv0, uv1, uv2, uv3;
-        xy0 = xy1 = xy2 = xy3 = uv0 = uv1 = uv2 = uv3 = make_double2(0.0, 0.0);
-        uint32_t pkr[EPT];
-        const int2 *nsrc = pd.node_src;
-        const uint32_t *epk = pd.elem_pack;
-#define HFEM_GATHER1(J, XY, UV, SRC, NN)                                                           \
-    if (J < NPT) {                                                                                 \
-        const bool ok = tid + J * BLOCK < (NN);                                                    \
-        const int ix = ok ? SRC[J < NPT ? J : 0].x : 0, iu = ok ? SRC[J < NPT ? J : 0].y : 0;      \
-        XY = *(ix >= 0 ? x_free + ix : x_fixed + ~ix);                                             \
-        UV = *(iu >= 0 ? u_free + iu : u_fixed + ~iu);                                             \
-    }
-#define HFEM_GATHER(SRC, NN)                                                                       \
-    HFEM_GATHER1(0, xy0, uv0, SRC, NN) HFEM_GATHER1(1, xy1, uv1, SRC, NN)                          \
-    HFEM_GATHER1(2, xy2, uv2, SRC, NN) HFEM_GATHER1(3, xy3, uv3, SRC, NN)
-#define HFEM_LOAD_SRC(DST, OFF, NN)                                                                \
-    _Pragma("unroll") for (int j = 0; j < NPT; ++j) {                                              \
-        const int l = tid + j * BLOCK;                                                             \
-        DST[j] = nsrc[(OFF) + (l < (NN) ? l : 0)];                                                 \
-    }
-#define HFEM_LOAD_PK(OFF, NN)                                                                      \
-    _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
-        const int i = tid + j * BLOCK;                                                             \
-        pkr[j] = epk[(OFF) + (i < (NN) ? i : 0)];                                                  \
-    }
-#define HFEM_STAGE1(J, XY, UV)                                                                     \
-    if (J < NPT) {                                                                                 \
-        const int l = tid + J * BLOCK;                                                             \
-        if (l < d_n_node) { nd_xy[l] = XY; nd_uv[l] = UV; }                                        \
-        if (l < d_n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }         \
-    }
-#define HFEM_STAGE()                                                                               \
-    HFEM_STAGE1(0, xy0, uv0) HFEM_STAGE1(1, xy1, uv1) HFEM_STAGE1(2, xy2, uv2) HFEM_STAGE1(3, xy3, uv3) \
-    _Pragma("unroll") for (int j = 0; j < EPT; ++j) {                                              \
-        const int i = tid + j * BLOCK;                                                             \
-        if (i < d_n_elem) lpk[i] = pkr[j];                                                         \
-    }
-        {
-            const int c_elem_off = HFEM_DESC(t0, 0), c_node_off = HFEM_DESC(t0, 2);
-            d_n_elem = HFEM_DESC(t0, 1); d_n_node = HFEM_DESC(t0, 3); d_n_owned = HFEM_DESC(t0, 4);
-            d_edge_off = HFEM_DESC(t0, 5); d_n_edge = HFEM_DESC(t0, 6);
-            const bool hn = t0 + 1 < t1;
-            const int tq = hn ? t0 + 1 : t0;
-            const int q_node_off = hn ? HFEM_DESC(tq, 2) : 0;
-            q_elem_off = hn ? HFEM_DESC(tq, 0) : 0; q_n_elem = hn ? HFEM_DESC(tq, 1) : 0;
-            q_n_node = hn ? HFEM_DESC(tq, 3) : 0; q_n_owned = hn ? HFEM_DESC(tq, 4) : 0;
-            q_edge_off = hn ? HFEM_DESC(tq, 5) : 0; q_n_edge = hn ? HFEM_DESC(tq, 6) : 0;
-            HFEM_LOAD_SRC(s, c_node_off, d_n_node)
-            HFEM_LOAD_SRC(s1, q_node_off, q_n_node)
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) s2[j] = make_int2(0, 0);
-            HFEM_LOAD_PK(c_elem_off, d_n_elem)
-            HFEM_GATHER(s, d_n_node)
-            HFEM_STAGE()          // the gather is the youngest load: this wait retires everything above
-        }
-
-        for (int t = t0; t < t1; ++t) {
-            __syncthreads();                       // tile t is staged
-            // ---- issue tile t+1's gather + element records and tile t+2's row maps: they land
-            //      while the element loop runs (nothing in that loop waits on vmcnt)
-            {
-                const bool hn2 = t + 2 < t1;
-                const int tr = hn2 ? t + 2 : t;
-                const int r_node_off = hn2 ? HFEM_DESC(tr, 2) : 0, r_n_node = hn2 ? HFEM_DESC(tr, 3) : 0;
-                HFEM_GATHER(s1, q_n_node)
-                HFEM_LOAD_PK(q_elem_off, q_n_elem)
-                HFEM_LOAD_SRC(s2, r_node_off, r_n_node)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- elements of tile t: LDS in, LDS out -- no VMEM dependence
-            const int n_owned = d_n_owned;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                const int i = tid + j * BLOCK;
-                if (i < d_n_elem && !(lpk[i] & kSkipBit)) {
-                    const uint32_t p = lpk[i];
-                    const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask),
-                              l2 = (int)((p >> (2 * kLocalBits)) & kLocalMask);
-                    double2 gx[3], gu[3];
-                    const double e = tri3_element<true>(nd_xy[l0], nd_xy[l1], nd_xy[l2], nd_uv[l0], nd_uv[l1],
-                                                        nd_uv[l2], k, gx, gu);
-                    if (p & kHomeBit) e_loc += e;
-                    if (l0 < n_owned) {
-                        unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
-                        unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
-                    }
-                    if (l1 < n_owned) {
-                        unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
-                        unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
-                    }
-                    if (l2 < n_owned) {
-                        unsafeAtomicAdd(&acc0[l2], gx[2].x); unsafeAtomicAdd(&acc1[l2], gx[2].y);
-                        unsafeAtomicAdd(&acc2[l2], gu[2].x); unsafeAtomicAdd(&acc3[l2], gu[2].y);
-                    }
-                }
-            }
-            const int n_edge = skip_edges ? 0 : d_n_edge;
-            for (int i = tid; i < n_edge; i += BLOCK) {      // boundary tiles only
-                const uint32_t p = pd.edge_pack[d_edge_off + i];
-                const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
-                const double4 tt = T_edge ? T_edge[pd.edge_gid[d_edge_off + i]] : Tconst;
-                double2 gx[2], gu[2];
-                const double wk = edge2_element<true>(nd_xy[l0], nd_xy[l1], nd_uv[l0], nd_uv[l1], tt, gx, gu);
-                if (p & kHomeBit) e_loc -= wk;
-                if (l0 < n_owned) {
-                    unsafeAtomicAdd(&acc0[l0], gx[0].x); unsafeAtomicAdd(&acc1[l0], gx[0].y);
-                    unsafeAtomicAdd(&acc2[l0], gu[0].x); unsafeAtomicAdd(&acc3[l0], gu[0].y);
-                }
-                if (l1 < n_owned) {
-                    unsafeAtomicAdd(&acc0[l1], gx[1].x); unsafeAtomicAdd(&acc1[l1], gx[1].y);
-                    unsafeAtomicAdd(&acc2[l1], gu[1].x); unsafeAtomicAdd(&acc3[l1], gu[1].y);
-                }
-            }
-            __syncthreads();                       // all accumulation of tile t done
-            // ---- tail.  Order matters for the vmcnt counter (in order, loads and stores together):
-            //      A store addresses  B accumulators -> registers  C stage tile t+1 (waits for the
-            //      prefetch; no store is pending yet)  D rotate row maps  E issue the stores LAST, so
-            //      they drain under the next tile's element loop.
-            double2 ogx[NPT], ogu[NPT];
-            int rx[NPT], ru[NPT];                  // destination rows (-1: nothing to store); no pointer arrays (scratch)
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) {
-                const int l = tid + j * BLOCK;
-                rx[j] = (l < n_owned && gx_free && s[j].x >= 0) ? s[j].x : -1;                        // A
-                ru[j] = (l < n_owned && gu_free && s[j].y >= 0) ? s[j].y : -1;
-                ogx[j] = ogu[j] = make_double2(0.0, 0.0);
-                if (l < n_owned) {                                                                   // B
-                    ogx[j] = make_double2(acc0[l], acc1[l]);
-                    ogu[j] = make_double2(acc2[l], acc3[l]);
-                }
-            }
-            d_n_node = q_n_node; d_n_owned = q_n_owned; d_n_elem = q_n_elem; d_edge_off = q_edge_off;    // C
-            d_n_edge = q_n_edge;
-            HFEM_STAGE()
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) { s[j] = s1[j]; s1[j] = s2[j]; }                          // D
-            {
-                const bool hn2 = t + 2 < t1;
-                const int tr = hn2 ? t + 2 : t;
-                q_elem_off = hn2 ? HFEM_DESC(tr, 0) : 0; q_n_elem = hn2 ? HFEM_DESC(tr, 1) : 0;
-                q_n_node = hn2 ? HFEM_DESC(tr, 3) : 0; q_n_owned = hn2 ? HFEM_DESC(tr, 4) : 0;
-                q_edge_off = hn2 ? HFEM_DESC(tr, 5) : 0; q_n_edge = hn2 ? HFEM_DESC(tr, 6) : 0;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) {                                                          // E (sc1, branch-free:
-                const double2 vx = ogx[j], vu = ogu[j];            // idle lanes pass an out-of-range offset, dropped by the hardware)
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&vx), rsx,
-                                                       rx[j] >= 0 ? rx[j] * 16 : (int)0x80000000, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&vu), rsu,
-                                                       ru[j] >= 0 ? ru[j] * 16 : (int)0x80000000, 0, 16);
-            }
-        }
-#undef HFEM_GATHER
-#undef HFEM_GATHER1
-#undef HFEM_STAGE1
-#undef HFEM_LOAD_SRC
-#undef HFEM_LOAD_PK
-#undef HFEM_STAGE
-    }
-#undef HFEM_DESC
-    const double tot = block_sum(e_loc, red);
-    if (tid == 0) partials[blockIdx.x] = tot;
-}
-#endif  // HFEM_LAB
+#define HFEM_LAB_SECTION 1           // persistent pipelined variant (lab build only)
+#include "tri3_energy_lab.inc"
+#undef HFEM_LAB_SECTION
+#endif
 
 // Deterministic sum of the per-tile partial energies (fixed order).
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double *__restrict__ partials, int n,
@@ -696,12 +467,9 @@ struct Defaults {
 } g_def;
 
 #ifdef HFEM_LAB
-int g_tiled_ablate = 0, g_tiled_stagger = 0, g_tiled_stagger_mode = 0;
-int g_fast_stagger = 0, g_fast_stagger_shift = 8, g_fast_stagger_groups = 4;
-int g_tiled_pipe = 0;      // k > 0: persistent pipelined kernel, k workgroups per CU
-int g_tri3_stream = 0;     // chunked plans take the streamed kernel (tri3_stream.hip)
-int g_stream_ablate = 0;
-int g_pair_chain = -1, g_pair_ablate = 0;   // pair kernel: force the slot loop (0 plain, 1 carrying), ablation bits
+#define HFEM_LAB_SECTION 2           // lab knobs
+#include "tri3_energy_lab.inc"
+#undef HFEM_LAB_SECTION
 #endif
 
 hfem_plan::Tune current_tune() {
@@ -788,61 +556,15 @@ bool launch_fast_f64(const hfem_plan *plan, const Tri3Launch &A, int n, bool has
 }
 
 #ifdef HFEM_LAB
-// lab variants of the TRI3 plan launch (ablations, stamps, pipelined and streamed kernels).  true: launched.
-bool launch_tri3_lab(const hfem_plan *plan, Tri3Launch &A, int n, bool hasb, const LagSum &lag, int *n_partials) {
-    const HostPlan &h = plan->host;
-    const int blk = plan->tune.tiled_block, abl = g_tiled_ablate;
-    if (g_tiled_pipe > 0 && abl == 0) {
-        int G = std::min(g_tiled_pipe * 256, n);
-        if ((n + G - 1) / G > kPipeMaxTiles) G = (n + kPipeMaxTiles - 1) / kPipeMaxTiles;
-#define HFEM_LAUNCH_PIPE(BLK, NPT, EPT)                                                                                  \
-    {                                                                                                                    \
-        hipLaunchKernelGGL((tri3_energy_pipe_kernel<BLK, NPT, EPT>), dim3(G), dim3(BLK), (size_t)plan->lds_bytes_pipe,   \
-                           A.s, A.pd, A.tile_begin, n, (const double2 *)A.x_free, (const double2 *)A.x_fixed,            \
-                           (const double2 *)A.u_free, (const double2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials,       \
-                           (double2 *)A.gx, (double2 *)A.gu, h.max_nodes, h.max_owned, A.skip_edges);                    \
-        *n_partials = G;                                                                                                 \
-        return true;                                                                                                     \
-    }
-        if (A.x_free && A.u_free && h.nn > 0 && h.ne > 0) {      // clamped (branch-free) prefetch loads read row 0
-            if (blk == 256 && h.max_nodes <= 512 && h.max_elems <= 3 * 256) HFEM_LAUNCH_PIPE(256, 2, 3)
-            if (blk == 256 && h.max_nodes <= 1024 && h.max_elems <= 6 * 256) HFEM_LAUNCH_PIPE(256, 4, 6)
-            if (blk == 512 && h.max_nodes <= 512 && h.max_elems <= 2 * 512) HFEM_LAUNCH_PIPE(512, 1, 2)
-            if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 3 * 512) HFEM_LAUNCH_PIPE(512, 2, 3)
-            if (blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 4 * 512) HFEM_LAUNCH_PIPE(512, 2, 4)
-            if (blk == 1024 && h.max_nodes <= 1024 && h.max_elems <= 2 * 1024) HFEM_LAUNCH_PIPE(1024, 1, 2)
-        }
-#undef HFEM_LAUNCH_PIPE
-    }
-    if (abl == 64 && plan->tune.tiled_fast && blk == 512 && h.max_nodes <= 1024 && h.max_elems <= 2048) {
-        launch_fast<512, 2, 4, false, 16, double2, 0, false, false, true>(A, n, AdamFuse{}, LagSum{});   // stamped instance
-        return true;
-    }
-    if (abl == 0 && g_tri3_stream && !hasb && blk == 512 &&
-        launch_tri3_stream(plan, n + (lag.prev ? 1 : 0), A.tile_begin, (const double *)A.x_free, (const double *)A.x_fixed,
-                           (const double *)A.u_free, (const double *)A.u_fixed, A.k, (const double *)A.T_edge, A.tc,
-                           A.partials, (double *)A.gx, (double *)A.gu, A.skip_edges, plan->tune.store_policy, lag, A.s,
-                           g_stream_ablate) == 1)
-        return true;
-    if (abl != 0) {      // ablations of the generic loop kernel at 256 / 512 threads
-#define HFEM_LAUNCH_ABL(BLK, ABL)                                                                                        \
-    hipLaunchKernelGGL((tri3_energy_tiled_kernel<BLK, ABL>), dim3(n), dim3(BLK), A.lds, A.s, A.pd, A.tile_begin,          \
-                       (const double2 *)A.x_free, (const double2 *)A.x_fixed, (const double2 *)A.u_free,                 \
-                       (const double2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (double2 *)A.gx, (double2 *)A.gu,    \
-                       A.max_nodes, A.max_owned, A.skip_edges, g_tiled_stagger, g_tiled_stagger_mode, A.stamps)
-#define HFEM_ABL_CASE(V) case V: if (blk == 512) HFEM_LAUNCH_ABL(512, V); else HFEM_LAUNCH_ABL(256, V); return true;
-        switch (abl) {
-            HFEM_ABL_CASE(1) HFEM_ABL_CASE(2) HFEM_ABL_CASE(4) HFEM_ABL_CASE(6) HFEM_ABL_CASE(8) HFEM_ABL_CASE(5)
-            HFEM_ABL_CASE(13) HFEM_ABL_CASE(128) HFEM_ABL_CASE(384) HFEM_ABL_CASE(640) HFEM_ABL_CASE(129) HFEM_ABL_CASE(64)
-            HFEM_ABL_CASE(10) HFEM_ABL_CASE(14) HFEM_ABL_CASE(32) HFEM_ABL_CASE(48) HFEM_ABL_CASE(16)
-            default: break;
-        }
-#undef HFEM_ABL_CASE
-#undef HFEM_LAUNCH_ABL
-    }
-    return false;
-}
-#endif  // HFEM_LAB
+#define HFEM_LAB_SECTION 3           // lab launches + the hooks used below
+#include "tri3_energy_lab.inc"
+#undef HFEM_LAB_SECTION
+#else
+#define HFEM_LAB_UPLOAD_STAMPS(raw, h, rc)
+#define HFEM_LAB_REFRESH_TUNE(plan)
+#define HFEM_LAB_TRI3_LAUNCH(plan, A, n, hasb, phys, lag, n_partials, launched)
+#define HFEM_LAB_PAIR_LAUNCH(plan, P, n, hasb, phys, lag, rc_pair)
+#endif
 
 // Host-side launch state of a plan (partials bank of the lagged loss sum).  One plan = one stream at a time: the state
 // is guarded by the plan's mutex, and a HFEM_FLAG_SUM_PREVIOUS launch must come on the stream that left the partials.
@@ -982,9 +704,7 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
         if (!rc && !h.tile_chunks.empty()) rc = hfem_upload(&raw->d_tile_chunks, h.tile_chunks.data(), h.tile_chunks.size() / 4, raw->device_bytes);
         if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
-#ifdef HFEM_LAB
-        if (!rc) rc = hfem_upload(&raw->d_stamps, nullptr, (h.tiles.size() + 1) * 16, raw->device_bytes);
-#endif
+        HFEM_LAB_UPLOAD_STAMPS(raw, h, rc)
         if (!rc && p->lds_bytes > 64 * 1024) {
             set_error("plan: tile needs more than 64 KiB of LDS");
             rc = -1;
@@ -1067,9 +787,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
     if (int rc = use_device(plan->device)) return rc;
     PlanLock lock(plan);
-#ifdef HFEM_LAB
-    plan->tune = current_tune();              // lab tooling flips options between launches on one plan (single-threaded)
-#endif
+    HFEM_LAB_REFRESH_TUNE(plan)
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
     const double4 tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
@@ -1119,30 +837,18 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
         A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
         bool launched = false;
-#ifdef HFEM_LAB
-        A.stagger = g_fast_stagger >= 0 ? g_fast_stagger : (n >= 768 ? 150 : 0);
-        A.stagger_cfg = g_fast_stagger_shift | ((g_fast_stagger_groups - 1) << 8);
-        if (!phys) launched = launch_tri3_lab(plan, A, n, hasb, lag, &n_partials);
-#endif
+        HFEM_LAB_TRI3_LAUNCH(plan, A, n, hasb, phys, lag, n_partials, launched)
         if (!launched && h.paired) {      // paired plan (plan_elem_order 5, the default): its records are the pair kernel's
             PairLaunch P;
             P.grid = n + (lag.prev ? 1 : 0); P.tile_begin = (int)tile_begin;
             P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
             P.k = A.k; P.T_edge = A.T_edge; P.tc = tc; P.partials = A.partials; P.gx = A.gx; P.gu = A.gu;
             P.skip_edges = A.skip_edges; P.s = s;
-#ifdef HFEM_LAB
-            P.chain = g_pair_chain; P.lab_bits = g_pair_ablate;
-#endif
+
             HFEM_ARG_CHECK(!(lag.prev && (hasb || phys)), "HFEM_FLAG_SUM_PREVIOUS: default forces and convention only");
             if (plan->span_buf) P.span = plan->span_buf + (size_t)(plan->span_next++ % plan->span_slots) * 2 * (size_t)nt;
             int rc_pair = 0;
-#ifdef HFEM_LAB
-            if (plan->tune.pair_tiles_per_wg > 1 && !hasb && !phys) {
-                P.grid = 0;
-                rc_pair = launch_tri3_pair_pipe(plan, P, n, plan->tune.pair_tiles_per_wg, lag);
-                P.grid = n + (lag.prev ? 1 : 0);
-            }
-#endif
+            HFEM_LAB_PAIR_LAUNCH(plan, P, n, hasb, phys, lag, rc_pair)
             if (!rc_pair) rc_pair = launch_tri3_pair(plan, P, (hasb || phys) ? 1 : 0, hasb, phys, lag, AdamFuse{});
             HFEM_ARG_CHECK(rc_pair == 1, "paired plan: tile shape outside the pair kernel's instances");
             launched = true;
@@ -1444,54 +1150,9 @@ extern "C" int hfem_set_option(const char *name, int value) {
         g_def.plan_snap = value;
         set_plan_snap(value);
 #ifdef HFEM_LAB
-    } else if (n == "tiled_ablate") {
-        g_tiled_ablate = value;
-    } else if (n == "tiled_stagger") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 100000, "tiled_stagger is in 10 ns ticks, 0..100000");
-        g_tiled_stagger = value;
-    } else if (n == "tiled_stagger_mode") {
-        g_tiled_stagger_mode = value;
-    } else if (n == "fast_stagger") {
-        HFEM_ARG_CHECK(value >= -1 && value <= 100000, "fast_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
-        g_fast_stagger = value;
-    } else if (n == "fast_stagger_shift") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 20, "fast_stagger_shift: bit of the workgroup index, 0..20");
-        g_fast_stagger_shift = value;
-    } else if (n == "fast_stagger_groups") {
-        HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "fast_stagger_groups: 2, 4 or 8");
-        g_fast_stagger_groups = value;
-    } else if (n == "tiled_pipe") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 8, "tiled_pipe must be 0..8 workgroups per CU");
-        g_tiled_pipe = value;
-    } else if (n == "tri3_stream") {
-        g_tri3_stream = value ? 1 : 0;
-    } else if (n == "stream_ablate") {
-        g_stream_ablate = value;
-    } else if (n == "pair_pipe_wps") {
-        HFEM_ARG_CHECK(value == 3 || value == 4, "pair_pipe_wps must be 3 or 4");
-        g_def.pair_pipe_wps = value;
-    } else if (n == "pair_tiles_per_wg") {
-        HFEM_ARG_CHECK(value >= 1 && value <= 16, "pair_tiles_per_wg must be 1..16");
-        g_def.pair_tiles_per_wg = value;
-    } else if (n == "pair_chain") {
-        g_pair_chain = value;
-    } else if (n == "pair_ablate") {
-        g_pair_ablate = value;
-    } else if (n == "quad4_stagger") {
-        HFEM_ARG_CHECK(value >= -1 && value <= 100000, "quad4_stagger is in 10 ns ticks, 0..100000 (-1: auto)");
-        g_quad4_stagger = value;
-    } else if (n == "quad4_stagger_groups") {
-        HFEM_ARG_CHECK(value == 2 || value == 4 || value == 8, "quad4_stagger_groups: 2, 4 or 8");
-        g_quad4_stagger_groups = value;
-    } else if (n == "quad4_stagger_shift") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 20, "quad4_stagger_shift: bit of the workgroup index, 0..20");
-        g_quad4_stagger_shift = value;
-    } else if (n == "quad4_pipe") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 8, "quad4_pipe: 0 (one workgroup per tile) or 1..8 persistent workgroups per CU");
-        g_quad4_pipe = value;
-    } else if (n == "quad4_ablate") {
-        HFEM_ARG_CHECK(value >= 0 && value <= 4, "quad4_ablate: lab variants 0..4");
-        g_quad4_ablate = value;
+#define HFEM_LAB_SECTION 4
+#include "tri3_energy_lab.inc"
+#undef HFEM_LAB_SECTION
 #endif
     } else {
         set_error("hfem_set_option: unknown option '" + n + "' (lab knobs need libhidenn_hip_lab.so)");
@@ -1525,18 +1186,9 @@ extern "C" int hfem_get_option(const char *name) {
 #endif
     }
 #ifdef HFEM_LAB
-    if (n == "tiled_ablate") return g_tiled_ablate;
-    if (n == "tiled_stagger") return g_tiled_stagger;
-    if (n == "tiled_stagger_mode") return g_tiled_stagger_mode;
-    if (n == "fast_stagger") return g_fast_stagger;
-    if (n == "tiled_pipe") return g_tiled_pipe;
-    if (n == "tri3_stream") return g_tri3_stream;
-    if (n == "stream_ablate") return g_stream_ablate;
-    if (n == "pair_chain") return g_pair_chain;
-    if (n == "pair_ablate") return g_pair_ablate;
-    if (n == "quad4_stagger") return g_quad4_stagger;
-    if (n == "quad4_pipe") return g_quad4_pipe;
-    if (n == "quad4_ablate") return g_quad4_ablate;
+#define HFEM_LAB_SECTION 5
+#include "tri3_energy_lab.inc"
+#undef HFEM_LAB_SECTION
 #endif
     return -1;
 }

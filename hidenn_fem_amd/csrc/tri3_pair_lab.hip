@@ -1,3 +1,9 @@
+// LAB BUILD ONLY (-DHFEM_LAB, libhidenn_hip_lab.so): the instrumented copy of the paired-slot kernel -- the ablation bits
+// (HFEM_PAIR_LAB), the lane-chain cost model and the forced slot loops that scripts/ drives (hfem_set_option "pair_ablate",
+// "pair_chain").  The product kernel (tri3_pair.hip) carries none of it; this copy is what the ablation ladders of DESIGN.md
+// section 4.1 were measured with, fp64 reference-convention instances only.  Nothing in this file is compiled into
+// libhidenn_hip.so.
+#ifdef HFEM_LAB
 // Paired-slot TRI3 + EDGE2 energy kernel, gfx950 (MI355X): the tiled owner-computes pass of tri3_energy.hip with FEWER
 // LDS ATOMICS per element.
 //
@@ -18,6 +24,12 @@
 
 namespace hfem {
 
+#ifdef HFEM_LAB
+#define HFEM_PAIR_LAB(bit) (lab_bits & (bit))          /* ablations: 1 no atomics, 2 no slot phase, 4 no write-out, 8 no gather loads, 16 return at once, 32 return after the row-map loads, 64 after the record loads, 128 after the first barrier, 256 no tile-energy store, 512 no edges, 1024 no record loads, 2048 no LDS fill, 4096 lane-chain cost model (8 atomics + DPP), 8192 8 atomics only */
+#else
+#define HFEM_PAIR_LAB(bit) false
+#endif
+
 // BLOCK threads per tile; NPT >= ceil(max nodes / BLOCK), EPT >= ceil(max slots / BLOCK).  WPS = waves per SIMD the
 // register budget is sized for.  Measured best on T1M (round 2, profiles/r02): 256 threads, three slots per thread,
 // 86 VGPRs, four workgroups per CU -- 9.5 us against 11.2 us for the one-element-per-slot kernel at 512 threads.
@@ -27,12 +39,12 @@ namespace hfem {
 // torch.optim.Adam's update instead of storing the gradient (AdamFuse, hfem_tri3_energy_adam_step).
 template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
           bool ADAM = false, bool CHAIN = false, int CAPN = 0>
-__global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
+__global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_lab_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
     const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     V2 *__restrict__ gx_free, V2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    LagSum lag, AdamFuse af, int col_stride) {
+    LagSum lag, AdamFuse af, int col_stride, int lab_bits) {
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     const int cap_n = CAPN > 0 ? CAPN : cap_nodes;       // CAPN > 0: the uv array's offset folds into the ds_read immediates
     extern __shared__ double2 lds[];
@@ -52,6 +64,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         if (tid == 0) lag.out[0] = tot;
         return;
     }
+    if (HFEM_PAIR_LAB(16)) return;                      // lab: dispatch cost of this grid shape alone
     const int slot = xcd_tile(blockIdx.x, n_launch);
     // span stamps (hfem_plan_set_span_stamps, off by default): when this workgroup started -- scalar registers only
     unsigned long long t_start = 0;
@@ -63,12 +76,19 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
 #pragma unroll
     for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];      // lanes past the stride repeat its last record
     const TileDesc d = pd.tiles[tile_begin + slot];     // scalar loads, in flight with the row maps
+    if (HFEM_PAIR_LAB(32)) {                            // lab: + one round of index loads
+        int acc = d.n_node;
+        for (int j = 0; j < NPT; ++j) acc += s[j].x;
+        if (acc == 0x7fffffff) partials[slot] = 1.0;
+        return;
+    }
     // ---- slot records, from the tile index alone as well (uniform slot stride; column stride `col_stride` is the plan's):
     //      thread t walks column t, row j at j * col_stride + t.  Unguarded; what lies past n_elem is masked below.
     uint32_t w0[EPT], w1[EPT];
     const size_t rec0 = (size_t)(tile_begin + slot) * pd.elem_stride;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
+        if (HFEM_PAIR_LAB(1024)) { w0[j] = kSkipBit | tid; w1[j] = 0u; continue; }
         const size_t i = rec0 + min(tid + j * col_stride, pd.elem_stride - 1);
         w0[j] = pd.elem_pack[i];
         w1[j] = pd.elem_pack_hi[i];
@@ -79,13 +99,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     for (int j = 0; j < NPT; ++j) {
         const V2 *px = s[j].x >= 0 ? x_free + s[j].x : x_fixed + ~s[j].x;
         const V2 *pu = s[j].y >= 0 ? u_free + s[j].y : u_fixed + ~s[j].y;
+        if (HFEM_PAIR_LAB(8)) { vx[j].x = vx[j].y = (decltype(vx[j].x))(0.001 * tid); vu[j] = vx[j]; continue; }
         vx[j] = *px;
         vu[j] = *pu;
     }
     __builtin_amdgcn_sched_barrier(0);                  // all gather loads are issued before the first is waited for
     const int n_owned = d.n_owned;
     // boundary tiles: their Neumann-edge records now, not after the slot loop (a late dependent load on the critical path)
-    const int n_edge = skip_edges ? 0 : d.n_edge;
+    const int n_edge = (skip_edges || HFEM_PAIR_LAB(512)) ? 0 : d.n_edge;
     uint32_t edge_rec = 0u;
     int edge_id = 0;
     if (tid < n_edge) {
@@ -95,9 +116,17 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
         if (!(tid < col_stride && tid + j * col_stride < d.n_elem)) { w0[j] = kSkipBit; w1[j] = 0u; }
+    if (HFEM_PAIR_LAB(64)) {                            // lab: + the slot-record loads (second dependent round)
+        uint32_t acc = 0;
+        for (int j = 0; j < EPT; ++j) acc += w0[j] ^ w1[j];
+        for (int j = 0; j < NPT; ++j) acc += (uint32_t)s[j].x;
+        if (acc == 0x7fffffffu) partials[slot] = 1.0;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
+        if (HFEM_PAIR_LAB(2048)) continue;
         if (l < d.n_node) {
             nd_xy[l] = make_double2((double)vx[j].x, (double)vx[j].y);
             nd_uv[l] = make_double2((double)vu[j].x, (double)vu[j].y);
@@ -105,13 +134,21 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     __syncthreads();
+    if (HFEM_PAIR_LAB(128)) {                           // lab: + LDS fill and the first barrier
+        uint32_t acc = 0;
+        for (int j = 0; j < EPT; ++j) acc += w0[j] ^ w1[j];
+        if (acc == 0x7fffffffu || nd_xy[tid].x == 1.2345) partials[slot] = 1.0;
+        return;
+    }
 
     auto add_row = [&](int l, const double2 gx, const double2 gu) {
+        if (HFEM_PAIR_LAB(1)) return;
         unsafeAtomicAdd(&acc0[l], gx.x); unsafeAtomicAdd(&acc1[l], gx.y);
         unsafeAtomicAdd(&acc2[l], gu.x); unsafeAtomicAdd(&acc3[l], gu.y);
     };
     double e_loc = 0.0;
-    if (!CHAIN) {
+    if (HFEM_PAIR_LAB(2)) {
+    } else if (!CHAIN) {
     // ---- slots: registers + LDS only
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -125,7 +162,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
                 double2 gx[3], gu[3];
                 const double e = tri3_element<true, HASB, PHYS>(Xn, nd_xy[lb], Xc, Un, nd_uv[lb], Uc, k, gx, gu);
                 if (p & kHomeBit) e_loc += e;
-                if (lb < n_owned) add_row(lb, gx[1], gu[1]);
+                if (lb < n_owned && !HFEM_PAIR_LAB(4096 | 8192)) add_row(lb, gx[1], gu[1]);
                 sxn = gx[0]; sun = gu[0]; sxc = gx[2]; suc = gu[2];
             }
             if (q & (1u << 10)) {                       // B = (n, c, d)
@@ -137,6 +174,21 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
                 sxn.x += gx[0].x; sxn.y += gx[0].y; sun.x += gu[0].x; sun.y += gu[0].y;
                 sxc.x += gx[1].x; sxc.y += gx[1].y; suc.x += gu[1].x; suc.y += gu[1].y;
             }
+#ifdef HFEM_LAB
+            if (HFEM_PAIR_LAB(4096 | 8192)) {           // lab: what a LANE chain would cost (timing only, results are not valid):
+                if (HFEM_PAIR_LAB(4096)) {              // rows of b, c handed to the next lane by DPP and added to its n, d rows
+                    auto shr = [](double v) {
+                        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xF, 0xF, false);
+                        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xF, 0xF, false);
+                        return __hiloint2double(hi, lo);
+                    };
+                    sxn.x += shr(sxc.x); sxn.y += shr(sxc.y); sun.x += shr(suc.x); sun.y += shr(suc.y);
+                    sxn.x += shr(sxc.y); sxn.y += shr(sxc.x); sun.x += shr(suc.y); sun.y += shr(suc.x);
+                }
+                if (ln < n_owned) add_row(ln, sxn, sun);   // n flushed; b was flushed above (stands in for d), c is not
+                continue;
+            }
+#endif
             if (ln < n_owned) add_row(ln, sxn, sun);
             if (lc < n_owned) add_row(lc, sxc, suc);
         }
@@ -237,7 +289,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
-        if (l < n_owned) {
+        if (l < n_owned && !HFEM_PAIR_LAB(4)) {
             if (gx_free && s[j].x >= 0) {
                 V2 v;
                 v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
@@ -257,7 +309,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         double tile_e = 0.0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
-        partials[slot] = tile_e;
+        if (!HFEM_PAIR_LAB(256) || tile_e == 1.2345) partials[slot] = tile_e;
     }
     if (pd.span && tid == 0) {                          // ... and when its first wave's stores had left (100 MHz ticks)
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -266,27 +318,27 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     }
 }
 
-constexpr int kPairCapN = 656, kPairCapO = 560;          // compile-time LDS strides of the default tile shape (557 owned nodes)
+constexpr int kPairLabCapN = 656, kPairLabCapO = 560;          // compile-time LDS strides of the default tile shape (557 owned nodes)
 template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM, bool CHAIN>
-static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
-    constexpr int CAPN = CAPO > 0 ? kPairCapN : 0;
+static void launch_pair_lab_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
+    constexpr int CAPN = CAPO > 0 ? kPairLabCapN : 0;
     const size_t lds = CAPO > 0 ? (size_t)(CAPN * 32 + CAPO * 32 + 128) : A.lds;
-    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN>), dim3(A.grid), dim3(BLK), lds, A.s,
+    hipLaunchKernelGGL((tri3_energy_pair_lab_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN>), dim3(A.grid), dim3(BLK), lds, A.s,
                        A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
                        (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
-                       CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride);
+                       CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride, A.lab_bits);
 }
 template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM>
-static void launch_pair_inst(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
-    if (A.chain) launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, true>(A, lag, af);
-    else launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, false>(A, lag, af);
+static void launch_pair_lab_inst(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
+    if (A.chain) launch_pair_lab_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, true>(A, lag, af);
+    else launch_pair_lab_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, false>(A, lag, af);
 }
 
 // Launch on a paired plan: picks the instance that holds the plan's tile shape.  1 = launched, 0 = none does.
 // mode: 0 fp64 reference convention (zero body force), 1 general fp64 (body force and / or physical convention),
 //       2 fp32 rows, 3 fused Adam write-out on fp64 rows, 4 the same on fp32 rows (3, 4: hasb selects the body-force instance).
-int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
-                     const AdamFuse &af) {
+int launch_tri3_pair_lab(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
+                         const AdamFuse &af) {
     const HostPlan &h = plan->host;
     if (!h.paired || !plan->d_elem_pack_hi) return 0;
     A.pd = plan_dev(plan);
@@ -294,67 +346,27 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.lds = (size_t)plan->lds_bytes;
     A.col_stride = h.col_stride;
     if (A.chain < 0) A.chain = h.n_chained > 0 ? 1 : 0;   // chained records need the carrying slot loop
-    if (h.pair_block == 512) {
-        // 512 threads per tile (shard-aware tile policy, hfem_plan_create: launches of 100 k - 600 k elements): NPT = 2
-        // (<= 1024 nodes), one or two slot rows; the plain slot loop only
-        if (h.max_nodes > 2 * 512 || h.max_rows > 2 || A.chain) return 0;
-        if (mode == 0) {
-            if (h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN) launch_pair_inst2<512, 2, 2, 560, false, false, double2, false, false>(A, lag, af);
-            else launch_pair_inst2<512, 2, 2, 0, false, false, double2, false, false>(A, lag, af);
-            return 1;
-        }
-        if (mode == 1) {
-            if (phys) launch_pair_inst2<512, 2, 2, 0, true, true, double2, false, false>(A, lag, af);
-            else launch_pair_inst2<512, 2, 2, 0, true, false, double2, false, false>(A, lag, af);
-            return 1;
-        }
-        if (mode == 2) { launch_pair_inst2<512, 2, 2, 0, false, false, float2, false, false>(A, lag, af); return 1; }
-        if (mode == 3) {
-            if (hasb) launch_pair_inst2<512, 2, 2, 0, true, false, double2, true, false>(A, lag, af);
-            else launch_pair_inst2<512, 2, 2, 0, false, false, double2, true, false>(A, lag, af);
-            return 1;
-        }
-        if (mode == 4) {
-            if (hasb) launch_pair_inst2<512, 2, 2, 0, true, false, float2, true, false>(A, lag, af);
-            else launch_pair_inst2<512, 2, 2, 0, false, false, float2, true, false>(A, lag, af);
-            return 1;
-        }
-        return 0;
-    }
-    const bool cc = h.max_owned <= kPairCapO && h.max_nodes <= kPairCapN;   // (656 + 560) * 32 + 128 = 39040 B: four workgroups per CU
+    if (h.pair_block != 256 || mode != 0) return 0;            // lab copy: the fp64 reference-convention instances only
+    const bool cc = h.max_owned <= kPairLabCapO && h.max_nodes <= kPairLabCapN;   // (656 + 560) * 32 + 128 = 39040 B: four workgroups per CU
     const int npt = h.max_nodes <= 3 * 256 ? 3 : 4;
     const int ept = h.max_rows > 0 ? h.max_rows : 1;     // slots per thread (0: a plan of element-less tiles)
     if (h.max_nodes > 4 * 256 || ept > 6) return 0;
-#define HFEM_PAIR_EPT(NPT, CO, HB, PH, V, AD)                                                    \
+#define HFEM_PAIRLAB_EPT(NPT, CO, HB, PH, V, AD)                                                    \
     switch (ept) {                                                                               \
-        case 1: case 2: case 3: launch_pair_inst<256, NPT, 3, CO, HB, PH, V, AD>(A, lag, af); return 1; \
-        case 4: launch_pair_inst<256, NPT, 4, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
-        case 5: launch_pair_inst<256, NPT, 5, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
-        default: launch_pair_inst<256, NPT, 6, CO, HB, PH, V, AD>(A, lag, af); return 1;          \
+        case 1: case 2: case 3: launch_pair_lab_inst<256, NPT, 3, CO, HB, PH, V, AD>(A, lag, af); return 1; \
+        case 4: launch_pair_lab_inst<256, NPT, 4, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
+        case 5: launch_pair_lab_inst<256, NPT, 5, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
+        default: launch_pair_lab_inst<256, NPT, 6, CO, HB, PH, V, AD>(A, lag, af); return 1;          \
     }
     if (mode == 0) {
-        if (cc && npt == 3) HFEM_PAIR_EPT(3, 560, false, false, double2, false)
-        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, false)
-        HFEM_PAIR_EPT(4, 0, false, false, double2, false)
-    } else if (mode == 1) {
-        if (phys) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, true, double2, false) HFEM_PAIR_EPT(4, 0, true, true, double2, false) }
-        (void)hasb;
-        if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, double2, false)
-        HFEM_PAIR_EPT(4, 0, true, false, double2, false)
-    } else if (mode == 2) {
-        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, false)
-        HFEM_PAIR_EPT(4, 0, false, false, float2, false)
-    } else if (mode == 3) {                      // fused Adam write-out: fp64 rows
-        if (hasb) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, double2, true) HFEM_PAIR_EPT(4, 0, true, false, double2, true) }
-        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, true)
-        HFEM_PAIR_EPT(4, 0, false, false, double2, true)
-    } else if (mode == 4) {                      // fused Adam write-out: fp32 rows (parameters, moments, new rows all float)
-        if (hasb) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, float2, true) HFEM_PAIR_EPT(4, 0, true, false, float2, true) }
-        if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, true)
-        HFEM_PAIR_EPT(4, 0, false, false, float2, true)
+        if (cc && npt == 3) HFEM_PAIRLAB_EPT(3, 560, false, false, double2, false)
+        if (npt == 3) HFEM_PAIRLAB_EPT(3, 0, false, false, double2, false)
+        HFEM_PAIRLAB_EPT(4, 0, false, false, double2, false)
     }
-#undef HFEM_PAIR_EPT
+#undef HFEM_PAIRLAB_EPT
     return 0;
 }
 
 }  // namespace hfem
+
+#endif  // HFEM_LAB

@@ -41,12 +41,17 @@ PY
   echo "pmc $c $tag done"
 }
 if [ "$PART" = traffic ] || [ "$PART" = all ]; then
-  rm -f "$OUT/pmc_summary.txt"
+  # XS: the workloads of this call (a gpurun call is limited to 20 minutes: split the list over calls; the summary file
+  # is appended to)
+  XS=${XS:-"T1M Q1M T2M cfg5 cfg5auto cfg5r cfg5u"}
   for c in FETCH_SIZE WRITE_SIZE; do
-    pmc_one $c T1M_replayed --only-regime replayed
-    pmc_one $c T1M_rotating --only-regime rotating_sets
-    for x in Q1M T2M cfg5 cfg5auto cfg5r cfg5u; do
-      pmc_one $c $x --only-extra $x
+    for x in $XS; do
+      if [ "$x" = T1M ]; then
+        pmc_one $c T1M_replayed --only-regime replayed
+        pmc_one $c T1M_rotating --only-regime rotating_sets
+      else
+        pmc_one $c $x --only-extra $x
+      fi
     done
   done
   cat "$OUT/pmc_summary.txt"

@@ -101,7 +101,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._tabs = dict(n=n_params, dev=dev, used={},
                           free=[(torch.zeros(nbytes, dtype=torch.uint8).pin_memory(), torch.zeros(nbytes, dtype=torch.uint8, device=dev))
                                 for _ in range(self._TAB_SLOTS)])
-        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ticket = torch.zeros(1056, dtype=torch.int32, device=dev)      # HFEM_ADAM_TICKET_INTS
 
     def _table(self, todo):
         import ctypes as C
@@ -128,7 +128,7 @@ class FusedAdam(torch.optim.Optimizer):
         host, tab_dev = tabs["free"].pop()
         total_vecs = sum((p.numel() + (1 if p.dtype == torch.float64 else 3)) // (2 if p.dtype == torch.float64 else 4)
                          for _, p, _, _ in todo)
-        chunk = max(256, -(-total_vecs // 4096))                   # <= ~4096 blocks, each a contiguous run of 16-byte vectors
+        chunk = max(256, -(-total_vecs // 2048))                   # <= ~2048 blocks (8 per CU: 512 ... 8192 measured flat), contiguous runs of 16-byte vectors
         chunk = -(-chunk // 256) * 256
         tab = (_lib.AdamTensor * len(todo))()
         blk = 0

@@ -318,7 +318,10 @@ int hfem_counter_add(int device, int64_t *counter, int64_t inc, void *stream);
  * the 16-byte vectors [b * chunk_vecs, (b + 1) * chunk_vecs); n_blocks = total.  dtype per tensor: 0 fp64, 1 fp32.
  * Step count: step_dev (may be NULL) holds the number of COMPLETED steps; the update uses step_dev[0] + step_offset
  * (step_offset alone when step_dev is NULL: a host-side count).  With step_dev the kernel itself bumps the counter once
- * all blocks have read it (ticket_dev: an int32 in device memory, zero before the first call) -- no hfem_counter_add.   */
+ * all blocks have read it (ticket_dev: HFEM_ADAM_TICKET_INTS int32 of device memory, zero before the first call; a
+ * two-level last-arriver count) -- no hfem_counter_add.  Keep n_blocks at a few per CU (<= 2048): every block ends with
+ * one device-scope atomic.                                                                                            */
+#define HFEM_ADAM_TICKET_INTS 1056
 typedef struct hfem_adam_tensor {
     void *p; const void *g; void *m; void *v;
     int64_t n;

@@ -1,33 +1,50 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): FusedAdam.step alone on T1M-sized parameters (two fp64 tensors of ~500 k rows x 2), K steps per
-hipGraph -> us per step and the achieved bandwidth over its 7 arrays per tensor (p, g, m, v read; p, m, v written)."""
+"""Dev tool (GPU box): what a T1M training iteration costs -- energy launch + FusedAdam (multi-tensor, one launch) vs the
+per-tensor launches, and the one-launch EnergyAdamStep; K iterations per hipGraph."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hidenn_fem_amd.optim import FusedAdam
+from hidenn_fem_amd.mesh import structured_tri_mesh
+from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+from hidenn_fem_amd.loss import EnergyLoss2D
+from hidenn_fem_amd.optim import FusedAdam, EnergyAdamStep
+from hidenn_fem_amd.graphed import GraphedTraining
 
-dev = torch.device("cuda:0")
-n = [(499000, 2), (500000, 2)]
-ps = [torch.nn.Parameter(torch.randn(s, dtype=torch.float64, device=dev)) for s in n]
-for p in ps:
-    p.grad = torch.randn_like(p)
-opt = FusedAdam(ps, lr=1e-9, capturable=True).init_state()
+d = torch.device("cuda:0")
+f64 = torch.float64
+mesh = structured_tri_mesh(1001, 501, length=2.0, height=1.0, jitter=0.2, seed=0, dtype=f64)
 K = 100
-s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3):
-        opt.step()
-torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    for _ in range(K):
-        opt.step()
-t0 = time.perf_counter()
-while time.perf_counter() - t0 < 0.3:
-    g.replay(); torch.cuda.synchronize()
-ts = []
-for _ in range(5):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / K)
-us = sorted(ts)[2] * 1e6
-byt = sum(p.numel() for p in ps) * 8 * 7
-print(f"FusedAdam.step: {us:.2f} us, {byt / 1e6:.1f} MB -> {byt / us / 1e6:.2f} TB/s")
+
+
+def model(dt=f64):
+    torch.manual_seed(0)
+    c, cn, g, b, mn, e = mesh
+    return PiecewiseLinearShapeNN2D(c.to(dt), cn, boundary_mask=g, dirichlet_mask=b, u_fixed=0.0, neumann_edges=e).to(d)
+
+
+def timeit(gt):
+    for _ in range(5):
+        gt.replay()
+    torch.cuda.synchronize()
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < 0.5:
+        gt.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); gt.replay(); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / K * 1e6)
+    return sorted(ts)[2]
+
+
+for dt in (f64, torch.float32):
+    m = model(dt)
+    lf = EnergyLoss2D(device=d, dtype=dt)
+    opt = FusedAdam([dict(params=[m.node_coords_free], lr=1e-9), dict(params=[m.u_free], lr=1e-12)], capturable=True)
+    print(dt, "energy + multi-tensor FusedAdam: %.2f us/iteration" % timeit(GraphedTraining(lambda: lf.value_and_grad_(m), opt, steps_per_replay=K, direct=True, warmup=2)), flush=True)
+    m2 = model(dt)
+    tr = EnergyAdamStep(m2, lf, lr_x=1e-9, lr_u=1e-12)
+    print(dt, "one-launch EnergyAdamStep:        %.2f us/iteration" % timeit(GraphedTraining(tr.step_lagged, None, steps_per_replay=K, direct=True, begin=tr.begin_lagged, end=tr.flush_loss)), flush=True)
+    m3 = model(dt)
+    only = FusedAdam([dict(params=[m3.node_coords_free], lr=1e-9), dict(params=[m3.u_free], lr=1e-12)], capturable=True)
+    lf.value_and_grad_(m3)
+    print(dt, "multi-tensor FusedAdam alone:     %.2f us/step" % timeit(GraphedTraining(lambda: None, only, steps_per_replay=K, direct=True, warmup=2)), flush=True)

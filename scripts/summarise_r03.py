@@ -43,7 +43,8 @@ if os.path.exists(os.path.join(src, "pmc_summary.txt")):
     pm = {}
     for line in open(os.path.join(src, "pmc_summary.txt")):
         p = line.split()
-        pm[(p[0], p[1])] = (float(p[-1]), p[2], int(p[4]))
+        k = p.index("launches")                       # the kernel name in between may contain spaces ("void hfem::...")
+        pm[(p[0], p[1])] = (float(p[-1]), " ".join(p[2:k]), int(p[k + 1]))
     tr = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes on `bench.py --only-regime ...` / "
                     "`--only-extra ...` (scripts/prof_r03.sh), MI355X round 3, mean over the launches of the energy kernel.  The "
                     "counters sit on the L2's fabric side: requests served by the Infinity Cache are counted (upper bound on HBM bytes)",

@@ -474,3 +474,99 @@ def test_same_bank_ranges_sum_to_the_whole_evaluation_and_span_stamps():
     run(0, 0, -1, 0)
     torch.cuda.synchronize()
     assert int(buf.abs().sum().item()) == 0
+
+
+def _two_gpu_worker(rank, world, port, q):
+    """One rank of the 2-GPU LibraryComm test: owner-sharded training through the in-library RCCL communicator (plain
+    and overlapped) against the same steps through torch.distributed's own nccl collectives."""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    d = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=d)
+    try:
+        from hidenn_fem_amd.mesh import structured_tri_mesh
+        from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+        from hidenn_fem_amd.loss import EnergyLoss2D
+        from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
+        coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 151, jitter=0.2, seed=6, dtype=F64)
+
+        def trainer(comm):
+            torch.manual_seed(2)
+            m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(d)
+            sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm)
+            sh.setup_interfaces()
+            sh.init_owner_adam(1e-6, 1e-8)
+            return m, sh
+        comm = LibraryComm(d)
+        n_iter = 8
+        m_pg, sh_pg = trainer(None)                              # torch.distributed collectives (the checked path)
+        ref = [sh_pg.owner_train_step().item() for _ in range(n_iter)]
+        m_lib, sh_lib = trainer(comm)                            # in-library RCCL, eager
+        got = [sh_lib.owner_train_step().item() for _ in range(n_iter)]
+        m_ov, sh_ov = trainer(comm)                              # in-library RCCL, overlapped, 4 iterations per hipGraph
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            sh_ov.owner_train_step_overlapped()
+            first = sh_ov.finish_overlapped().item()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        per = 4
+        losses = torch.zeros(per, dtype=F64, device=d)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(per):
+                sh_ov.owner_train_step_overlapped()
+                if i:
+                    losses[i - 1].copy_(sh_ov.loss_global)
+            losses[per - 1].copy_(sh_ov.finish_overlapped())
+        g.replay()
+        torch.cuda.synchronize()
+        got_ov = [first] + losses.tolist()
+        # dense mode: out-of-place all-reduce through the library vs torch.distributed
+        sh_lib.evaluate_local()
+        l1 = sh_lib.exchange()[0].item()
+        sh_pg.evaluate_local()
+        l2 = sh_pg.exchange()[0].item()
+        torch.cuda.synchronize()
+        own_x, _ = sh_pg.owned_rows()
+        dx = (m_lib.node_coords_free[own_x] - m_pg.node_coords_free[own_x]).abs().max().item()
+        q.put((rank, ref, got, got_ov, l1, l2, dx, sh_lib.mid - sh_lib.lo, sh_lib.hi - sh_lib.mid))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node); one-GPU boxes skip")
+def test_library_comm_two_gpus_matches_torch_distributed():
+    """the in-library RCCL path (ncclCommInitRank with a broadcast id, ncclAllGather payload layout against
+    hfem_iface_unpack's [world][stride] expectation, coexistence with torch's own communicator) with MORE than one rank:
+    two processes, two GPUs -- eager, overlapped and hipGraph-captured -- against the torch.distributed collectives."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ref, got, got_ov, l1, l2, dx, nb, ni in res:
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+        np.testing.assert_allclose(got_ov, ref[:len(got_ov)], rtol=1e-12)
+        assert abs(l1 - l2) <= 1e-12 * abs(l2) and dx <= 1e-12
+        assert nb > 0 and ni > 0
+    assert res[0][1] == res[1][1], "both ranks report the same global energies"

@@ -15,6 +15,7 @@ left edge Dirichlet, right edge Neumann (500 edges), u_free ~ 1e-5 N(0,1), E=10e
 N > 1: `value` is WEAK scaling (the plate grows to N x 1,000,000 elements; every rank evaluates its contiguous tile range,
 then ONE small all_gather of interface parameter rows + partial energies -- owner-sharded mode, in-library RCCL on the
 kernel's stream, the K steps in one hipGraph).  Beside it, in `config`:
+  eval_exchange_overlap             the headline step with the exchange of step k under the interior tiles of step k + 1
   train_step / train_step_overlap   whole Adam iterations (exchange on the critical path / hidden under the interior tiles)
   alt_exchange                      the north-star's literal wording: a dense sum all-reduce of [gX|gU|loss]
   strong_scaling                    BASELINE configs[3] and [4] AS STATED: 10^6 TRI3 FIXED sharded over the N ranks (and, at
@@ -72,6 +73,7 @@ def parse():
                     "cfg5auto | cfg5r | cfg5u) and exit")
     ap.add_argument("--emulate-shard", default="", help="N = 1: 'r/N' -- time the kernel over the tile range rank r of N "
                     "would evaluate on the FIXED 10^6-element mesh (strong-scaling rehearsal) and exit")
+    ap.add_argument("--reorder", default="auto", help="row storage order of the triangular models (auto | hilbert | off); A/B runs")
     ap.add_argument("--rotating-sets", type=int, default=10, help="parameter/gradient sets of the rotating leg (32 MB each)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the multi-rank path on fewer GPUs than ranks)")
@@ -331,7 +333,7 @@ def main():
         coords, conn, geom, bc, mn, edges = mesh6
         torch.manual_seed(0)
         return PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
-                                        neumann_edges=edges).to(dev)
+                                        neumann_edges=edges, reorder=a.reorder).to(dev)
 
     def t1m_mesh(nranks=1):
         nx = (a.nx - 1) * nranks + 1
@@ -480,9 +482,12 @@ def main():
         return dict(mode=mode, value=n_elems / (el / a.steps), ms_per_step=el / a.steps * 1e3, launch=ln,
                     ms_per_step_replays=[round(r / a.steps * 1e3, 5) for r in regs])
 
-    alt = train = train_ov = strong = None
+    alt = train = train_ov = strong = eval_ov = None
     if world > 1:
         how = comm_state
+        eval_ov = leg(sh.owner_step_overlapped, "evaluation + interface exchange, the exchange of step k on a side stream under the "
+                      "interior tiles of step k+1 (the headline `value` keeps the exchange on the critical path)", ne,
+                      end_=sh.finish_overlapped)
         alt = leg(step_dense, f"dense: sum all-reduce of [gX|gU|loss] fp64, {sh.send.numel() * 8} B per rank, {how}", ne)
         train = leg(sh.owner_train_step, "owner-sharded training iteration: energy -> Adam on the rows the rank owns -> pack "
                     "(+ energy sum + step count) -> all_gather -> unpack; four launches + the collective, exchange on the "
@@ -515,6 +520,8 @@ def main():
                                     value=ne_s / (tmax[0].item() * 1e-6), achieved_GBs_all_ranks=tsum[1].item(),
                                     frac_of_N_x_8TBs=tsum[1].item() / (HBM_PEAK_GBS * world)),
                    eval_exchange=leg(sh_s.owner_step, "evaluation + interface exchange (the N = 1 definition of a step + the exchange)", ne_s),
+                   eval_exchange_overlap=leg(sh_s.owner_step_overlapped, "the same, exchange under the next step's interior tiles", ne_s,
+                                             end_=sh_s.finish_overlapped),
                    train_step=leg(sh_s.owner_train_step, "Adam iteration, exchange on the critical path", ne_s),
                    train_step_overlap=leg(sh_s.owner_train_step_overlapped, "Adam iteration, exchange under the next step's interior tiles",
                                           ne_s, end_=sh_s.finish_overlapped))
@@ -642,7 +649,7 @@ def main():
             c_, cn_, g_, b_, _, e_ = mesh
             torch.manual_seed(0)
             m_ = PiecewiseLinearShapeNN2D(c_, cn_, boundary_mask=g_, dirichlet_mask=b_, u_fixed=0.0, neumann_edges=e_,
-                                          **(model_kw or {})).to(dev)
+                                          **(model_kw or dict(reorder=a.reorder))).to(dev)
             lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64)
             pl = m_.tile_plan(0)
             x_, u_ = m_.node_coords_free.detach(), m_.u_free.detach()
@@ -792,6 +799,8 @@ def main():
             out["config"]["train_step_1gpu"] = train1
         if strong_emu is not None:
             out["config"]["strong_scaling_emulated"] = strong_emu
+        if eval_ov is not None:
+            out["config"]["eval_exchange_overlap"] = eval_ov
         if alt is not None:
             out["config"]["alt_exchange"] = alt
         if train is not None:

@@ -36,37 +36,44 @@ struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1
 // energy density * |det| at one point with weight w, and its gradient w.r.t. (a..d, G0, G1)
 // beta_w (body-force instances): w * b(xi_q).u_h(xi_q) of this point -- the density is w psi - beta_w; with the
 // cotangents below it adds only the sign(det) (-beta_w) cof(J) term (u_h's own gradient is added by the caller).
+// Cofactor form (round 3): with adj = [[d, -b], [-c, a]] the UNSCALED h^ = G adj^T = det H, eps^ = (h^00, h^11, h^01 + h^10),
+// sigma^ = C eps^ and  w |det| psi = t2/2 (eps^ . sigma^)  with  t2 = w / |det| = copysign(w, det) / det.  Nothing is
+// pre-scaled by 1/det (no a/det .. d/det), dE/dh^ = t2 sigma^, and the only trace of the 1/|det| factor in the backward
+// is  dE/d det = -E / det.  51 fp64 operations per point with gradients (57 in the scaled form); `inv` = 1 / det comes
+// from the caller, which inverts the four determinants of an element with ONE reciprocal.
 template <bool GRAD>
-__device__ __forceinline__ double jac_point(double a, double b, double c, double d, double2 g0, double2 g1,
+__device__ __forceinline__ double jac_point(double a, double b, double c, double d, double2 g0, double2 g1, double det, double inv,
                                             double w, const Tri3Consts &k, JacGrad &o, double beta_w = 0.0, double *A_out = nullptr) {
-    const double det = a * d - b * c;
-    const double inv = fast_rcp(det);
-    const double ai = a * inv, bi = b * inv, ci = c * inv, di = d * inv;
-    const double h00 = g0.x * di - g1.x * bi, h01 = g1.x * ai - g0.x * ci;
-    const double h10 = g0.y * di - g1.y * bi, h11 = g1.y * ai - g0.y * ci;
+    const double t2 = __builtin_copysign(w, det) * inv;                    // w / |det|  (sign through one v_bfi)
+    const double h00 = g0.x * d - g1.x * b, h01 = g1.x * a - g0.x * c;
+    const double h10 = g0.y * d - g1.y * b, h11 = g1.y * a - g0.y * c;
     const double gam = h01 + h10;
     const double sxx = k.c11 * h00 + k.c12 * h11, syy = k.c12 * h00 + k.c22 * h11, sxy = k.c33 * gam;
-    // |det| and sign(det) enter through sw = w sign(det) (one v_bfi on the high word, as in tri3_element):
-    // A w = det sw, sign(det) w psi = (sw / 2)(h : sigma) -- no compare / select chain
-    const double sw = __builtin_copysign(w, det);
-    const double aw = det * sw;                                            // A w
     const double hs = h00 * sxx + h11 * syy + gam * sxy;
+    double e = (0.5 * t2) * hs;                                            // w |det| psi
     if (A_out) *A_out = fabs(det);
     if (GRAD) {
-        const double p00 = aw * sxx, p01 = aw * sxy, p11 = aw * syy;
-        o.dg0 = make_double2(p00 * di - p01 * ci, p01 * di - p11 * ci);
-        o.dg1 = make_double2(p01 * ai - p00 * bi, p11 * ai - p01 * bi);
-        // dJ = -dG^T H + sign(det) (w psi - beta_w) cof(J)
-        double sd = (0.5 * sw) * hs;
-        if (A_out) sd -= __builtin_copysign(1.0, det) * beta_w;            // body-force instances only
-        o.da = sd * d - (o.dg0.x * h00 + o.dg0.y * h10);
-        o.db = -sd * c - (o.dg0.x * h01 + o.dg0.y * h11);
-        o.dc = -sd * b - (o.dg1.x * h00 + o.dg1.y * h10);
-        o.dd = sd * a - (o.dg1.x * h01 + o.dg1.y * h11);
+        const double p00 = t2 * sxx, p01 = t2 * sxy, p11 = t2 * syy;       // dE / d h^  (symmetric)
+        o.dg0 = make_double2(p00 * d - p01 * c, p01 * d - p11 * c);
+        o.dg1 = make_double2(p01 * a - p00 * b, p11 * a - p01 * b);
+        double ddet = -e * inv;                                            // through t2 = w sign(det) / det
+        if (A_out) ddet -= __builtin_copysign(1.0, det) * beta_w;          // body-force instances only: -sign(det) beta_w
+        o.da = (p01 * g1.x + p11 * g1.y) + ddet * d;
+        o.db = -(p00 * g1.x + p01 * g1.y) - ddet * c;
+        o.dc = -(p01 * g0.x + p11 * g0.y) - ddet * b;
+        o.dd = (p00 * g0.x + p01 * g0.y) + ddet * a;
     }
-    double e = (0.5 * aw) * hs;                                            // A w psi
     if (A_out) e -= fabs(det) * beta_w;
     return e;
+}
+
+// the four determinants of an element inverted with ONE v_rcp_f64 (quarter-rate) + Newton: 1/d_i from 1/(d0 d1 d2 d3).
+// A vanishing determinant makes all four results Inf / NaN -- the element's energy is NaN either way.
+__device__ __forceinline__ void rcp4(const double (&dt)[4], double (&iv)[4]) {
+    const double p01 = dt[0] * dt[1], p23 = dt[2] * dt[3];
+    const double r = fast_rcp(p01 * p23);
+    const double r01 = r * p23, r23 = r * p01;                             // 1/(d0 d1), 1/(d2 d3)
+    iv[0] = r01 * dt[1]; iv[1] = r01 * dt[0]; iv[2] = r23 * dt[3]; iv[3] = r23 * dt[2];
 }
 
 // reference-square corner signs, CCW from (-1,-1): xi_k = {-1,1,1,-1}, eta_k = {-1,-1,1,1}
@@ -114,11 +121,18 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
     double U[4][4], V[4][4];
     double2 gub[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
     double e = 0.0;
+    // J(xi, eta) is affine: a, c depend on eta only, b, d on xi only -- two values each; the four determinants first, one
+    // reciprocal for all of them
+    const double am = a1[0] - gp * a3[0], ap = a1[0] + gp * a3[0], cm = a1[1] - gp * a3[1], cp = a1[1] + gp * a3[1];
+    const double bm = a2[0] - gp * a3[0], bp = a2[0] + gp * a3[0], dm = a2[1] - gp * a3[1], dp = a2[1] + gp * a3[1];
+    const double dets[4] = {am * dm - bm * cm, am * dp - bp * cm, ap * dm - bm * cp, ap * dp - bp * cp};
+    double invs[4];
+    rcp4(dets, invs);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp;
-        const double a = a1[0] + eta * a3[0], b = a2[0] + xi * a3[0];
-        const double c = a1[1] + eta * a3[1], d = a2[1] + xi * a3[1];
+        const double a = (q & 2) ? ap : am, b = (q & 1) ? bp : bm;
+        const double c = (q & 2) ? cp : cm, d = (q & 1) ? dp : dm;
         const double2 g0 = make_double2(a1[2] + eta * a3[2], a1[3] + eta * a3[3]);
         const double2 g1 = make_double2(a2[2] + xi * a3[2], a2[3] + xi * a3[3]);
         JacGrad o;
@@ -132,7 +146,7 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
                 uhy += nk[j] * Un[j].y;
             }
             const double2 bq = Bq[q];
-            e += jac_point<GRAD>(a, PHYS ? c : b, PHYS ? b : c, d, g0, g1, 0.0625, k, o, 0.0625 * (uhx * bq.x + uhy * bq.y), &A16);
+            e += jac_point<GRAD>(a, PHYS ? c : b, PHYS ? b : c, d, g0, g1, dets[q], invs[q], 0.0625, k, o, 0.0625 * (uhx * bq.x + uhy * bq.y), &A16);
             if (GRAD) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -141,7 +155,7 @@ __device__ __forceinline__ double quad4_element(const double2 (&Xn)[4], const do
                 }
             }
         } else {
-            e += jac_point<GRAD>(a, PHYS ? c : b, PHYS ? b : c, d, g0, g1, 0.0625, k, o);
+            e += jac_point<GRAD>(a, PHYS ? c : b, PHYS ? b : c, d, g0, g1, dets[q], invs[q], 0.0625, k, o);
         }
         if (GRAD) {
             U[q][0] = o.da; U[q][1] = PHYS ? o.db : o.dc; U[q][2] = o.dg0.x; U[q][3] = o.dg0.y;
@@ -203,7 +217,8 @@ __global__ __launch_bounds__(kBlockQ) void quad4_energy_atomic_kernel(
             }
             JacGrad o;
             if (gX) {
-                e_loc += jac_point<true>(a, b, c, d, g0, g1, 1.0, k, o);
+                const double det = a * d - b * c;
+                e_loc += jac_point<true>(a, b, c, d, g0, g1, det, fast_rcp(det), 1.0, k, o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     gx[j].x += o.da * D0[j] + o.db * D1[j];
@@ -212,7 +227,8 @@ __global__ __launch_bounds__(kBlockQ) void quad4_energy_atomic_kernel(
                     gu[j].y += o.dg0.y * D0[j] + o.dg1.y * D1[j];
                 }
             } else {
-                e_loc += jac_point<false>(a, b, c, d, g0, g1, 1.0, k, o);
+                const double det = a * d - b * c;
+                e_loc += jac_point<false>(a, b, c, d, g0, g1, det, fast_rcp(det), 1.0, k, o);
             }
         }
         if (gX) {

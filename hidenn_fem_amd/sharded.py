@@ -366,19 +366,20 @@ class ShardedTri3Energy:
         elif hi > lo:
             self._evaluate_hip(lo, hi, self.loss_global, gx_v, gu_v, 8 | (256 if cont else 0))
 
-    def _pack_loss(self):
+    def _pack_loss(self, count_step=True):
         """Interface rows + this rank's energy into the payload, step counter += 1 (HIP: one launch)."""
         if self._hip:
             m, dev = self.model, self.send.device
             _lib.check(_lib.lib().hfem_plan_iface_pack(
                 self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
                 self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
-                self._adam["step"].data_ptr(), _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
+                self._adam["step"].data_ptr() if count_step else None, _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
         else:
             self._pack()
             with torch.no_grad():
                 self.payload[self.iface_rows, 0] = self._e_parts[0] + self._e_parts[1]
-                self._adam["step"] += 1
+                if count_step:
+                    self._adam["step"] += 1
 
     def owner_train_step(self):
         """ONE training iteration of the owner-sharded mode, all stream-ordered launches (capturable when ``comm`` is
@@ -411,6 +412,18 @@ class ShardedTri3Energy:
         self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)   # boundary tiles, same evaluation
         self._adam_step()
         self._pack_loss()
+        self._fork_exchange()
+        return self.loss_global
+
+    def owner_step_overlapped(self):
+        """``owner_step`` (evaluation + interface exchange, no optimiser) with the exchange of step k on the side stream
+        under the interior tiles of step k + 1 -- the evaluation-only counterpart of ``owner_train_step_overlapped``.
+        Gradients of the owned rows are in the send buffer when it returns; ``loss_global`` lags one step
+        (``finish_overlapped()`` joins the last exchange).  Needs ``init_owner_adam`` (its streams and buffers)."""
+        self._eval_range(self.mid, self.hi, 0, False)
+        self._join_exchange()
+        self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)
+        self._pack_loss(count_step=False)
         self._fork_exchange()
         return self.loss_global
 

@@ -210,13 +210,14 @@ def test_cfg5_genuinely_unstructured_4m_elements_vs_oracle():
     # oracle on the assembled arrays
     X = coords.numpy()
     U = np.zeros_like(X)
-    U[~bc.numpy()] = m.u_free.detach().cpu().numpy()
+    U[~bc.numpy()] = m.to_caller_order(m.u_free.detach(), "u").cpu().numpy()      # the model may store its rows along the curve
     mat, W = CF.plane_stress(), lf._W
     Tc = np.array([lf._ci * 1e5, 0.0, lf._cj * 1e5, 0.0])
     e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn.numpy(), mat, W)
     e_ref -= CF.edge2_energy(X, U, edges.numpy(), Tconst=Tc, gX=gX_ref, gU=gU_ref)
     assert abs(loss.item() - e_ref) <= 1e-12 * abs(e_ref)
-    gx, gu = m.node_coords_free.grad.cpu().numpy(), m.u_free.grad.cpu().numpy()
+    gx = m.to_caller_order(m.node_coords_free.grad, "x").cpu().numpy()
+    gu = m.to_caller_order(m.u_free.grad, "u").cpu().numpy()
     assert np.abs(gx - gX_ref[~geom.numpy()]).max() <= 1e-10 * np.abs(gX_ref).max()
     assert np.abs(gu - gU_ref[~bc.numpy()]).max() <= 1e-10 * np.abs(gU_ref).max()
     print(f"[unstructured 4M] elements {ne} nodes {nn} tiles {st['n_tiles']} halo elems x{st['tile_elem_total'] / ne:.3f} "

@@ -411,6 +411,19 @@ def test_overlapped_training_step_hip_eager_and_captured():
     sh3 = sharded(m3, False)
     plain = [sh3.owner_train_step().item() for _ in range(n_iter)]
     np.testing.assert_allclose(plain, ref_losses, rtol=1e-12)
+    # evaluation-only counterpart (what bench.py times as eval_exchange_overlap): same energy and gradients as owner_step
+    m4 = model()
+    sh4 = sharded(m4, True)
+    l_ref, gx_ref, gu_ref = sh4.owner_step()
+    l_ref, gx_ref, gu_ref = l_ref.item(), gx_ref.clone(), gu_ref.clone()
+    sh4.send.zero_()
+    for _ in range(3):
+        sh4.owner_step_overlapped()
+    assert sh4.finish_overlapped().item() == l_ref
+    _, gx4, gu4 = sh4._views(sh4.send)
+    assert (gx4 - gx_ref).abs().max().item() <= 1e-12 * gx_ref.abs().max().item()
+    assert (gu4 - gu_ref).abs().max().item() <= 1e-12 * gu_ref.abs().max().item()
+    assert int(sh4._adam["step"].item()) == 0
     comm.close()
 
 

@@ -329,6 +329,14 @@ def _worker_overlap(rank, world, port, q):
                 and torch.equal(plain.model.node_coords_free[seen_x], over.model.node_coords_free[seen_x])
                 and torch.equal(plain.model.u_free[seen_u], over.model.u_free[seen_u])
                 and int(over._adam["step"].item()) == K == int(plain._adam["step"].item()))
+        # evaluation-only overlapped step: the energy owner_step() reports, no optimiser step counted
+        plain.evaluate_owner()
+        e_plain = plain.exchange_halo()[0].item()
+        steps_before = int(plain._adam["step"].item())
+        for _ in range(2):
+            plain.owner_step_overlapped()
+        same = same and abs(plain.finish_overlapped().item() - e_plain) <= 1e-14 * abs(e_plain) \
+            and int(plain._adam["step"].item()) == steps_before
         moved = (plain.model.node_coords_free[own_x] - _make_trainer(world)[0].model.node_coords_free[own_x]).abs().max().item()
         q.put((rank, bool(same), l_plain, moved, plain.mid - plain.lo, plain.hi - plain.mid))
     finally:

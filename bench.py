@@ -483,11 +483,18 @@ def main():
                     ms_per_step_replays=[round(r / a.steps * 1e3, 5) for r in regs])
 
     alt = train = train_ov = strong = eval_ov = None
+    exchange_mode = "serial: evaluation -> pack -> all_gather -> unpack on one stream"
     if world > 1:
         how = comm_state
         eval_ov = leg(sh.owner_step_overlapped, "evaluation + interface exchange, the exchange of step k on a side stream under the "
-                      "interior tiles of step k+1 (the headline `value` keeps the exchange on the critical path)", ne,
-                      end_=sh.finish_overlapped)
+                      "interior tiles of step k+1 (fork / join inside the hipGraph: ~15 us per step on one rank, so it pays "
+                      "when the exposed exchange latency is larger)", ne, end_=sh.finish_overlapped)
+        # the headline is the faster of the two complete evaluation + exchange steps on THIS topology; both are reported
+        serial = dict(value=value, ms_per_step=ms_per_step, launch=launch, ms_per_step_replays=[round(r / a.steps * 1e3, 6) for r in regions])
+        if eval_ov["value"] > value:
+            value, ms_per_step, launch = eval_ov["value"], eval_ov["ms_per_step"], eval_ov["launch"]
+            regions = [r * a.steps * 1e-3 for r in eval_ov["ms_per_step_replays"]]
+            exchange_mode = "overlapped: the exchange of step k under the interior tiles of step k+1 (faster than the serial step on this topology)"
         alt = leg(step_dense, f"dense: sum all-reduce of [gX|gU|loss] fp64, {sh.send.numel() * 8} B per rank, {how}", ne)
         train = leg(sh.owner_train_step, "owner-sharded training iteration: energy -> Adam on the rows the rank owns -> pack "
                     "(+ energy sum + step count) -> all_gather -> unpack; four launches + the collective, exchange on the "
@@ -801,6 +808,8 @@ def main():
             out["config"]["strong_scaling_emulated"] = strong_emu
         if eval_ov is not None:
             out["config"]["eval_exchange_overlap"] = eval_ov
+            out["config"]["eval_exchange_serial"] = serial
+            out["config"]["exchange_mode"] = exchange_mode
         if alt is not None:
             out["config"]["alt_exchange"] = alt
         if train is not None:

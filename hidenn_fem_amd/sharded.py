@@ -432,14 +432,18 @@ class ShardedTri3Energy:
         not looking at; ``_join_exchange`` makes it ``loss_global``."""
         slot = self._loss_slots[1] if self.loss_global.data_ptr() == self._loss_slots[0].data_ptr() else self._loss_slots[0]
         if self._side is not None:                                 # GPU: all_gather + unpack on the side stream
+            if self._unpack != self._unpack_hip:
+                raise RuntimeError("owner_train_step_overlapped on a GPU needs the HIP pack / unpack")
+            if getattr(self, "inline_exchange", False):            # A/B switch: the same launches, all on the caller's stream
+                self._gather_payloads()
+                self._unpack_hip(slot)
+                self._pending = ("inline", slot)
+                return
             main = torch.cuda.current_stream(self.send.device)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 self._gather_payloads()
-                if self._unpack == self._unpack_hip:
-                    self._unpack_hip(slot)
-                else:
-                    raise RuntimeError("owner_train_step_overlapped on a GPU needs the HIP pack / unpack")
+                self._unpack_hip(slot)
             self._pending = (None, slot)
         elif self.world > 1 and self.comm is None:                 # CPU processes (gloo tests): asynchronous collective
             self._pending = (dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group, async_op=True), slot)
@@ -452,7 +456,8 @@ class ShardedTri3Energy:
             return
         work, slot = self._pending
         if self._side is not None:
-            torch.cuda.current_stream(self.send.device).wait_stream(self._side)
+            if work != "inline":
+                torch.cuda.current_stream(self.send.device).wait_stream(self._side)
             self.loss_global = slot
         else:
             if work is not None:

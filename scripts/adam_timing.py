@@ -48,3 +48,45 @@ for dt in (f64, torch.float32):
     only = FusedAdam([dict(params=[m3.node_coords_free], lr=1e-9), dict(params=[m3.u_free], lr=1e-12)], capturable=True)
     lf.value_and_grad_(m3)
     print(dt, "multi-tensor FusedAdam alone:     %.2f us/step" % timeit(GraphedTraining(lambda: None, only, steps_per_replay=K, direct=True, warmup=2)), flush=True)
+
+# ---- the owner-sharded iterations on ONE rank (world = 1, in-library RCCL communicator): what the launch chain of the
+#      multi-GPU step costs before any exchange latency -- plain (4 launches + all_gather) and overlapped (range split
+#      artificially 5 % / 95 %: 5 launches, all_gather + unpack on the side stream)
+from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
+comm = LibraryComm(d)
+for name, split, same_stream in (("owner_train_step", False, False), ("owner_train_step_overlapped", True, False),
+                                 ("owner_train_step_overlapped", True, True), ("owner_step_overlapped", True, False),
+                                 ("owner_step_overlapped", True, True)):
+    m = model(f64)
+    sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=f64), comm=comm)
+    sh.setup_interfaces()
+    sh.init_owner_adam(1e-9, 1e-12)
+    if split:
+        sh.mid = sh.plan.n_tiles // 20
+    if same_stream:                      # the same launches in the same order, exchange on the MAIN stream: what the fork / join costs
+        sh.inline_exchange = True
+        name_tag = name + " (one stream)"
+    else:
+        name_tag = name
+    body = getattr(sh, name)
+    end = sh.finish_overlapped if split else None
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body(); body()
+        if end: end()
+    torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(K):
+            body()
+        if end: end()
+    for _ in range(5): g.replay()
+    torch.cuda.synchronize()
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < 0.5:
+        g.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / K * 1e6)
+    print("world 1 %-44s %.2f us/iteration" % (name_tag, sorted(ts)[2]), flush=True)

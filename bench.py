@@ -578,6 +578,24 @@ def main():
             regimes["rotating_sets"] = dict(kernel_us=t_rot, kernel_us_regions=[round(v, 3) for v in rot_regions], wg_span_us=sp,
                                             launch_gap_us=gap, sets=R,
                                             working_set_mb=round(R * 4 * xf.numel() * 8 / 2 ** 20 + plan.stats["device_bytes"] / 2 ** 20, 1))
+            # for information: the same leg on a plan created with "store_policy" = 2 (nt gradient stores) -- what plans of
+            # >= 750 k nodes take by default and what a caller whose T1M-sized buffers are NOT cache-resident should set
+            try:
+                from hidenn_fem_amd.plan import TilePlan
+                prev_sp = L.hfem_get_option(b"store_policy")
+                _lib.check(L.hfem_set_option(b"store_policy", 2), "hfem_set_option")
+                try:
+                    plan_nt = TilePlan(model.connectivity, model.Nnodes, coords_hint=model.initial_node_coords, x_src=model._x_src,
+                                       u_src=model._u_src, edges=model.neumann_edges, tile_elems=a.tile_elems, device=dev)
+                finally:
+                    L.hfem_set_option(b"store_policy", prev_sp)
+                ko_nt = KernelOnly(model, loss_fn, plan_nt, 0, -1)
+                t_nt, _ = time_launches(lambda i: ko_nt(sets[i % R]), kreps)
+                t_nt_rep, _ = time_launches(lambda i: ko_nt(), kreps)
+                regimes["rotating_sets"]["nt_stores"] = dict(rotating_kernel_us=t_nt, replayed_kernel_us=t_nt_rep)
+                del ko_nt, plan_nt
+            except Exception as e:  # noqa: BLE001
+                note(f"nt-store leg failed: {type(e).__name__}: {str(e)[:120]}")
             del sets
     if only:
         if rank == 0:
@@ -617,6 +635,9 @@ def main():
                 r["kernel_us_source"] = "HIP events, (rewrite + energy) - (rewrite alone): an upper bound"
         r["achieved"] = alg_bytes / (r["kernel_us"] * 1e-6) / 1e9
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        if "nt_stores" in r:
+            for k_ in ("rotating", "replayed"):
+                r["nt_stores"][k_ + "_frac"] = alg_bytes / (r["nt_stores"][k_ + "_kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         if name in rocprof_us:                      # committed profiler run of the same leg, never the in-run figure
             r["rocprof_kernel_us"] = rocprof_us[name]
             r["rocprof_frac"] = alg_bytes / (rocprof_us[name] * 1e-6) / 1e9 / HBM_PEAK_GBS
@@ -639,7 +660,8 @@ def main():
                         alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
 
     # ---- config.extra (N = 1): the other readings of "1 M quad elements" and BASELINE config 5, kernel only, each with
-    #      its own roofline figures (algorithmic bytes of ITS element type over ITS kernel's average launch time):
+    #      its own roofline figures (algorithmic bytes of ITS element type over ITS kernel's average launch time) in the HBM
+    #      regime (rotating sets; `replayed_*` = the same buffers every launch):
     #        Q1M      10^6 QUAD4-iso elements (the extension element; parity unpinned by the reference)
     #        T2M      the same 10^6 quads split in two: 2 x 10^6 TRI3 (reference-pinned element)
     #        cfg5     4 x 10^6 TRI3, random diagonals + random element / node permutation, rows stored as given (reorder="off")
@@ -661,31 +683,43 @@ def main():
             pl = m_.tile_plan(0)
             x_, u_ = m_.node_coords_free.detach(), m_.u_free.detach()
             xfx, ufx = m_.node_coords_fixed, m_.u_fixed_rows()
-            gx_, gu_ = torch.empty_like(x_), torch.empty_like(u_)
             ls_ = torch.zeros((), dtype=f64, device=dev)
             _, Tc_ = lf_._traction(m_, None)
             Tcv, mat_ = dv(Tc_), dv(lf_._mat)
+            # two regimes, as for the headline kernel: the same buffers every launch, and R rotating parameter / gradient sets
+            # that together exceed the 256 MB Infinity Cache (the regime a training loop on a mesh of this size runs in)
+            set_mb = 4 * x_.numel() * 8 / 2 ** 20
+            R_ = max(2, int(320.0 / set_mb) + 1)
+            sets_ = [(x_.clone(), u_.clone(), torch.empty_like(x_), torch.empty_like(u_)) for _ in range(R_)]
 
-            def launch(i):
+            def launch_on(xs, us_, gxs, gus):
                 if quad:
-                    _lib.check(L.hfem_quad4_energy_plan(pl.handle, x_.data_ptr(), xfx.data_ptr(), u_.data_ptr(), ufx.data_ptr(),
-                                                        mat_, None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(), gu_.data_ptr(),
+                    _lib.check(L.hfem_quad4_energy_plan(pl.handle, xs.data_ptr(), xfx.data_ptr(), us_.data_ptr(), ufx.data_ptr(),
+                                                        mat_, None, Tcv, 0, -1, ls_.data_ptr(), gxs.data_ptr(), gus.data_ptr(),
                                                         8, stream_box[0].cuda_stream))
                 else:
-                    _lib.check(L.hfem_tri3_energy_plan(pl.handle, x_.data_ptr(), xfx.data_ptr(), u_.data_ptr(), ufx.data_ptr(),
-                                                       mat_, lf_._W, dv([0.0] * 6), None, Tcv, 0, -1, ls_.data_ptr(), gx_.data_ptr(),
-                                                       gu_.data_ptr(), 8, stream_box[0].cuda_stream))
-            us, _ = time_launches(launch, min(kreps, 60))
+                    _lib.check(L.hfem_tri3_energy_plan(pl.handle, xs.data_ptr(), xfx.data_ptr(), us_.data_ptr(), ufx.data_ptr(),
+                                                       mat_, lf_._W, dv([0.0] * 6), None, Tcv, 0, -1, ls_.data_ptr(), gxs.data_ptr(),
+                                                       gus.data_ptr(), 8, stream_box[0].cuda_stream))
+            n_l = min(kreps, 60) // R_ * R_ or R_
+            us_rep, _ = time_launches(lambda i: launch_on(*sets_[0]), n_l)
+            us, _ = time_launches(lambda i: launch_on(*sets_[i % R_]), n_l)
             ne_, nn_ = cn_.shape[0], c_.shape[0]
             ab = (16 if quad else 12) * ne_ + 64 * nn_ + 8
             st_ = pl.stats
+            stores_ = {16: "sc1 write-through", 2: "nt", 0: "plain"}.get(st_["store_policy"], str(st_["store_policy"]))
+            del sets_
             tr_ = traffic_tab.get(key, {})
             tr_ok = tr_.get("shape") == f"{ne_}/{nn_}/{st_['n_tiles']}"
             extras.append(dict(key=key, name=name, element="QUAD4" if quad else "TRI3", elements=ne_, nodes=nn_, tiles=st_["n_tiles"],
                                halo_elem_factor=st_["tile_elem_total"] / ne_, halo_node_factor=st_["tile_node_total"] / nn_,
                                row_order=getattr(m_, "row_order", "as given"), row_line_factor=getattr(m_, "row_line_factor", None),
+                               plan_row_line_factor=st_["row_line_factor"],
+                               regime=f"rotating: {R_} parameter / gradient sets, {round(R_ * set_mb + st_['device_bytes'] / 2 ** 20)} MB "
+                                      "(> the 256 MB Infinity Cache)", gradient_stores=stores_,
                                kernel_us=us, element_evals_per_s=ne_ / (us * 1e-6), alg_bytes_per_launch=ab,
                                achieved=ab / (us * 1e-6) / 1e9, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               replayed_kernel_us=us_rep, replayed_frac=ab / (us_rep * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                traffic=tr_.get("traffic_bytes_per_launch") if tr_ok else None,
                                traffic_over_alg=(tr_["traffic_bytes_per_launch"] / ab) if tr_ok else None))
             del m_, pl

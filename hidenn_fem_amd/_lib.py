@@ -28,6 +28,7 @@ class PlanStats(C.Structure):
         ("max_tile_elems", _i32), ("max_tile_edges", _i32),
         ("device_bytes", _i64), ("lds_bytes", _i32),
         ("shards", _i32), ("threads_per_tile", _i32), ("paired", _i32), ("slot_rows", _i32),
+        ("store_policy", _i32), ("reserved0", _i32), ("row_line_factor", _f64),
     ]
 
     def as_dict(self):

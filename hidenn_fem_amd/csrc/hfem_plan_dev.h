@@ -106,6 +106,7 @@ struct hfem_plan {
     unsigned long long *span_buf = nullptr;
     int64_t span_slots = 0, span_next = 0;
     int64_t device_bytes = 0;
+    double row_line_factor = 1.0; // distinct 128-byte lines per tile's coordinate rows / the minimum (hfem_plan_create)
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
 };

@@ -331,8 +331,9 @@ __global__ __launch_bounds__(kBlockQ) void quad4_eval_bwd_kernel(
 struct Quad4Body { double2 b[4]; };      // body force at the 2x2 Gauss points (reference coordinates)
 
 // V2: row storage type (double2, or float2 for fp32 models -- the reference's default dtype: widened on load, gradient rows
-// rounded once on store, fp64 arithmetic); PHYS: the opt-in physical gradient convention.
-template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false, int CAPN = 0, typename V2 = double2, bool PHYS = false>
+// rounded once on store, fp64 arithmetic); PHYS: the opt-in physical gradient convention; SP: cache policy of the gradient
+// stores (16 sc1 write-through, 2 nt: the plan's choice for meshes of 750 k nodes and more, tri3_energy.hip).
+template <int BLOCK, int NPT, int EPT, int ABL, int CAPO = 0, bool HASB = false, int CAPN = 0, typename V2 = double2, bool PHYS = false, int SP = 16>
 __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
     const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
@@ -476,14 +477,14 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
             if (gx_free && s[j].x >= 0) {
                 V2 v;
                 v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
-                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, 16);
-                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, 16);
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, SP);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, SP);
             }
             if (gu_free && s[j].y >= 0) {
                 V2 v;
                 v.x = acc2[l]; v.y = acc3[l];
-                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, 16);
-                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, 16);
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, SP);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, SP);
             }
         }
     }
@@ -975,6 +976,14 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
             if (hasb) HFEM_LAUNCH_Q4V(double2, 4, 4, 0, 0, true, 0, double2, true);
             else HFEM_LAUNCH_Q4V(double2, 4, 4, 0, 0, false, 0, double2, true);
         } else if (hasb) HFEM_LAUNCH_Q4(4, 4, 0, 0, true);               // body force: general instance (runtime strides)
+        else if (plan->tune.store_policy == 2 && g_quad4_const_caps && h.max_nodes <= 672 && h.max_owned <= 560 && h.max_elems <= 3 * 256) {
+            // big meshes: nt gradient stores (the plan's store policy), default tile shape
+            hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 3, 3, 0, 560, false, 672, double2, false, 2>), dim3(n), dim3(256), (size_t)39552, s,
+                               plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,
+                               (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
+                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, 672, 560, skip_edges, stagger, sshift,
+                               plan->d_stamps, body);
+        } else if (plan->tune.store_policy == 2) HFEM_LAUNCH_Q4(4, 4, 0, 0, false, 0, double2, false, 2);
         else if (g_quad4_const_caps && h.max_nodes <= 672 && h.max_owned <= 560 && h.max_elems <= 3 * 256) {
             // default tile shape (557 owned nodes): compile-time LDS strides, (672 + 560) * 32 + 128 = 39552 B: 4 workgroups per CU
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 3, 3, 0, 560, false, 672>), dim3(n), dim3(256), (size_t)39552, s,

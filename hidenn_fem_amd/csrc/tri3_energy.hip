@@ -445,8 +445,9 @@ using namespace hfem;
 namespace {
 struct Defaults {
     std::atomic<int> tiled_block{512};      // threads per tile (measured best on T1M: 512)
-    std::atomic<int> store_policy{16};      // gradient stores: 16 = sc1 (write-through: the line is dropped from the XCD's
-                                            // L2 and does not evict the re-read inputs / plan arrays), 0 = plain
+    std::atomic<int> store_policy{-1};      // gradient stores: 16 = sc1 (write-through: the line is dropped from the XCD's
+                                            // L2 and does not evict the re-read inputs / plan arrays), 2 = nt (non-temporal),
+                                            // 0 = plain; -1 = by mesh size (hfem_plan_create: nt from 750 k nodes)
     std::atomic<int> tiled_fast{1};         // register-prefetched kernel (0: the generic loop kernel)
     std::atomic<int> fast_const_caps{1};    // default tile shape: instance with compile-time accumulator strides
     std::atomic<int> pair_pipe_wps{4};      // pipelined kernel: register budget sized for this many waves per SIMD (3 or 4)
@@ -475,7 +476,7 @@ struct Defaults {
 hfem_plan::Tune current_tune() {
     hfem_plan::Tune t;
     t.tiled_block = g_def.tiled_block.load();
-    t.store_policy = g_def.store_policy.load();
+    t.store_policy = g_def.store_policy.load();          // -1 (auto) is resolved by hfem_plan_create, which knows the mesh
     t.tiled_fast = g_def.tiled_fast.load();
     t.fast_const_caps = g_def.fast_const_caps.load();
     t.pair_tiles_per_wg = g_def.pair_tiles_per_wg.load();
@@ -533,9 +534,15 @@ bool launch_fast_f64(const hfem_plan *plan, const Tri3Launch &A, int n, bool has
     const int n_lag = n + (lag.prev ? 1 : 0);
     // default shape (auto tile policy: <= 557 owned nodes): compile-time stride of the four accumulator arrays (12 of an
     // element's 18 LDS addresses); the footprint must stay <= 38 912 B (four workgroups per CU)
-    if (plan->tune.fast_const_caps && blk == 512 && !hasb && sp == 16 && h.max_nodes > 512 && h.max_owned <= 560 &&
+    if (plan->tune.fast_const_caps && blk == 512 && !hasb && (sp == 16 || sp == 2) && h.max_nodes > 512 && h.max_owned <= 560 &&
         h.max_nodes * 32 + 560 * 32 + 128 <= 38912 && h.max_elems <= 3 * 512) {
-        launch_fast<512, 2, 3, false, 16, double2, 560, false, false>(A, n_lag, AdamFuse{}, lag);
+        if (sp == 2) launch_fast<512, 2, 3, false, 2, double2, 560, false, false>(A, n_lag, AdamFuse{}, lag);   // nt stores (big meshes)
+        else launch_fast<512, 2, 3, false, 16, double2, 560, false, false>(A, n_lag, AdamFuse{}, lag);
+        return true;
+    }
+    if (sp == 2 && blk == 512 && !hasb && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512) {      // nt stores, general 512-thread shapes
+        if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 2, double2, 0, false, false>(A, n_lag, AdamFuse{}, lag);
+        else launch_fast<512, 2, 4, false, 2, double2, 0, false, false>(A, n_lag, AdamFuse{}, lag);
         return true;
     }
 #define HFEM_FAST_HB(BLK, NPT, EPT)                                                                                       \
@@ -647,6 +654,17 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     *out = nullptr;
     std::unique_ptr<hfem_plan> p(new hfem_plan);
     p->tune = current_tune();
+    // Gradient-store policy by mesh size (scripts/store_policy_sweep.py, profiles/r03/store_policy_sweep.jsonl; fraction of the
+    // 8 TB/s roofline, same buffers every launch / rotating sets that exceed the Infinity Cache):
+    //   10^6 elements    sc1 0.60 / 0.46    nt 0.55 / 0.51
+    //   2 10^6           sc1 0.57 / 0.48    nt 0.56 / 0.54
+    //   4 10^6           sc1 0.66 / 0.56    nt 0.66 / 0.65
+    // Write-through stores of 16-byte rows are partial-line writes; on lines the Infinity Cache does not hold they cost a fill.
+    // nt stores are merged in L2 and leave at the kernel's end: regime-independent, 9 % slower only where everything is
+    // cache-resident.  A training loop's working set (x, u, gradients, two moments each, the plan: ~190 B per node) stays in
+    // the 256 MB Infinity Cache up to ~10^6 nodes; from 750 k nodes the plan takes nt stores.
+    const bool auto_store = p->tune.store_policy < 0;
+    if (auto_store) p->tune.store_policy = nn >= 750000 ? 2 : 16;
     int32_t node_cap = g_def.plan_node_cap.load();
     const int32_t shards = std::max(1, g_def.plan_shards.load());
     int32_t pair_block = g_def.plan_pair_block.load();
@@ -689,6 +707,31 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
             return -1;
     }
     const HostPlan &h = p->host;
+    // Locality figure of the caller's row numbering as the tiles see it: distinct 128-byte lines (8 rows of 16 bytes) among a
+    // tile's coordinate rows / the minimum, averaged over the tiles.  ~1.3 for stored-along-the-curve or row-major structured
+    // numberings, up to 8 for a random one (every gathered row pulls its own line; hidenn_fem_amd/models.py repairs that
+    // with reorder="auto").  nt stores are merged line-wise in L2 -- on scattered rows there is nothing to merge and they
+    // lose (cfg5 as numbered: 169 vs 128 us), so such plans keep the write-through stores.
+    {
+        double acc = 0.0;
+        int64_t cnt = 0;
+        std::vector<int32_t> lines;
+        for (const TileDesc &d : h.tiles) {
+            lines.clear();
+            for (int32_t l = 0; l < d.n_node; ++l) {
+                const int32_t r = h.node_src[2 * ((size_t)d.node_off + l)];
+                if (r >= 0) lines.push_back(r >> 3);
+            }
+            if (lines.empty()) continue;
+            const size_t rows = lines.size();
+            std::sort(lines.begin(), lines.end());
+            const size_t distinct = std::unique(lines.begin(), lines.end()) - lines.begin();
+            acc += (double)distinct / (double)((rows + 7) / 8);
+            ++cnt;
+        }
+        p->row_line_factor = cnt ? acc / (double)cnt : 1.0;
+    }
+    if (auto_store && p->tune.store_policy == 2 && p->row_line_factor > 2.5) p->tune.store_policy = 16;
     p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
     p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
     if (device >= 0) {
@@ -732,6 +775,8 @@ extern "C" int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out) 
     out->threads_per_tile = h.paired ? h.pair_block : (h.npe == 4 ? 256 : plan->tune.tiled_block);
     out->paired = h.paired ? 1 : 0;
     out->slot_rows = h.paired ? h.max_rows : 0;
+    out->store_policy = plan->tune.store_policy;
+    out->row_line_factor = plan->row_line_factor;
     return 0;
 }
 
@@ -820,7 +865,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     double *pbase = plan->d_partials + (size_t)wbank * nt;
     LagSum lag;
     if (lag_consume) {
-        HFEM_ARG_CHECK(h.paired || (plan->tune.tiled_fast && plan->tune.tiled_block == 512 && !hasb && !phys && plan->tune.store_policy == 16 &&
+        HFEM_ARG_CHECK(h.paired || (plan->tune.tiled_fast && plan->tune.tiled_block == 512 && !hasb && !phys && plan->tune.store_policy != 0 &&
                        h.max_nodes <= 1024 && h.max_elems <= 2048),
                        "HFEM_FLAG_SUM_PREVIOUS: only the default (register-prefetched, 512-thread) kernel path implements it");
         lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
@@ -1116,7 +1161,8 @@ extern "C" int hfem_set_option(const char *name, int value) {
         HFEM_ARG_CHECK(value == 256 || value == 512 || value == 1024, "tiled_block must be 256, 512 or 1024");
         g_def.tiled_block = value;
     } else if (n == "store_policy") {
-        HFEM_ARG_CHECK(value == 0 || value == 16, "store_policy: 0 (plain) or 16 (sc1 write-through)");
+        HFEM_ARG_CHECK(value == -1 || value == 0 || value == 2 || value == 16 || value == 17 || value == 18,
+                       "store_policy: -1 (by mesh size, default), 16 (sc1 write-through), 2 (nt), 0 (plain), 17 (sc0 sc1), 18 (sc1 nt)");
         g_def.store_policy = value;
     } else if (n == "tiled_fast") {
         g_def.tiled_fast = value ? 1 : 0;

@@ -22,11 +22,12 @@ namespace hfem {
 // register budget is sized for.  Measured best on T1M (round 2, profiles/r02): 256 threads, three slots per thread,
 // 86 VGPRs, four workgroups per CU -- 9.5 us against 11.2 us for the one-element-per-slot kernel at 512 threads.
 // CAPO > 0: compile-time stride of the four accumulator arrays.  LDS layout as tri3_energy_fast_kernel.
+// SP: cache policy (aux bits) of the gradient stores: 16 = sc1 write-through (default), 0 plain, 2 nt, 17 sc0|sc1, 18 sc1|nt.
 // HASB: body-force table; PHYS: opt-in physical gradient convention (hfem_device.h); V2: row storage type (double2, or
 // float2 for fp32 models: widened on load, rounded once on store, fp64 arithmetic); ADAM: the write-out applies
 // torch.optim.Adam's update instead of storing the gradient (AdamFuse, hfem_tri3_energy_adam_step).
 template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
-          bool ADAM = false, bool CHAIN = false, int CAPN = 0>
+          bool ADAM = false, bool CHAIN = false, int CAPN = 0, int SP = 16>
 __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
     const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
@@ -241,14 +242,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
             if (gx_free && s[j].x >= 0) {
                 V2 v;
                 v.x = acc0[l]; v.y = acc1[l];           // rounds once for float2
-                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, 16);
-                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, 16);
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), rx, s[j].x * 16, 0, SP);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, SP);
             }
             if (gu_free && s[j].y >= 0) {
                 V2 v;
                 v.x = acc2[l]; v.y = acc3[l];
-                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, 16);
-                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, 16);
+                if (kWide) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), ru, s[j].y * 16, 0, SP);
+                else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, SP);
             }
         }
     }
@@ -267,11 +268,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
 }
 
 constexpr int kPairCapN = 656, kPairCapO = 560;          // compile-time LDS strides of the default tile shape (557 owned nodes)
-template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM, bool CHAIN>
+template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM, bool CHAIN, int SP = 16>
 static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
     constexpr int CAPN = CAPO > 0 ? kPairCapN : 0;
     const size_t lds = CAPO > 0 ? (size_t)(CAPN * 32 + CAPO * 32 + 128) : A.lds;
-    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN>), dim3(A.grid), dim3(BLK), lds, A.s,
+    hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN, SP>), dim3(A.grid), dim3(BLK), lds, A.s,
                        A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
                        (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
                        CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride);
@@ -332,7 +333,44 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
         case 5: launch_pair_inst<256, NPT, 5, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
         default: launch_pair_inst<256, NPT, 6, CO, HB, PH, V, AD>(A, lag, af); return 1;          \
     }
+    // nt (non-temporal) gradient stores -- the plan's store policy for meshes whose gradient arrays cannot stay in the
+    // Infinity Cache (hfem_plan_create, "store_policy" -1): instances for the plain slot loop and up to four slot rows; other
+    // shapes keep the write-through stores
+    const bool nt = plan->tune.store_policy == 2 && !A.chain && ept <= 4;
+#define HFEM_PAIR_NT(NPT, CO, V)                                                                              \
+    {                                                                                                         \
+        if (ept <= 3) launch_pair_inst2<256, NPT, 3, CO, false, false, V, false, false, 2>(A, lag, af);      \
+        else launch_pair_inst2<256, NPT, 4, CO, false, false, V, false, false, 2>(A, lag, af);               \
+        return 1;                                                                                             \
+    }
+    if (mode == 0 && nt) {
+        if (cc && npt == 3) HFEM_PAIR_NT(3, 560, double2)
+        if (npt == 3) HFEM_PAIR_NT(3, 0, double2)
+        HFEM_PAIR_NT(4, 0, double2)
+    }
+    if (mode == 2 && nt) {
+        if (npt == 3) HFEM_PAIR_NT(3, 0, float2)
+        HFEM_PAIR_NT(4, 0, float2)
+    }
+#undef HFEM_PAIR_NT
     if (mode == 0) {
+        const int sp = plan->tune.store_policy;
+        if (cc && npt == 3 && ept <= 3 && sp != 16 && !A.chain) {        // "store_policy" A/B instances of the default tile shape
+            const size_t lds = (size_t)(kPairCapN * 32 + kPairCapO * 32 + 128);
+#define HFEM_PAIR_SP(SPV)                                                                                                  \
+    hipLaunchKernelGGL((tri3_energy_pair_kernel<256, 3, 3, 4, 560, false, false, double2, false, false, kPairCapN, SPV>),  \
+                       dim3(A.grid), dim3(256), lds, A.s, A.pd, A.tile_begin, (const double2 *)A.x_free,                   \
+                       (const double2 *)A.x_fixed, (const double2 *)A.u_free, (const double2 *)A.u_fixed, A.k, A.T_edge,   \
+                       A.tc, A.partials, (double2 *)A.gx, (double2 *)A.gu, A.max_nodes, 560, A.skip_edges, lag, af,         \
+                       A.col_stride)
+            switch (sp) {
+                case 0: HFEM_PAIR_SP(0); return 1;
+                case 17: HFEM_PAIR_SP(17); return 1;
+                case 18: HFEM_PAIR_SP(18); return 1;
+                default: break;
+            }
+#undef HFEM_PAIR_SP
+        }
         if (cc && npt == 3) HFEM_PAIR_EPT(3, 560, false, false, double2, false)
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, false)
         HFEM_PAIR_EPT(4, 0, false, false, double2, false)

@@ -98,6 +98,11 @@ typedef struct hfem_plan_stats {
     int32_t threads_per_tile;             /* workgroup size of the tiled kernel this plan takes */
     int32_t paired;                       /* 1: paired slots (two fan-adjacent TRI3 per slot) */
     int32_t slot_rows;                    /* paired plans: slots per thread in the widest tile */
+    int32_t store_policy;                 /* gradient stores of this plan: 16 sc1 write-through, 2 nt (meshes of >= 750 k nodes
+                                             whose rows have locality), 0 plain -- "store_policy" -1 = this choice */
+    int32_t reserved0;
+    double row_line_factor;               /* distinct 128-byte lines among a tile's coordinate rows / the minimum, mean over the
+                                             tiles: ~1.3 = rows stored with locality, up to 8 = random numbering */
 } hfem_plan_stats;
 
 int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
@@ -208,7 +213,8 @@ int hfem_plan_set_span_stamps(hfem_plan *plan, uint64_t *dev_buf, int64_t n_slot
 /* Process-wide DEFAULTS (atomics) that hfem_plan_create captures into the plan it builds; changing one
  * never affects an existing plan, and launches on different plans may run from different threads (a plan
  * serialises its own launches with a mutex).  Product knobs: "tiled_block" (threads per tile of the
- * one-element-per-slot kernels: 256, 512, 1024), "store_policy", "tiled_fast", "fast_const_caps", "quad4_const_caps",
+ * one-element-per-slot kernels: 256, 512, 1024), "store_policy" (gradient stores: -1 = by mesh size and row locality -- nt
+ * from 750 k nodes, sc1 write-through below --, 16, 2, 0), "tiled_fast", "fast_const_caps", "quad4_const_caps",
  * "plan_elem_order" (-1 auto, 3 one element per slot, 5 paired slots, 6 paired slots chained into strips), "plan_node_cap"
  * (home nodes per tile; -1 = the shard-aware policy), "plan_shards" (ranks the tiles will be split over: tiles are sized
  * for the elements PER RANK and every rank's boundary tiles come first in its range), "plan_pair_block" (threads per tile

@@ -88,6 +88,8 @@ struct HostPlan {
     int32_t shards = 1;
     std::vector<int32_t> shard_desc;
     int32_t pair_block = 256;          // paired plans: threads per tile = columns of a tile's slot array (256 or 512)
+    std::vector<int32_t> owned_gid;    // global node id of every tile's owned nodes, (tile, local) order: a permutation of the nodes
+    std::vector<int32_t> owned_gid_by_slot;   // build scratch: node id of every compact node record
 };
 constexpr int kChunks = 3;
 

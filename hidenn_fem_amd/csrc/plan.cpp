@@ -952,8 +952,8 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             P.node_src.push_back(x_src ? x_src[n] : n);
             P.node_src.push_back(u_src ? u_src[n] : n);
         };
-        for (int32_t n : own_order) push_node(n);
-        for (int32_t n : halo) push_node(n);
+        for (int32_t n : own_order) { push_node(n); P.owned_gid_by_slot.push_back(n); }
+        for (int32_t n : halo) { push_node(n); P.owned_gid_by_slot.push_back(n); }
         for (int64_t i = edg_ptr[t]; i < edg_ptr[t + 1]; ++i) {
             const int32_t g = tedge[i];
             const int64_t ni = edges[2 * (int64_t)g], nj = edges[2 * (int64_t)g + 1];
@@ -986,6 +986,15 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
             P.shard_desc.insert(P.shard_desc.end(), {lo, mid, hi, 0});
         }
         if (shards > 1) P.tiles.swap(sorted_tiles);
+    }
+    // owned node ids in (final tile order, local order): every node exactly once -- the TILE-MAJOR node order a caller can store
+    // its parameter rows in (hfem_plan_export 11; hidenn_fem_amd/models.py reorder="tile")
+    {
+        std::vector<int32_t> og;
+        og.reserve(nn);
+        for (const TileDesc &d : P.tiles)
+            for (int32_t l = 0; l < d.n_owned; ++l) og.push_back(P.owned_gid_by_slot[(size_t)d.node_off + l]);
+        P.owned_gid.swap(og);
     }
     // ---- uniform node stride: tile t's row-map records start at t * node_stride, so a kernel can load them from its
     //      tile index alone, in parallel with the descriptor (one dependent memory round trip less: desc -> maps -> rows

@@ -797,6 +797,7 @@ extern "C" int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf,
         case 8: src = h.tile_chunks.data(); n = (int64_t)h.tile_chunks.size(); break;
         case 9: src = h.elem_gid_b.data(); n = (int64_t)h.elem_gid_b.size(); break;
         case 10: src = h.shard_desc.data(); n = (int64_t)h.shard_desc.size(); break;
+        case 11: src = h.owned_gid.data(); n = (int64_t)h.owned_gid.size(); break;
         case 6: {   // lab build: device stamps, 16 x uint64 per tile, returned as 32 x int32 per tile
             n = (int64_t)h.tiles.size() * 32;
             if (buf) {

@@ -25,10 +25,11 @@ def _np_mask(t):
     return t.detach().cpu().numpy().astype(bool)
 
 
-ROW_LINE_THRESHOLD = 1.6      # reorder="auto": store the parameter rows along the locality curve above this figure (row-major
-                              # structured numberings read 1.4-1.5 and gain nothing -- T1M 9.03 vs 9.38 us, T2M 19.6 vs 19.6 --;
-                              # the Delaunay generator's 1.74 gains 6 %: 40.6 -> 38.1 us; random numberings, 8.0, gain 3.6x)
-ROW_REORDER_MIN_NODES = 4096  # ... and only for meshes big enough for it to matter (smaller ones live in the caches)
+ROW_REORDER_MIN_NODES = 4096  # reorder="auto": meshes of this many nodes or more store their parameter rows TILE-MAJOR (smaller ones
+                              # live in the caches and keep the reference's layout).  Measured against the numbering as given
+                              # (us per launch, same buffers / rotating sets beyond the Infinity Cache): row-major structured
+                              # T1M 9.12 / 11.8 -> 8.96 / 10.8, T2M 19.65 -> 18.75, random numbering (cfg5) 128 -> 34.6,
+                              # Delaunay 40.6 -> 38.9; rows along the Hilbert curve ("hilbert"): T1M 9.38, cfg5 36.3
 
 
 def row_line_factor(rows_along_curve: np.ndarray, chunk: int = 512, rows_per_line: int = 8) -> float:
@@ -248,15 +249,18 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
                  neumann_edges=None, reorder="auto"):
         """Reference signature (models.py:242-251) plus ``reorder``: how the rows of the two parameter tensors are
         STORED.  The reference hands over whatever numbering the mesher produced (mesh.py:136-144); a tile gathers
-        16-byte rows, so a numbering without locality costs up to 8x the read traffic.  ``"auto"`` (default) measures
-        the numbering (``row_line_factor``) and, when it is poor on a mesh of >= 4096 nodes, stores
-        ``node_coords_free`` / ``u_free`` along the Hilbert curve of the initial coordinates; ``"hilbert"`` always
-        does, ``"off"`` never.  Node numbering, ``connectivity``, masks, ``coords``, ``u_full``, ``forward`` and
+        16-byte rows and writes 16-byte gradient rows, so a numbering without locality costs up to 8x the read traffic
+        and even a row-major one makes most of a tile's gradient stores partial 128-byte lines.  ``"auto"`` (default):
+        meshes of >= 4096 nodes store ``node_coords_free`` / ``u_free`` TILE-MAJOR -- the rows of the nodes a tile of the
+        default plan owns are one contiguous run (``"tile"`` forces it; costs one host-side plan build at construction);
+        ``"hilbert"``: rows along the Hilbert curve of the initial coordinates; ``"off"``: the reference's layout, bit
+        for bit.  ``row_line_factor`` reports the locality of the numbering as given (1 = along the curve, 1.4-1.5
+        row-major structured, 8 = random).  Node numbering, ``connectivity``, masks, ``coords``, ``u_full``, ``forward`` and
         ``state_dict()`` stay in the CALLER's numbering either way; only the raw parameter tensors (and hence
         ``.grad`` and optimiser state) are in storage order -- ``to_caller_order`` / ``from_caller_order`` convert."""
         super().__init__()
-        if reorder not in ("auto", "hilbert", "off"):
-            raise ValueError("reorder must be 'auto', 'hilbert' or 'off'")
+        if reorder not in ("auto", "hilbert", "tile", "off"):
+            raise ValueError("reorder must be 'auto', 'tile', 'hilbert' or 'off'")
         self.scale = 1e-5
         self.dim_u = 2
         # opt-in (SURVEY F4): "reference" = dN_dx = Jinv * dN_dxi exactly as models.py:351; "physical" = Jinv^T
@@ -282,9 +286,19 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
             cf, cu = curve[fm[curve]], curve[um[curve]]
             caller_row_x = np.cumsum(fm) - 1                     # row of node n in the caller's numbering
             self.row_line_factor = row_line_factor(caller_row_x[cf])
-            if reorder == "hilbert" or (self.row_line_factor > ROW_LINE_THRESHOLD and self.Nnodes >= ROW_REORDER_MIN_NODES):
+            if reorder == "hilbert":
                 idx_free, idx_ufree = cf, cu
                 self.row_order = "hilbert"
+            elif reorder == "tile" or (reorder == "auto" and self.Nnodes >= ROW_REORDER_MIN_NODES):
+                # TILE-MAJOR: the rows of the nodes a tile owns are one contiguous run, in the tile's local order (host-only
+                # plan of the default tiling; hfem_plan_export 11): every gradient store covers whole 128-byte lines and the
+                # gather of the owned rows is perfectly coalesced
+                hp = TilePlan(connectivity, self.Nnodes, coords_hint=node_coords, edges=neumann_edges, device=None,
+                              nodes_per_elem=connectivity.shape[1])
+                tm = hp.export("owned_node_ids").astype(np.int64)
+                hp.close()
+                idx_free, idx_ufree = tm[fm[tm]], tm[um[tm]]
+                self.row_order = "tile"
         t_free = torch.from_numpy(idx_free).to(node_coords.device)
         self.node_coords_free = nn.Parameter(node_coords[t_free].clone())
         self.register_buffer("node_coords_fixed", node_coords[boundary_mask].clone())

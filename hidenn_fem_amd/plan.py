@@ -16,7 +16,8 @@ import torch
 from . import _lib
 
 EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
-              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8, "elem_gid_b": 9, "shard_desc": 10}
+              "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8, "elem_gid_b": 9, "shard_desc": 10,
+              "owned_node_ids": 11}
 
 
 def _np(a, dtype):

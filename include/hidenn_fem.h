@@ -122,7 +122,10 @@ int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
  * (lab build only), 7 elem_pack_hi u32 (QUAD4 plans: 4th local node of every slot; paired TRI3
  * plans: node d + presence/home bits of element B), 8 tile_chunks (chunked lab order), 9 elem_gid_b
  * i32 (paired plans: global id of every slot's element B; -1 = none), 10 shard_desc [shards][4] i32 = {tile_lo,
- * tile_mid, tile_hi, 0} per rank: the rank's boundary tiles are [tile_lo, tile_mid), its interior tiles [tile_mid, tile_hi).
+ * tile_mid, tile_hi, 0} per rank: the rank's boundary tiles are [tile_lo, tile_mid), its interior tiles [tile_mid, tile_hi),
+ * 11 owned_node_ids [Nn] i32: the global node id of every tile's owned nodes in (tile, local) order -- a permutation of the
+ * nodes; a caller that stores its parameter rows in THIS order gives every tile one contiguous run of rows (full-line
+ * gradient stores, perfectly coalesced gathers).
  * Returns the element count, or <0.  buf may be NULL to query the size.  The per-tile arrays are laid out
  * with uniform strides (tile t's node records start at t * node_stride, its slot records at t * elem_stride, padded;
  * extra records follow the last tile): walk them through tile_desc's offsets and counts, not as dense arrays.    */

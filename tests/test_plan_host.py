@@ -533,7 +533,7 @@ def test_tile_local_nodes_follow_the_row_order_when_rows_are_stored_along_the_cu
     mesh = structured_tri_mesh(129, 65, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=torch.float64)
     c, conn, g, b, mn, e = mesh
     kw = dict(boundary_mask=g, dirichlet_mask=b, u_fixed=0.0, neumann_edges=e)
-    for reorder, sorted_by_row in (("auto", True), ("off", False)):
+    for reorder, sorted_by_row in (("hilbert", True), ("tile", True), ("off", False)):
         m = PiecewiseLinearShapeNN2D(c, conn, reorder=reorder, **kw)
         plan = TilePlan(conn, c.shape[0], coords_hint=c, x_src=m._x_src, u_src=m._u_src, edges=e)
         td, ns = plan.export("tile_desc"), plan.export("node_src")
@@ -549,7 +549,7 @@ def test_tile_local_nodes_follow_the_row_order_when_rows_are_stored_along_the_cu
             lines.append(len(np.unique(rows[rows >= 0] // 8)) / max(1, (rows >= 0).sum() / 8))
         if sorted_by_row:
             assert n_sorted == 2 * td.shape[0]
-            assert np.mean(lines) < 2.0                        # a tile's rows sit in few 128-byte lines
+            assert np.mean(lines) < 3.0                        # a tile's rows (halo included) sit in few 128-byte lines
         else:
             assert np.mean(lines) > 4.0                        # as given: nearly one line per row
         # the partition invariants do not depend on the local order

@@ -581,6 +581,8 @@ def main():
             # for information: the same leg on a plan created with "store_policy" = 2 (nt gradient stores) -- what plans of
             # >= 750 k nodes take by default and what a caller whose T1M-sized buffers are NOT cache-resident should set
             try:
+                if only:
+                    raise StopIteration          # profiler helper runs: the regime's own launches only
                 from hidenn_fem_amd.plan import TilePlan
                 prev_sp = L.hfem_get_option(b"store_policy")
                 _lib.check(L.hfem_set_option(b"store_policy", 2), "hfem_set_option")
@@ -594,6 +596,8 @@ def main():
                 t_nt_rep, _ = time_launches(lambda i: ko_nt(), kreps)
                 regimes["rotating_sets"]["nt_stores"] = dict(rotating_kernel_us=t_nt, replayed_kernel_us=t_nt_rep)
                 del ko_nt, plan_nt
+            except StopIteration:
+                pass
             except Exception as e:  # noqa: BLE001
                 note(f"nt-store leg failed: {type(e).__name__}: {str(e)[:120]}")
             del sets

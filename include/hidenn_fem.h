@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HFEM_VERSION 100   /* 0.1.0 */
+#define HFEM_VERSION 110   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
 
 int hfem_version(void);
 const char *hfem_last_error(void);

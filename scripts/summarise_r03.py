@@ -28,7 +28,9 @@ if os.path.exists(os.path.join(src, "kernel_stats_replayed.csv")):
            "shape": shapes.get("T1M", ("1000000/501501/1024",))[0], "alg_bytes_per_launch": ALG, "regimes": {}}
     for r in ("replayed", "rewritten_inputs", "rotating_sets"):
         rows = [x for x in csv.DictReader(open(os.path.join(src, f"kernel_stats_{r}.csv"))) if "tri3_energy_" in x["Name"]]
-        k = max(rows, key=lambda x: float(x["TotalDurationNs"]))
+        # T1M's plan takes the sc1 (16) store instance; other instances of the kernel in the same run are other legs
+        sc1 = [x for x in rows if x["Name"].split("(")[0].rstrip().endswith(", 16>")]
+        k = max(sc1 or rows, key=lambda x: float(x["TotalDurationNs"]))
         avg = float(k["AverageNs"]) * 1e-3
         out["regimes"][r] = {"kernel": k["Name"][:90], "calls": int(k["Calls"]), "avg_us": avg, "min_us": float(k["MinNs"]) * 1e-3,
                              "frac_of_8TBs": ALG / avg * 1e-6 / 8000.0}

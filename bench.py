@@ -746,6 +746,37 @@ def main():
             print(json.dumps(dict(only_extra=a.only_extra, extras=extras)), flush=True)
         return None
 
+    # ---- config.fp32_rows (N = 1): T1M as the reference would run it by default -- an fp32 model (src/loss.py:16,
+    #      src/models.py:274): float rows widened on load, gradients rounded once on store, fp64 arithmetic and loss; kernel
+    #      only, its own algorithmic bytes (12 Ne + 32 Nn + 8)
+    fp32_leg = None
+    if world == 1 and not a.no_extra:
+        try:
+            m32 = PiecewiseLinearShapeNN2D(coords.float(), conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                           neumann_edges=edges, reorder=a.reorder).to(dev)
+            pl32 = m32.tile_plan(a.tile_elems)
+            x32, u32 = m32.node_coords_free.detach(), m32.u_free.detach()
+            xfx32, ufx32 = m32.node_coords_fixed, m32.u_fixed_rows()
+            gx32, gu32 = torch.empty_like(x32), torch.empty_like(u32)
+            ls32 = torch.zeros((), dtype=f64, device=dev)
+            lf32 = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=torch.float32)
+            _, Tc32 = lf32._traction(m32, None)
+            mat32, Tcv32, Bk32 = dv(lf32._mat), dv(Tc32), dv([0.0] * 6)
+
+            def launch32(i):
+                _lib.check(L.hfem_tri3_energy_plan_f32(pl32.handle, x32.data_ptr(), xfx32.data_ptr(), u32.data_ptr(), ufx32.data_ptr(),
+                                                       mat32, lf32._W, Bk32, None, Tcv32, 0, -1, ls32.data_ptr(), gx32.data_ptr(),
+                                                       gu32.data_ptr(), 8, stream_box[0].cuda_stream), "hfem_tri3_energy_plan_f32")
+            us32, _ = time_launches(launch32, kreps)
+            ab32 = 12 * ne + 32 * nn + 8
+            fp32_leg = dict(workload="T1M with fp32 parameter / gradient rows (the reference's default dtype), fp64 arithmetic",
+                            kernel_us=us32, element_evals_per_s=ne / (us32 * 1e-6), alg_bytes_per_launch=ab32,
+                            achieved=ab32 / (us32 * 1e-6) / 1e9, frac=ab32 / (us32 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            regime="replayed (same buffers every launch)")
+            del m32, pl32
+        except Exception as e:  # noqa: BLE001
+            note(f"fp32_rows leg failed: {type(e).__name__}: {str(e)[:160]}")
+
     # ---- config.strong_scaling_emulated (N = 1): BASELINE configs[3] AS STATED on one GPU -- the FIXED 10^6-element mesh
     #      sharded N ways by a plan prepared for N ranks (shard-aware tile policy), kernel only over the tile range of the
     #      first, a middle and the last rank; the max is what a strong-scaling step waits for
@@ -842,6 +873,8 @@ def main():
             out["config"]["inline_loss_step"] = inline_step
         if train1 is not None:
             out["config"]["train_step_1gpu"] = train1
+        if fp32_leg is not None:
+            out["config"]["fp32_rows"] = fp32_leg
         if strong_emu is not None:
             out["config"]["strong_scaling_emulated"] = strong_emu
         if eval_ov is not None:

@@ -17,6 +17,7 @@ then ONE small all_gather of interface parameter rows + partial energies -- owne
 kernel's stream, the K steps in one hipGraph).  Beside it, in `config`:
   eval_exchange_overlap             the headline step with the exchange of step k under the interior tiles of step k + 1
   train_step / train_step_overlap   whole Adam iterations (exchange on the critical path / hidden under the interior tiles)
+  train_step_fused[_overlap]        the same with Adam applied by the energy kernel's own write-out (three launches per step)
   alt_exchange                      the north-star's literal wording: a dense sum all-reduce of [gX|gU|loss]
   strong_scaling                    BASELINE configs[3] and [4] AS STATED: 10^6 TRI3 FIXED sharded over the N ranks (and, at
                                     N = 8, the 4.1 M-element Delaunay mesh), kernel-only per rank and end to end
@@ -215,8 +216,8 @@ def main():
                 run()
         if begin:
             begin()
-        for _ in range(a.warmup):
-            body()
+        for _ in range(a.warmup + (a.warmup & 1)):      # W warm-up steps (rounded up to even: the fused steps alternate between
+            body()                                      # two parameter buffers and a captured graph assumes the parity it saw)
         if end:
             end()
         run()
@@ -427,7 +428,7 @@ def main():
 
     if world > 1:
         sh.setup_interfaces()
-        sh.init_owner_adam(lr_x=1e-9, lr_u=1e-12)      # tiny steps: the mesh stays valid over any number of iterations
+        sh.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)      # tiny steps: the mesh stays valid over any number of iterations
 
     def step_dense():           # north-star literal: one all-reduce of [gX|gU|loss] (every rank gets everything)
         sh.evaluate_local()
@@ -482,7 +483,7 @@ def main():
         return dict(mode=mode, value=n_elems / (el / a.steps), ms_per_step=el / a.steps * 1e3, launch=ln,
                     ms_per_step_replays=[round(r / a.steps * 1e3, 5) for r in regs])
 
-    alt = train = train_ov = strong = eval_ov = None
+    alt = train = train_ov = strong = eval_ov = train_fused = train_fused_ov = None
     exchange_mode = "serial: evaluation -> pack -> all_gather -> unpack on one stream"
     if world > 1:
         how = comm_state
@@ -502,6 +503,14 @@ def main():
         train_ov = leg(sh.owner_train_step_overlapped, "the same iteration, exchange of step k on a side stream under the "
                        f"interior tiles of step k+1 (boundary tiles {sh.mid - sh.lo} of {sh.hi - sh.lo} on this rank)", ne,
                        end_=sh.finish_overlapped)
+        if a.steps % 2 == 0:          # the fused steps alternate between two parameter buffers: an even number per hipGraph
+            train_fused = leg(sh.owner_train_step_fused, "owner-sharded training iteration with Adam applied by the energy kernel's "
+                              "write-out (hfem_tri3_energy_adam_step_ex on the rank's tile range): energy+Adam -> pack -> all_gather "
+                              "-> unpack, three launches + the collective, no gradient traffic", ne)
+            train_fused_ov = leg(sh.owner_train_step_fused_overlapped, "the fused iteration with the exchange under the next step's "
+                                 "interior tiles", ne, end_=sh.finish_overlapped)
+        else:
+            note("fused training legs skipped: --steps must be even (ping-pong parameter buffers inside one hipGraph)")
 
     # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
     def strong_leg(name, mesh6_s):
@@ -509,7 +518,7 @@ def main():
         lf_s = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
         sh_s = ShardedTri3Energy(m_s, lf_s, comm=comm)
         sh_s.setup_interfaces()
-        sh_s.init_owner_adam(lr_x=1e-9, lr_u=1e-12)
+        sh_s.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)
         ne_s, nn_s = mesh6_s[1].shape[0], mesh6_s[0].shape[0]
         ko = KernelOnly(m_s, lf_s, sh_s.plan, sh_s.lo, sh_s.hi)
         us, _ = time_launches(lambda i: ko(), max(a.steps, 50))
@@ -532,6 +541,10 @@ def main():
                    train_step=leg(sh_s.owner_train_step, "Adam iteration, exchange on the critical path", ne_s),
                    train_step_overlap=leg(sh_s.owner_train_step_overlapped, "Adam iteration, exchange under the next step's interior tiles",
                                           ne_s, end_=sh_s.finish_overlapped))
+        if a.steps % 2 == 0:
+            res["train_step_fused"] = leg(sh_s.owner_train_step_fused, "Adam inside the energy launch, exchange on the critical path", ne_s)
+            res["train_step_fused_overlap"] = leg(sh_s.owner_train_step_fused_overlapped, "Adam inside the energy launches, exchange "
+                                                  "under the next step's interior tiles", ne_s, end_=sh_s.finish_overlapped)
         del sh_s, m_s, ko
         return res
 
@@ -887,6 +900,9 @@ def main():
             out["config"]["train_step"] = train
         if train_ov is not None:
             out["config"]["train_step_overlap"] = train_ov
+        if train_fused is not None:
+            out["config"]["train_step_fused"] = train_fused
+            out["config"]["train_step_fused_overlap"] = train_fused_ov
         if strong is not None:
             out["config"]["strong_scaling"] = strong
         if notes:

@@ -79,7 +79,7 @@ PROTOTYPES = {
     "hfem_tri3_energy_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i32, _vp]),
     "hfem_tri3_energy_adam_step_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                                _vp, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i32, _vp]),
+                                                _vp, _f64, _f64, _f64, _f64, _f64, _vp, _i32, _i32, _vp, _i32, _vp]),
     "hfem_adam_prep": (C.c_int, [C.c_int, _vp, _f64, _f64, _vp, _vp]),
     "hfem_plan_loss_sum": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "hfem_iface_pack": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -92,7 +92,7 @@ PROTOTYPES = {
     "hfem_mg_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "hfem_adam_step_rows_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _vp, _vp]),
     "hfem_plan_set_span_stamps": (C.c_int, [_vp, _vp, _i64]),
-    "hfem_plan_iface_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "hfem_plan_iface_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _f64, _f64, _vp, _vp]),
     "hfem_adam_step_rows2_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _f64,
                                            _f64, _f64, _f64, _vp, _i64, _vp]),
     "hfem_quad4_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void iface_pack_sum_kernel(const double2 *__re
                                                              const int32_t *__restrict__ rows, int n_x, int n_u,
                                                              double2 *__restrict__ out, int64_t loss_slot,
                                                              const double *__restrict__ partials, int n_partials,
-                                                             int64_t *__restrict__ counter) {
+                                                             int64_t *__restrict__ counter, double beta1, double beta2,
+                                                             double *__restrict__ bc_next) {
     __shared__ double red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_x) out[i] = x_free[rows[i]];
@@ -57,16 +58,25 @@ __global__ __launch_bounds__(256) void iface_pack_sum_kernel(const double2 *__re
         const double tot = block_sum(v, red);
         if (threadIdx.x == 0) {
             out[loss_slot] = make_double2(tot, 0.0);
-            if (counter) counter[0] += 1;
+            if (counter) {
+                const int64_t c = counter[0] + 1;
+                counter[0] = c;
+                if (bc_next) {                              // bias corrections of step c + 1 (hfem_adam_prep's scalars)
+                    bc_next[0] = 1.0 - pow(beta1, (double)(c + 1));
+                    bc_next[1] = sqrt(1.0 - pow(beta2, (double)(c + 1)));
+                }
+            }
         }
     }
 }
 
 int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
-                          int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, hipStream_t s) {
+                          int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
+                          double beta2, double *bc_next, hipStream_t s) {
     const int n = n_x + n_u > 0 ? n_x + n_u : 1;
     hipLaunchKernelGGL(iface_pack_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double2 *)x_free,
-                       (const double2 *)u_free, rows, n_x, n_u, (double2 *)out, loss_slot, partials, n_partials, counter);
+                       (const double2 *)u_free, rows, n_x, n_u, (double2 *)out, loss_slot, partials, n_partials, counter,
+                       beta1, beta2, bc_next);
     return launch_status("hfem_plan_iface_pack");
 }
 

@@ -162,7 +162,8 @@ void free_tri3_det(hfem_plan *plan);
 int det_prepare(hfem_plan *plan, hipStream_t s);   // adjacency of the fixed-order kernels (TRI3 and QUAD4), built on first use
 // exchange.hip: interface pack + tile-energy sum + step-counter bump in one launch (hfem_plan_iface_pack)
 int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
-                          int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, hipStream_t s);
+                          int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
+                          double beta2, double *bc_next, hipStream_t s);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

@@ -1005,8 +1005,8 @@ extern "C" int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free,
                                           double beta1, double beta2, double eps, const double *bc_dev,
                                           double *loss_out, int32_t flags, void *stream) {
     return hfem_tri3_energy_adam_step_ex(plan, 0, x_free, x_fixed, u_free, u_fixed, mat, W, nullptr, T_edge, Tconst, x_out,
-                                         u_out, m_x, v_x, m_u, v_u, lr_x, lr_u, beta1, beta2, eps, bc_dev, loss_out, flags,
-                                         stream);
+                                         u_out, m_x, v_x, m_u, v_u, lr_x, lr_u, beta1, beta2, eps, bc_dev, 0, -1, loss_out,
+                                         flags, stream);
 }
 
 // General form: dtype 0 = fp64 rows, 1 = fp32 rows (parameters, fixed rows, moments and new rows all float: an fp32 model,
@@ -1018,7 +1018,8 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
                                              const double Bk[6], const double *T_edge, const double Tconst[4], void *x_out,
                                              void *u_out, void *m_x, void *v_x, void *m_u, void *v_u, double lr_x,
                                              double lr_u, double beta1, double beta2, double eps, const double *bc_dev,
-                                             double *loss_out, int32_t flags, void *stream) {
+                                             int32_t tile_begin, int32_t tile_end, double *loss_out, int32_t flags,
+                                             void *stream) {
     HFEM_ARG_CHECK(plan && mat && loss_out && x_free && u_free, "null pointer");
     HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64 rows, 1 = fp32 rows");
     HFEM_ARG_CHECK(x_out && u_out && m_x && v_x && m_u && v_u && bc_dev, "null optimiser buffer");
@@ -1030,21 +1031,28 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
     HFEM_ARG_CHECK(h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
                    "fused Adam step: needs tiles of <= 1024 nodes / 2048 element slots");
     HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_GX | HFEM_FLAG_NO_GU)), "fused Adam step updates both parameter tensors");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SAME_BANK)), "fused Adam step: reference convention, atomic accumulation, whole plan");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC)), "fused Adam step: reference convention, atomic accumulation");
     bool hasb = false;
     for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
     if (int rc = use_device(plan->device)) return rc;
     PlanLock lock(plan);
     hipStream_t s = (hipStream_t)stream;
-    const int n = (int)h.tiles.size(), nt = n;
+    // a tile RANGE updates exactly the rows its tiles own (element sharding: hidenn_fem_amd/sharded.py, fused steps); the rows
+    // of the other tiles are not touched in x_out / u_out -- the caller keeps both parameter buffers complete
+    const int nt = (int)h.tiles.size();
+    if (tile_end < 0) tile_end = nt;
+    HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
+    const int n = tile_end - tile_begin;
     const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0;
+    const bool same_bank = (flags & HFEM_FLAG_SAME_BANK) != 0;
     HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
+    HFEM_ARG_CHECK(!same_bank || ((flags & HFEM_FLAG_NO_LOSS_SUM) && !lag_consume), "HFEM_FLAG_SAME_BANK needs HFEM_FLAG_NO_LOSS_SUM and excludes HFEM_FLAG_SUM_PREVIOUS");
     HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
     HFEM_ARG_CHECK(!lag_consume || plan->prev_stream == stream,
                    "HFEM_FLAG_SUM_PREVIOUS: the previous unsummed launch went to another stream (one plan = one stream)");
     HFEM_ARG_CHECK(!lag_consume || !hasb, "HFEM_FLAG_SUM_PREVIOUS: zero body force only");
-    const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (plan->bank ^ 1) : plan->bank;
-    double *pbase = plan->d_partials + (size_t)wbank * nt;
+    const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (same_bank ? plan->bank : (plan->bank ^ 1)) : plan->bank;
+    double *pbase = plan->d_partials + (size_t)wbank * nt + tile_begin;
     LagSum lag;
     if (lag_consume) {
         lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
@@ -1057,7 +1065,7 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
         af.mx = m_x; af.vx = v_x; af.mu = m_u; af.vu = v_u;
         af.bc = bc_dev; af.lr_x = lr_x; af.lr_u = lr_u; af.b1 = beta1; af.b2 = beta2; af.eps = eps;
         Tri3Launch A;
-        A.pd = plan_dev(plan); A.tile_begin = 0;
+        A.pd = plan_dev(plan); A.tile_begin = tile_begin;
         A.x_free = x_free; A.x_fixed = x_fixed; A.u_free = u_free; A.u_fixed = u_fixed;
         A.k = make_consts(mat, W, hasb ? Bk : nullptr); A.T_edge = (const double4 *)T_edge;
         A.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
@@ -1067,7 +1075,7 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
         const int grid = n + (lag_consume ? 1 : 0);
         if (h.paired) {
             PairLaunch P;
-            P.grid = grid; P.tile_begin = 0;
+            P.grid = grid; P.tile_begin = tile_begin;
             P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
             P.k = A.k; P.T_edge = A.T_edge; P.tc = A.tc; P.partials = pbase; P.skip_edges = A.skip_edges; P.s = s;
             HFEM_ARG_CHECK(launch_tri3_pair(plan, P, dtype == 0 ? 3 : 4, hasb, false, lag, af) == 1,
@@ -1089,7 +1097,14 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
         if (int rc = launch_status("hfem_tri3_energy_adam_step")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) {
-        plan->bank = wbank; plan->prev_begin = 0; plan->prev_n = n; plan->prev_stream = stream;
+        if (same_bank && plan->prev_n > 0 && n > 0 &&
+            (tile_end == plan->prev_begin || tile_begin == plan->prev_begin + plan->prev_n)) {
+            plan->prev_begin = std::min(plan->prev_begin, (int)tile_begin);      // adjacent ranges of one evaluation: their union
+            plan->prev_n += n;
+        } else if (!same_bank || n > 0) {
+            plan->prev_begin = tile_begin; plan->prev_n = n;
+        }
+        plan->bank = wbank; plan->prev_stream = stream;
         return 0;
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, pbase, n, loss_out);
@@ -1133,10 +1148,13 @@ extern "C" int hfem_plan_set_span_stamps(hfem_plan *plan, uint64_t *dev_buf, int
 // Owner-sharded step, one launch: pack this rank's interface rows into its all_gather payload (hfem_iface_pack), put
 // the sum of the tile energies that the HFEM_FLAG_NO_LOSS_SUM launch(es) over [tile_begin, tile_end) left in the plan into
 // out[loss_slot] (same order and bits as hfem_plan_loss_sum), and -- when `counter` is given -- bump that device counter
-// (the optimiser's step count: hfem_adam_step_rows2_dev reads it BEFORE this launch with step_offset = 1).
+// (the optimiser's step count: hfem_adam_step_rows2_dev reads it BEFORE this launch with step_offset = 1) and, when bc_next is
+// given too, write the bias-correction scalars {1 - beta1^(c + 1), sqrt(1 - beta2^(c + 1))} of the NEXT step (c = the bumped
+// count) there -- what the fused energy + Adam launch of that step reads (hfem_tri3_energy_adam_step_ex), so no hfem_adam_prep.
 extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
                                     const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
-                                    int64_t loss_slot, int64_t *counter, void *stream) {
+                                    int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                                    void *stream) {
     HFEM_ARG_CHECK(plan && out, "null pointer");
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && loss_slot >= n_x + n_u, "bad sizes");
@@ -1148,7 +1166,7 @@ extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t
     PlanLock lock(plan);
     return launch_iface_pack_sum(x_free, u_free, rows, n_x, n_u, out, loss_slot,
                                  plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, counter,
-                                 (hipStream_t)stream);
+                                 beta1, beta2, bc_next, (hipStream_t)stream);
 }
 
 // Options.  Product: tiled_block (256 / 512 / 1024 threads per tile), store_policy (0 plain, 16 sc1 write-through),

@@ -391,7 +391,7 @@ class EnergyAdamStep:
             self.plan.handle, self._dtype, ptr(self._x[i]), ptr(self._xfix) if self._xfix.numel() else None, ptr(self._u[i]),
             ptr(self._ufix) if self._ufix.numel() else None, self._mat, float(self.loss_fn._W), self._Bk, None, self._Tc,
             ptr(self._x[o]), ptr(self._u[o]), ptr(st["exp_avg_x"]), ptr(st["exp_avg_sq_x"]), ptr(st["exp_avg_u"]),
-            ptr(st["exp_avg_sq_u"]), self.lr_x, self.lr_u, self.betas[0], self.betas[1], self.eps, ptr(self._bc),
+            ptr(st["exp_avg_sq_u"]), self.lr_x, self.lr_u, self.betas[0], self.betas[1], self.eps, ptr(self._bc), 0, -1,
             ptr(self.loss), self._flags | _extra_flags, sp), "hfem_tri3_energy_adam_step")
         self.model.node_coords_free.data = self._x[o]
         self.model.u_free.data = self._u[o]

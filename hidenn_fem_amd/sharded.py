@@ -119,16 +119,9 @@ class ShardedTri3Energy:
         return buf[nx + nu:nx + nu + 1], buf[:nx].view(-1, 2), buf[nx:nx + nu].view(-1, 2)
 
     def _evaluate_hip(self, lo, hi, loss_v, gx_v, gu_v, flags=0):
-        m, lf = self.model, self.loss_fn
+        m = self.model
         dev = m.node_coords_free.device
-        c = getattr(self, "_consts", None)
-        if c is None:                                   # per-step host work is pointer reads only
-            if m.node_coords_free.dtype != F64 or m.u_free.dtype != F64:
-                raise RuntimeError("sharded evaluation needs an fp64 model (model.double())")
-            _, Tconst = lf._traction(m, None)
-            dv = lambda a: (C.c_double * len(a))(*a)
-            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst), _lib.lib().hfem_tri3_energy_plan)
-        mat, W, Bk, Tc, fn = c
+        mat, W, Bk, Tc, fn = self._hip_consts()
         # fixed rows are looked up on every call (the model caches them and tracks u_fixed._version / device): an
         # in-place edit of u_fixed or model.to(device) is never served from a stale pointer
         xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()
@@ -136,6 +129,18 @@ class ShardedTri3Energy:
         rc = fn(self.plan.handle, m.node_coords_free.data_ptr(), pxfix, m.u_free.data_ptr(), pufix, mat, W, Bk, None,
                 Tc, int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), int(flags), _lib.stream_ptr(dev))
         _lib.check(rc, "hfem_tri3_energy_plan")
+
+    def _hip_consts(self):
+        """Host-side constants of the energy launches (built once: per-step host work is pointer reads only)."""
+        c = getattr(self, "_consts", None)
+        if c is None:
+            m, lf = self.model, self.loss_fn
+            if m.node_coords_free.dtype != F64 or m.u_free.dtype != F64:
+                raise RuntimeError("sharded evaluation needs an fp64 model (model.double())")
+            _, Tconst = lf._traction(m, None)
+            dv = lambda a: (C.c_double * len(a))(*a)
+            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst), _lib.lib().hfem_tri3_energy_plan)
+        return c
 
     def evaluate_local(self):
         """Kernel over this rank's tiles only (no communication): fills the send buffer."""
@@ -323,7 +328,7 @@ class ShardedTri3Energy:
         return self.loss_global, c["out"][0], c["out"][1]
 
     # ------------------------------------------------------------------ a whole owner-sharded training iteration
-    def init_owner_adam(self, lr_x: float, lr_u: float, betas=(0.9, 0.999), eps: float = 1e-8, adam=None):
+    def init_owner_adam(self, lr_x: float, lr_u: float, betas=(0.9, 0.999), eps: float = 1e-8, adam=None, fused: bool = False):
         """State of ``owner_train_step`` / ``owner_train_step_overlapped``: Adam moments of the rows this rank OWNS
         (full-size arrays, only owned rows are ever touched), the device step counter (= completed steps) and the
         owned-row lists.  Call once, before any graph capture.  ``adam`` is the test seam of the CPU multi-process
@@ -337,6 +342,17 @@ class ShardedTri3Energy:
                           step=torch.zeros(1, dtype=torch.int64, device=dev), lr=(float(lr_x), float(lr_u)),
                           betas=(float(betas[0]), float(betas[1])), eps=float(eps))
         self._adam_step = adam or self._adam_hip
+        # ``fused=True``: state of the ``*_fused`` steps -- Adam's update applied by the energy kernel's own write-out
+        # (hfem_tri3_energy_adam_step_ex on tile ranges): a second, complete copy of each parameter tensor (the launch reads one
+        # and writes the rows its tiles own into the other; ``param.data`` alternates between the two) and the device scalars
+        # of the next step's bias corrections, which every pack launch refreshes
+        self._fused = None
+        if fused:
+            import math
+            b1, b2 = self._adam["betas"]
+            self._fused = dict(x=[m.node_coords_free.data, m.node_coords_free.data.clone()],
+                               u=[m.u_free.data, m.u_free.data.clone()], k=0,
+                               bc=torch.tensor([1.0 - b1, math.sqrt(1.0 - b2)], dtype=F64, device=dev))
         self._e_parts = torch.zeros(2, dtype=F64, device=dev)      # seam evaluators: energies of the two tile sub-ranges
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = None
@@ -370,10 +386,12 @@ class ShardedTri3Energy:
         """Interface rows + this rank's energy into the payload, step counter += 1 (HIP: one launch)."""
         if self._hip:
             m, dev = self.model, self.send.device
+            fz = getattr(self, "_fused", None)
             _lib.check(_lib.lib().hfem_plan_iface_pack(
                 self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
                 self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
-                self._adam["step"].data_ptr() if count_step else None, _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
+                self._adam["step"].data_ptr() if count_step else None, self._adam["betas"][0], self._adam["betas"][1],
+                fz["bc"].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
         else:
             self._pack()
             with torch.no_grad():
@@ -411,6 +429,60 @@ class ShardedTri3Energy:
         self._join_exchange()                                      # foreign interface rows of the previous step are in
         self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)   # boundary tiles, same evaluation
         self._adam_step()
+        self._pack_loss()
+        self._fork_exchange()
+        return self.loss_global
+
+    # ---- fused steps: the energy launch applies Adam's update to the rows its tiles own (no gradient traffic, no Adam launch)
+    def _fused_range(self, lo, hi, cont):
+        """Energy over tiles [lo, hi) with the fused Adam write-out: reads the current parameter buffers, writes the new rows of
+        the nodes those tiles own into the other buffers.  HIP only; fp64 models; default forces."""
+        if hi <= lo:
+            return
+        fz, a, m = self._fused, self._adam, self.model
+        dev = self.send.device
+        mat, W, Bk, Tc, _ = self._hip_consts()
+        i, o = fz["k"] & 1, (fz["k"] + 1) & 1
+        xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()
+        _lib.check(_lib.lib().hfem_tri3_energy_adam_step_ex(
+            self.plan.handle, 0, fz["x"][i].data_ptr(), xfix.data_ptr() if xfix.numel() else None, fz["u"][i].data_ptr(),
+            ufix.data_ptr() if ufix.numel() else None, mat, W, None, None, Tc, fz["x"][o].data_ptr(), fz["u"][o].data_ptr(),
+            a["mx"].data_ptr(), a["vx"].data_ptr(), a["mu"].data_ptr(), a["vu"].data_ptr(), a["lr"][0], a["lr"][1],
+            a["betas"][0], a["betas"][1], a["eps"], fz["bc"].data_ptr(), int(lo), int(hi), self.loss_global.data_ptr(),
+            8 | (256 if cont else 0) | (0 if m.N_edges else 4), _lib.stream_ptr(dev)), "hfem_tri3_energy_adam_step_ex")
+
+    def _fused_swap(self):
+        """The new rows become the model's parameters (``param.data`` alternates between the two buffers: capture an EVEN
+        number of fused steps per hipGraph)."""
+        fz, m = self._fused, self.model
+        fz["k"] += 1
+        i = fz["k"] & 1
+        m.node_coords_free.data = fz["x"][i]
+        m.u_free.data = fz["u"][i]
+
+    def owner_train_step_fused(self):
+        """``owner_train_step`` with Adam's update applied by the energy kernel itself: THREE launches + the collective
+        (energy+Adam -> pack (+ energy sum, step count, next bias corrections) -> all_gather -> unpack), the gradient never
+        goes to memory.  Needs ``init_owner_adam(..., fused=True)``; same numbers as ``owner_train_step``."""
+        if self._fused is None or not self._hip:
+            raise RuntimeError("owner_train_step_fused needs init_owner_adam(..., fused=True) and the HIP evaluator")
+        self._fused_range(self.lo, self.hi, False)
+        self._fused_swap()
+        self._pack_loss()
+        self._gather_payloads()
+        self._unpack()
+        return self.loss_global
+
+    def owner_train_step_fused_overlapped(self):
+        """The fused iteration with the exchange of step k under the interior tiles of step k + 1 (the launch order of
+        ``owner_train_step_overlapped``; Adam is inside the two energy launches, which read one parameter buffer and write
+        the other, so the boundary tiles still see the step's input values of the rows interior tiles own)."""
+        if self._fused is None or not self._hip:
+            raise RuntimeError("owner_train_step_fused_overlapped needs init_owner_adam(..., fused=True) and the HIP evaluator")
+        self._fused_range(self.mid, self.hi, False)
+        self._join_exchange()
+        self._fused_range(self.lo, self.mid, self.hi > self.mid)
+        self._fused_swap()
         self._pack_loss()
         self._fork_exchange()
         return self.loss_global

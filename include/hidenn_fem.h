@@ -193,13 +193,16 @@ int hfem_tri3_energy_adam_step(hfem_plan *plan, const double *x_free, const doub
 /* General form.  dtype: 0 = fp64 rows, 1 = fp32 rows -- x / u / fixed rows, moments and new rows all float (an fp32 model, the
  * reference's default dtype src/loss.py:16, src/models.py:274, trains in one launch per iteration with no widening copy;
  * element arithmetic and loss_out stay fp64, the update is torch.optim.Adam's fp32 arithmetic on the once-rounded
- * gradient).  Bk [3][2]: body-force table as in hfem_tri3_energy_plan (NULL / zeros: none; not with SUM_PREVIOUS).      */
+ * gradient).  Bk [3][2]: body-force table as in hfem_tri3_energy_plan (NULL / zeros: none; not with SUM_PREVIOUS).
+ * [tile_begin, tile_end) (-1 = all): a tile range updates exactly the rows its tiles own and leaves the other rows of
+ * x_out / u_out alone (element sharding: the caller keeps both parameter buffers complete); flags accept
+ * HFEM_FLAG_SAME_BANK for the second range of one evaluation.                                                      */
 int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, const void *x_free, const void *x_fixed,
                                   const void *u_free, const void *u_fixed, const double mat[4], double W,
                                   const double Bk[6], const double *T_edge, const double Tconst[4], void *x_out,
                                   void *u_out, void *m_x, void *v_x, void *m_u, void *v_u, double lr_x, double lr_u,
-                                  double beta1, double beta2, double eps, const double *bc_dev, double *loss_out,
-                                  int32_t flags, void *stream);
+                                  double beta1, double beta2, double eps, const double *bc_dev, int32_t tile_begin,
+                                  int32_t tile_end, double *loss_out, int32_t flags, void *stream);
 int hfem_adam_prep(int device, int64_t *step_dev, double beta1, double beta2, double *bc_dev, void *stream);
 /* loss_out[0] = sum, in tile order, of the per-tile partial energies that a launch with
  * HFEM_FLAG_NO_LOSS_SUM over the same tile range left in the plan (TRI3 and QUAD4 plans alike).   */
@@ -394,10 +397,12 @@ int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const 
 /* hfem_iface_pack + the rank's energy + the optimiser's step counter in ONE launch (the owner-sharded training step is a
  * chain of small dependent launches, each worth a kernel boundary): out as hfem_iface_pack; out[loss_slot] = {sum, in tile
  * order, of the tile energies that the HFEM_FLAG_NO_LOSS_SUM launch(es) over [tile_begin, tile_end) left in the plan, 0};
- * counter (may be NULL) += 1.  loss_slot >= n_x + n_u, in double2 units.                                          */
+ * counter (may be NULL) += 1; bc_next (may be NULL; needs counter) = {1 - beta1^(c + 1), sqrt(1 - beta2^(c + 1))} with c the
+ * bumped count: the bias corrections of the NEXT step, for its fused energy + Adam launch (no hfem_adam_prep launch).
+ * loss_slot >= n_x + n_u, in double2 units.                                                                       */
 int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
                          const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
-                         int64_t loss_slot, int64_t *counter, void *stream);
+                         int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
 
 /* In-library collectives: one RCCL communicator per rank (one process per GPU).  Rank 0 calls
  * hfem_mg_unique_id and broadcasts the 128 bytes by any side channel (torch.distributed, a file, MPI); every rank

@@ -54,13 +54,14 @@ for dt in (f64, torch.float32):
 #      artificially 5 % / 95 %: 5 launches, all_gather + unpack on the side stream)
 from hidenn_fem_amd.sharded import LibraryComm, ShardedTri3Energy
 comm = LibraryComm(d)
-for name, split, same_stream in (("owner_train_step", False, False), ("owner_train_step_overlapped", True, False),
-                                 ("owner_train_step_overlapped", True, True), ("owner_step_overlapped", True, False),
-                                 ("owner_step_overlapped", True, True)):
+for name, split, same_stream in (("owner_train_step", False, False), ("owner_train_step_fused", False, False),
+                                 ("owner_train_step_overlapped", True, False), ("owner_train_step_overlapped", True, True),
+                                 ("owner_train_step_fused_overlapped", True, False), ("owner_train_step_fused_overlapped", True, True),
+                                 ("owner_step_overlapped", True, False), ("owner_step_overlapped", True, True)):
     m = model(f64)
     sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=f64), comm=comm)
     sh.setup_interfaces()
-    sh.init_owner_adam(1e-9, 1e-12)
+    sh.init_owner_adam(1e-9, 1e-12, fused="fused" in name)
     if split:
         sh.mid = sh.plan.n_tiles // 20
     if same_stream:                      # the same launches in the same order, exchange on the MAIN stream: what the fork / join costs

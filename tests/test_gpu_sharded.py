@@ -411,6 +411,67 @@ def test_overlapped_training_step_hip_eager_and_captured():
     sh3 = sharded(m3, False)
     plain = [sh3.owner_train_step().item() for _ in range(n_iter)]
     np.testing.assert_allclose(plain, ref_losses, rtol=1e-12)
+    # fused steps: Adam applied by the energy kernel's write-out on tile ranges (ping-pong parameter buffers, bias corrections
+    # refreshed by the pack launch) -- plain and overlapped, eager and 4 iterations per hipGraph
+    def sharded_fused(m, split):
+        sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm)
+        sh.setup_interfaces()
+        sh.init_owner_adam(lr_x, lr_u, fused=True)
+        if split:
+            sh.mid = sh.plan.n_tiles // 3
+        return sh
+    for name, split in (("owner_train_step_fused", False), ("owner_train_step_fused_overlapped", True)):
+        m5 = model()
+        sh5 = sharded_fused(m5, split)
+        step = getattr(sh5, name)
+        got = []
+        for k in range(n_iter - 1):                            # 12: an even number, as the captured variant needs
+            step()
+            if not split:
+                got.append(sh5.loss_global.item())
+            elif k:
+                got.append(sh5.loss_global.item())
+        if split:
+            got.append(sh5.finish_overlapped().item())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(got, ref_losses[:n_iter - 1], rtol=1e-12)
+        assert int(sh5._adam["step"].item()) == n_iter - 1
+        # one more eager step brings it level with the reference loop's parameters
+        step()
+        if split:
+            sh5.finish_overlapped()
+        for a, b in zip(m5.parameters(), m0.parameters()):
+            assert (a - b).abs().max().item() <= 1e-12 * b.abs().max().item()
+        # captured: 4 iterations per graph
+        m6 = model()
+        sh6 = sharded_fused(m6, split)
+        step6 = getattr(sh6, name)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step6(); step6()
+            if split:
+                sh6.finish_overlapped()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g6 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g6):
+            for _ in range(4):
+                step6()
+            if split:
+                sh6.finish_overlapped()
+        g6.replay(); g6.replay()
+        torch.cuda.synchronize()
+        assert int(sh6._adam["step"].item()) == 10
+        assert abs(sh6.loss_global.item() - ref_losses[9]) <= 1e-12 * abs(ref_losses[9])
+        # the model's parameters are the buffers the last step wrote
+        m7 = model()
+        o7 = FusedAdam([dict(params=[m7.node_coords_free], lr=lr_x), dict(params=[m7.u_free], lr=lr_u)])
+        for _ in range(10):
+            lf.value_and_grad_(m7)
+            o7.step()
+        for a, b in zip(m6.parameters(), m7.parameters()):
+            assert (a - b).abs().max().item() <= 1e-12 * b.abs().max().item()
     # evaluation-only counterpart (what bench.py times as eval_exchange_overlap): same energy and gradients as owner_step
     m4 = model()
     sh4 = sharded(m4, True)

@@ -374,6 +374,32 @@ def test_examples_run_against_the_drop_in_api(g_lbfgs):
     assert abs(l3 - l3r) <= 1e-4 * abs(l3r) + 1e-7       # fused kernel == the reference's autograd form (fp32 run)
     _, l4 = e4.run(nx=40, ny=20, steps=2, log_every=100)
     assert l4 < 0.0
+    # example 4 in fp64 against the reference's op chain on the CPU, driven by the same torch.optim.LBFGS (2 outer steps = 40
+    # closure calls): same mesh, same initial u_free (same seed, same RNG call) -> the same final energy
+    from src.mesh import generate_mesh
+    from oracle import ref_chain as R
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D as P2D
+    torch.manual_seed(17)
+    m4, l4_64 = e4.run(nx=40, ny=20, steps=2, dtype=F64, log_every=100)
+    nodes, conn4, geom4, bc4, mn4, edges4 = generate_mesh(2.0, 1.0, [(0.5, 0.7, 0.12), (1.0, 0.3, 0.15), (1.4, 0.6, 0.1)],
+                                                          {"up": 0, "down": 0, "right": 2, "left": 1}, 40, 20)
+    torch.manual_seed(17)
+    cpu = P2D(nodes.to(F64), conn4, boundary_mask=geom4, dirichlet_mask=bc4, u_fixed=0.0, neumann_edges=edges4)   # construction only
+    mesh4 = dict(n_nodes=nodes.shape[0], conn=conn4, free_mask=~geom4, boundary_mask=geom4, coords_fixed=nodes.to(F64)[geom4],
+                 u_free_mask=~bc4, dirichlet_mask=bc4, u_fixed=torch.tensor(0.0, dtype=F64), edges=edges4)
+    xf = cpu.node_coords_free.detach().clone().requires_grad_(True)
+    uf = cpu.u_free.detach().clone().requires_grad_(True)
+    opt_ref = torch.optim.LBFGS([xf, uf])
+
+    def closure_ref():
+        opt_ref.zero_grad()
+        v = R.total_energy(xf, uf, mesh4)
+        v.backward()
+        return v
+    for _ in range(2):
+        l4_ref = opt_ref.step(closure_ref).item()
+    assert abs(l4_64 - l4_ref) <= 1e-8 * abs(l4_ref), (l4_64, l4_ref)
+    assert (m4.to_caller_order(m4.u_free.detach(), "u").cpu() - uf.detach()).abs().max().item() <= 1e-6 * uf.detach().abs().max().item()
     # LBFGS on the reference's own mini-mesh, fp64: same closure-loss sequence as the reference
     from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
     from hidenn_fem_amd.loss import EnergyLoss2D

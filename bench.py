@@ -390,7 +390,7 @@ def main():
         r_, n_ = (int(v) for v in a.emulate_shard.split("/"))
         model = build_model(t1m_mesh())
         lf = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
-        print(json.dumps(dict(emulate_shard=a.emulate_shard, **shard_kernel_leg(model, lf, n_, [r_], max(a.steps, 50)))), flush=True)
+        print(json.dumps(dict(emulate_shard=a.emulate_shard, **shard_kernel_leg(model, lf, n_, [r_], max(a.steps, 200)))), flush=True)
         return None
 
     # ------------------------------------------------------------------------------------------------ main workload
@@ -521,7 +521,7 @@ def main():
         sh_s.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)
         ne_s, nn_s = mesh6_s[1].shape[0], mesh6_s[0].shape[0]
         ko = KernelOnly(m_s, lf_s, sh_s.plan, sh_s.lo, sh_s.hi)
-        us, _ = time_launches(lambda i: ko(), max(a.steps, 50))
+        us, _ = time_launches(lambda i: ko(), max(a.steps, 200))
         ne_r, nn_r, ab = range_work(sh_s.plan, sh_s.lo, sh_s.hi)
         t = torch.tensor([us, float(ab) / (us * 1e-6) / 1e9], dtype=f64, device=dev)
         tmax, tsum = t.clone(), t.clone()
@@ -556,7 +556,7 @@ def main():
                                      unstructured_tri_mesh(2_050_000, seed=2, dtype=f64)))
 
     # ------------------------------------------------------------------------------------------------ roofline legs
-    kreps = max(a.steps, 50)
+    kreps = max(a.steps, 200)      # kernel-only legs: >= 200 launches per graph whatever --steps is (amortises the ~20 us graph launch)
     ko_main = KernelOnly(model, loss_fn, plan, lo, hi)
     k_us, samples = time_launches(lambda i: ko_main(), kreps) if only in ("", "replayed") and not a.only_extra else (float("nan"), [])
     # The same kernel in the cache regimes a training loop sees:

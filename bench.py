@@ -18,6 +18,9 @@ kernel's stream, the K steps in one hipGraph).  Beside it, in `config`:
   eval_exchange_overlap             the headline step with the exchange of step k under the interior tiles of step k + 1
   train_step / train_step_overlap   whole Adam iterations (exchange on the critical path / hidden under the interior tiles)
   train_step_fused[_overlap]        the same with Adam applied by the energy kernel's own write-out (three launches per step)
+  peer_exchange                     the evaluation / training steps with the interface rows STORED by the pack launch into every
+                                    rank's receive window (csrc/peer.hip: IPC-mapped memory, xGMI stores + flags; no collective,
+                                    no second stream), verified in the run against the collective path; headline if faster
   alt_exchange                      the north-star's literal wording: a dense sum all-reduce of [gX|gU|loss]
   strong_scaling                    BASELINE configs[3] and [4] AS STATED: 10^6 TRI3 FIXED sharded over the N ranks (and, at
                                     N = 8, the 4.1 M-element Delaunay mesh), kernel-only per rank and end to end
@@ -68,6 +71,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra / train_step_1gpu / strong_scaling_emulated")
     ap.add_argument("--no-regimes", action="store_true", help="skip the cache-regime legs (roofline = the replayed leg)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip config.strong_scaling")
+    ap.add_argument("--no-peer", action="store_true", help="skip the peer-window exchange legs (config.peer_exchange / sharded_step_1gpu)")
     ap.add_argument("--only-regime", default="", help="profiler helper: run ONLY this roofline leg (replayed | "
                     "rewritten_inputs | rotating_sets) and exit")
     ap.add_argument("--only-extra", default="", help="profiler helper: run ONLY this config.extra workload (Q1M | T2M | cfg5 | "
@@ -512,6 +516,61 @@ def main():
         else:
             note("fused training legs skipped: --steps must be even (ping-pong parameter buffers inside one hipGraph)")
 
+    # ---- N > 1: the same steps with the interface rows written straight into the peers' receive windows (csrc/peer.hip): no
+    #      collective, no second stream.  Verified in this run against the collective path before anything is timed; a failure
+    #      (IPC mapping, a flag that never arrives) is reported in notes and the legs are dropped -- never a silent fallback.
+    peer_legs, peer_state = None, None
+
+    def enable_peer(sh_, tag):
+        """Switch sh_ to peer-window exchange after checking it against the collective path on this very topology."""
+        l_ref = sh_.owner_step()[0].item()
+        sh_.enable_peer_exchange(timeout_s=5.0)
+        l_got = sh_.owner_step()[0].item()
+        torch.cuda.synchronize()
+        st = sh_.peer.status()
+        ok = torch.tensor([1.0 if (st[0] == 0 and l_got == l_ref) else 0.0], dtype=f64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() != 1.0:
+            sh_.peer.close()
+            sh_.peer = None
+            raise RuntimeError(f"{tag}: peer-window exchange disagrees with the collective path on some rank "
+                               f"(this rank: status {st}, energy {l_got!r} vs {l_ref!r})")
+
+    if world > 1 and not a.no_peer:
+        try:
+            enable_peer(sh, "T1M x N")
+            peer_state = f"verified in this run against the collective path on {world} ranks (same global energy, to the bit)"
+            peer_legs = dict(
+                eval_exchange=leg(sh.owner_step, "evaluation + interface exchange: energy -> put (pack + energy sum + stores into every "
+                                  "rank's window + flags) -> get (wait for the flags, unpack); three launches, one stream", ne),
+                eval_exchange_overlap=leg(sh.owner_step_overlapped, "the same with the get of step k after the interior tiles of step k+1",
+                                          ne, end_=sh.finish_overlapped),
+                train_step=leg(sh.owner_train_step, "Adam iteration: energy -> Adam on owned rows -> put -> get", ne),
+                train_step_overlap=leg(sh.owner_train_step_overlapped, "Adam iteration, the get of step k after the interior tiles of "
+                                       "step k+1", ne, end_=sh.finish_overlapped))
+            if a.steps % 2 == 0:
+                peer_legs["train_step_fused"] = leg(sh.owner_train_step_fused, "Adam inside the energy launch -> put -> get", ne)
+                peer_legs["train_step_fused_overlap"] = leg(sh.owner_train_step_fused_overlapped, "Adam inside the two energy launches, "
+                                                            "the get after the next step's interior tiles", ne, end_=sh.finish_overlapped)
+            st = torch.tensor([float(sh.peer.status()[0])], dtype=f64, device=dev)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            if st.item() != 0.0:
+                raise RuntimeError("a rank timed out waiting for a peer's flags during the timed legs")
+            best = max(("eval_exchange", "eval_exchange_overlap"), key=lambda k: peer_legs[k]["value"])
+            if peer_legs[best]["value"] > value:
+                value, ms_per_step, launch = peer_legs[best]["value"], peer_legs[best]["ms_per_step"], peer_legs[best]["launch"]
+                regions = [r * a.steps * 1e-3 for r in peer_legs[best]["ms_per_step_replays"]]
+                exchange_mode = ("peer windows" + (", the get under the next step's interior tiles" if best.endswith("overlap") else "")
+                                 + ": interface rows stored by the pack launch into every rank's window over xGMI (faster than the "
+                                 "all_gather steps on this topology; config.peer_exchange)")
+        except Exception as e:  # noqa: BLE001
+            peer_legs = None
+            peer_state = f"unavailable: {type(e).__name__}: {str(e)[:200]}"
+            note("peer-window exchange " + peer_state)
+            if sh.peer is not None:
+                sh.peer.close()
+                sh.peer = None
+
     # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
     def strong_leg(name, mesh6_s):
         m_s = build_model(mesh6_s)
@@ -545,6 +604,26 @@ def main():
             res["train_step_fused"] = leg(sh_s.owner_train_step_fused, "Adam inside the energy launch, exchange on the critical path", ne_s)
             res["train_step_fused_overlap"] = leg(sh_s.owner_train_step_fused_overlapped, "Adam inside the energy launches, exchange "
                                                   "under the next step's interior tiles", ne_s, end_=sh_s.finish_overlapped)
+        if peer_legs is not None:          # the peer-window steps on the fixed mesh (verified again: another plan, other tables)
+            try:
+                enable_peer(sh_s, name[:12])
+                res["peer_exchange"] = dict(
+                    eval_exchange=leg(sh_s.owner_step, "energy -> put -> get", ne_s),
+                    eval_exchange_overlap=leg(sh_s.owner_step_overlapped, "the get after the next step's interior tiles", ne_s,
+                                              end_=sh_s.finish_overlapped),
+                    train_step=leg(sh_s.owner_train_step, "energy -> Adam -> put -> get", ne_s),
+                    train_step_overlap=leg(sh_s.owner_train_step_overlapped, "the get after the next step's interior tiles", ne_s,
+                                           end_=sh_s.finish_overlapped))
+                if a.steps % 2 == 0:
+                    res["peer_exchange"]["train_step_fused"] = leg(sh_s.owner_train_step_fused, "energy+Adam -> put -> get", ne_s)
+                    res["peer_exchange"]["train_step_fused_overlap"] = leg(sh_s.owner_train_step_fused_overlapped,
+                                                                           "the get after the next step's interior tiles", ne_s,
+                                                                           end_=sh_s.finish_overlapped)
+                res["peer_exchange"]["status"] = sh_s.peer.status()[0]
+            except Exception as e:  # noqa: BLE001
+                note(f"peer-window exchange on {name[:12]}: {type(e).__name__}: {str(e)[:160]}")
+            if sh_s.peer is not None:
+                sh_s.peer.close()
         del sh_s, m_s, ko
         return res
 
@@ -845,6 +924,42 @@ def main():
         except Exception as e:  # noqa: BLE001
             note(f"train_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
 
+    # ---- N = 1: what the owner-sharded step machinery costs on ONE rank (no peer to talk to: every microsecond above the
+    #      plain iteration is overhead of the exchange path) -- all_gather stand-in on one stream, the side-stream overlap,
+    #      and the peer-window put / get; plain and fused (Adam inside the energy launch); K iterations per hipGraph.
+    shard1 = None
+    if world == 1 and not a.no_extra and not a.no_peer and not only and not a.only_extra:
+        try:
+            m_ = build_model(mesh6)
+            lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+            sh_ = ShardedTri3Energy(m_, lf_)
+            sh_.setup_interfaces()
+            sh_.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)
+            n_t = sh_.hi - sh_.lo
+            sh_.mid = sh_.lo + max(1, n_t // 20)            # 5 % of the tiles play the boundary part, as on a real shard
+            K1 = max(2, (max(a.steps, 100) // 2) * 2)
+
+            def us(body, end_=None):
+                el, _, ln = timed_steps(body, K1, None, end_)
+                return round(el / K1 * 1e6, 3)
+            shard1 = dict(workload=f"T1M on one rank, {K1} iterations per hipGraph, boundary part = {sh_.mid - sh_.lo} of {n_t} tiles",
+                          unit="us per iteration")
+            shard1["collective_path"] = dict(train_step=us(sh_.owner_train_step),
+                                             train_step_overlap_side_stream=us(sh_.owner_train_step_overlapped, sh_.finish_overlapped),
+                                             train_step_fused=us(sh_.owner_train_step_fused),
+                                             train_step_fused_overlap_side_stream=us(sh_.owner_train_step_fused_overlapped,
+                                                                                     sh_.finish_overlapped))
+            sh_.enable_peer_exchange()
+            shard1["peer_windows"] = dict(train_step=us(sh_.owner_train_step),
+                                          train_step_overlap=us(sh_.owner_train_step_overlapped, sh_.finish_overlapped),
+                                          train_step_fused=us(sh_.owner_train_step_fused),
+                                          train_step_fused_overlap=us(sh_.owner_train_step_fused_overlapped, sh_.finish_overlapped))
+            shard1["peer_windows"]["status"] = sh_.peer.status()[0]
+            sh_.peer.close()
+            del sh_, m_
+        except Exception as e:  # noqa: BLE001
+            note(f"sharded_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
+
     out = None
     if rank == 0:
         cpu = None
@@ -905,6 +1020,10 @@ def main():
             out["config"]["train_step_fused_overlap"] = train_fused_ov
         if strong is not None:
             out["config"]["strong_scaling"] = strong
+        if peer_state is not None:
+            out["config"]["peer_exchange"] = dict(state=peer_state, **(peer_legs or {}))
+        if shard1 is not None:
+            out["config"]["sharded_step_1gpu"] = shard1
         if notes:
             out["config"]["notes"] = notes
         if cpu is not None:

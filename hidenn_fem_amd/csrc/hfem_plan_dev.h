@@ -164,6 +164,29 @@ int det_prepare(hfem_plan *plan, hipStream_t s);   // adjacency of the fixed-ord
 int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
                           int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
                           double beta2, double *bc_next, hipStream_t s);
+// peer.hip: the interface payload written straight into every rank's receive window (no collective); layout in peer.hip
+constexpr int kMaxPeers = 16;
+constexpr size_t kPeerFlags = 0, kPeerData = 256;
+struct PeerView {                    // kernel argument: every rank's window as mapped into THIS process
+    char *win[kMaxPeers];
+    char *ctl;                       // this rank's private control block (seq, ticket, status)
+    int rank, world;
+};
+}  // namespace hfem
+struct hfem_peer {
+    int device = -1;
+    int64_t stride = 0;              // double2 units per rank and slot: interface rows + the loss entry
+    size_t bytes = 0;
+    char *local = nullptr;           // this rank's window (hipExtMallocWithFlags, uncached)
+    char *ctl = nullptr;             // seq / ticket / status (hipMalloc)
+    std::vector<void *> opened;      // hipIpcOpenMemHandle results (the peers' windows)
+    bool connected = false;
+    hfem::PeerView view{};
+};
+namespace hfem {
+int launch_iface_put(const hfem_peer *peer, const double *x_free, const double *u_free, const int32_t *rows, int n_x,
+                     int n_u, int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
+                     double beta2, double *bc_next, hipStream_t s);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

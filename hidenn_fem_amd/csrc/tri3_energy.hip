@@ -1169,6 +1169,28 @@ extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t
                                  beta1, beta2, bc_next, (hipStream_t)stream);
 }
 
+// hfem_plan_iface_pack whose payload goes straight into every rank's receive window (csrc/peer.hip): pack + energy sum +
+// step count + the stores over xGMI + the arrival flags, one launch, no collective
+extern "C" int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end,
+                                   const double *x_free, const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u,
+                                   int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                                   void *stream) {
+    HFEM_ARG_CHECK(plan && peer, "null pointer");
+    HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
+    HFEM_ARG_CHECK(peer->connected, "hfem_peer_connect has not been called");
+    HFEM_ARG_CHECK(peer->device == plan->device, "plan and peer windows live on different devices");
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && loss_slot >= n_x + n_u && loss_slot < peer->stride, "bad sizes");
+    HFEM_ARG_CHECK((n_x + n_u == 0 || rows) && (n_x == 0 || x_free) && (n_u == 0 || u_free), "null pointer");
+    const int32_t nt = (int32_t)plan->host.tiles.size();
+    if (tile_end < 0) tile_end = nt;
+    HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
+    if (int rc = use_device(plan->device)) return rc;
+    PlanLock lock(plan);
+    return launch_iface_put(peer, x_free, u_free, rows, n_x, n_u, loss_slot,
+                            plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, counter, beta1,
+                            beta2, bc_next, (hipStream_t)stream);
+}
+
 // Options.  Product: tiled_block (256 / 512 / 1024 threads per tile), store_policy (0 plain, 16 sc1 write-through),
 // tiled_fast, fast_const_caps, quad4_const_caps, plan_elem_order (0..4), plan_node_cap, plan_chunk_cap, plan_curve
 // (0 Morton, 1 Hilbert): DEFAULTS that the next hfem_plan_create captures (a plan keeps what it was created with).

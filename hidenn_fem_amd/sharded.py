@@ -86,6 +86,62 @@ class LibraryComm:
             pass
 
 
+class PeerWindows:
+    """Receive windows of the peer-write interface exchange (``hfem_peer_*``, ``csrc/peer.hip``): each rank allocates one
+    window of ``2 x world x stride`` payload slots + arrival flags, the 64-byte IPC handles travel once over the already
+    initialised ``torch.distributed`` group (any backend), and from then on the pack launch of every step stores this
+    rank's interface rows straight into every rank's window (xGMI) -- no collective, no second stream, capturable.
+    ``world == 1`` needs no handle exchange (the rank's own window is the only one)."""
+
+    def __init__(self, device: torch.device, stride: int, group=None, rank: Optional[int] = None,
+                 world: Optional[int] = None, timeout_s: float = 5.0):
+        L = _lib.lib()
+        self.device = device
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.timeout_ticks = int(timeout_s * 1e8)                   # s_memrealtime runs at 100 MHz
+        self._h = C.c_void_p()
+        _lib.check(L.hfem_peer_create(_lib.dev_index(device), self.rank, self.world, int(stride), C.byref(self._h)),
+                   "hfem_peer_create")
+        if self.world > 1:
+            mine = (C.c_char * 64)()
+            _lib.check(L.hfem_peer_ipc_handle(self._h, mine), "hfem_peer_ipc_handle")
+            box = [None] * self.world
+            dist.all_gather_object(box, bytes(mine.raw), group=group)
+            allh = (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(box))
+            _lib.check(L.hfem_peer_connect(self._h, allh), "hfem_peer_connect")
+            dist.barrier(group=group)                               # every window is mapped everywhere before the first put
+
+    @property
+    def handle(self):
+        return self._h
+
+    def status(self):
+        """(sticky status bits, completed puts) -- synchronises with the device.  Bit 1: a get timed out waiting for a peer."""
+        st, puts = C.c_int32(0), C.c_int64(0)
+        _lib.check(_lib.lib().hfem_peer_status(self._h, C.byref(st), C.byref(puts)), "hfem_peer_status")
+        return st.value, puts.value
+
+    def check(self):
+        st, _ = self.status()
+        if st:
+            raise RuntimeError(f"peer-window exchange: status {st} (a rank waited {self.timeout_ticks / 1e8:.1f} s for a "
+                               "peer's interface rows that never arrived)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                _lib.lib().hfem_peer_destroy(self._h)
+            finally:
+                self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedTri3Energy:
     """``loss = sharded(model); loss.backward()`` with elements sharded over the ranks of
     ``group``.  ``evaluate`` is the per-rank evaluator ``(lo, hi, loss_view, gx_view, gu_view)``;
@@ -98,6 +154,7 @@ class ShardedTri3Energy:
         """``comm``: a ``LibraryComm`` -> the collectives are in-library RCCL calls on the current stream
         (hipGraph-capturable); ``None`` -> ``torch.distributed`` on ``group`` (any backend; what the CPU tests use)."""
         self.model, self.loss_fn, self.group, self.comm = model, loss_fn, group, comm
+        self.peer: Optional[PeerWindows] = None          # enable_peer_exchange(): interface rows by stores into peer windows
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is not None and world is not None:      # planning / single-process tests: act as rank of world
@@ -252,6 +309,19 @@ class ShardedTri3Energy:
                                     need_u=self._need_n[1], payload_bytes=int(self.iface_stride * 16))
         return self
 
+    def enable_peer_exchange(self, timeout_s: float = 5.0):
+        """Exchange the interface rows by PEER WRITES instead of an all_gather (``PeerWindows``; HIP evaluator only): the
+        pack launch stores the payload into every rank's window and the unpack launch waits for the arrival flags in its
+        own -- same payload, same unpack tables, same numbers.  Every ``owner_*`` step then runs on ONE stream; the
+        ``*_overlapped`` steps keep their launch order (the flags arrive while the interior tiles run).  Collective over
+        the group: call it on every rank, after ``setup_interfaces`` and before any graph capture."""
+        if not self._hip or self._unpack != self._unpack_hip:
+            raise RuntimeError("enable_peer_exchange needs the HIP evaluator and the HIP pack / unpack")
+        self.peer = PeerWindows(self.send.device, self.iface_stride, self.group, rank=self.rank, world=self.world,
+                                timeout_s=timeout_s)
+        self._step_cache = None
+        return self
+
     def _pack_hip(self):
         m, dev = self.model, self.send.device
         _lib.check(_lib.lib().hfem_iface_pack(_lib.dev_index(dev), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
@@ -261,6 +331,12 @@ class ShardedTri3Energy:
     def _unpack_hip(self, loss=None):
         m, dev = self.model, self.send.device
         loss = self.loss_global if loss is None else loss
+        if self.peer is not None:
+            _lib.check(_lib.lib().hfem_peer_iface_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
+                                                      self._need_n[0], self._need_n[1], m.node_coords_free.data_ptr(),
+                                                      m.u_free.data_ptr(), self.iface_rows, loss.data_ptr(),
+                                                      self.peer.timeout_ticks, _lib.stream_ptr(dev)), "hfem_peer_iface_get")
+            return
         _lib.check(_lib.lib().hfem_iface_unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(),
                                                 self._need_dst.data_ptr(), self._need_n[0], self._need_n[1],
                                                 m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.world,
@@ -271,6 +347,8 @@ class ShardedTri3Energy:
         """Kernel over this rank's tiles: gradient rows of the owned nodes into the local (send) buffer, the
         partial energy straight into the payload's loss slot."""
         _, gx_v, gu_v = self._views(self.send)
+        if self.peer is not None:                  # the put launch sums the tile energies itself
+            return self._eval_range(self.lo, self.hi, 0, False)
         self._evaluate(self.lo, self.hi, self.payload[self.iface_rows, 0:1], gx_v, gu_v)
 
     def exchange_halo(self):
@@ -279,12 +357,17 @@ class ShardedTri3Energy:
         updated the owned rows (and once before the first evaluation if ranks do not start from identical
         parameters).  Returns (global loss, local gx view, local gu view)."""
         _, gx_v, gu_v = self._views(self.send)
-        self._pack()
+        if self.peer is not None:
+            self._pack_loss(count_step=False)
+        else:
+            self._pack()
         self._gather_payloads()
         self._unpack()
         return self.loss_global, gx_v, gu_v
 
     def _gather_payloads(self):
+        if self.peer is not None:                      # the put launch already delivered the payload
+            return
         if self.comm is not None:
             self.comm.all_gather(self.payload, self.gathered)
         elif self.world > 1:
@@ -295,6 +378,9 @@ class ShardedTri3Energy:
     def owner_step(self):
         """evaluate_owner() + exchange_halo() with every Python-side lookup hoisted (views, parameter objects, ctypes
         functions, the stream): the N > 1 loop is host-bound, so this is what bench.py times.  HIP evaluator only."""
+        if self.peer is not None:
+            self.evaluate_owner()
+            return self.exchange_halo()
         c = getattr(self, "_step_cache", None)
         if c is None:
             _, gx_v, gu_v = self._views(self.send)
@@ -387,6 +473,14 @@ class ShardedTri3Energy:
         if self._hip:
             m, dev = self.model, self.send.device
             fz = getattr(self, "_fused", None)
+            ad = getattr(self, "_adam", None)
+            if self.peer is not None:
+                _lib.check(_lib.lib().hfem_plan_iface_put(
+                    self.plan.handle, self.peer.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(),
+                    m.u_free.data_ptr(), self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.iface_rows,
+                    ad["step"].data_ptr() if count_step else None, ad["betas"][0] if ad else 0.0, ad["betas"][1] if ad else 0.0,
+                    fz["bc"].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_put")
+                return
             _lib.check(_lib.lib().hfem_plan_iface_pack(
                 self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
                 self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
@@ -503,6 +597,9 @@ class ShardedTri3Energy:
         """all_gather + unpack of THIS step off the main stream.  The global energy goes to the loss slot the caller is
         not looking at; ``_join_exchange`` makes it ``loss_global``."""
         slot = self._loss_slots[1] if self.loss_global.data_ptr() == self._loss_slots[0].data_ptr() else self._loss_slots[0]
+        if self.peer is not None:                                  # the put is on its way; the get runs at the join
+            self._pending = ("peer", slot)
+            return
         if self._side is not None:                                 # GPU: all_gather + unpack on the side stream
             if self._unpack != self._unpack_hip:
                 raise RuntimeError("owner_train_step_overlapped on a GPU needs the HIP pack / unpack")
@@ -527,7 +624,10 @@ class ShardedTri3Energy:
         if self._pending is None:
             return
         work, slot = self._pending
-        if self._side is not None:
+        if work == "peer":
+            self._unpack_hip(slot)
+            self.loss_global = slot
+        elif self._side is not None:
             if work != "inline":
                 torch.cuda.current_stream(self.send.device).wait_stream(self._side)
             self.loss_global = slot

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HFEM_VERSION 110   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
+#define HFEM_VERSION 111   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
 
 int hfem_version(void);
 const char *hfem_last_error(void);
@@ -403,6 +403,36 @@ int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const 
 int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
                          const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
                          int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
+
+/* Peer-window exchange (csrc/peer.hip): the interface payload of hfem_plan_iface_pack written BY THE PACK KERNEL into a
+ * receive window on every rank -- stores over xGMI into IPC-mapped device memory -- with arrival flags, instead of an
+ * all_gather: no collective, no second stream, capturable.  One process per GPU (at most 16 ranks).  Set-up, once:
+ *   hfem_peer_create(device, rank, world, stride, &peer)   stride = interface rows + 1 (double2 units, as the all_gather
+ *                                                          payload); allocates and zeroes this rank's window
+ *   hfem_peer_ipc_handle(peer, h64)                        64-byte hipIpcMemHandle_t of the window; exchange the handles of
+ *                                                          all ranks by any side channel (torch.distributed, a file, MPI)
+ *   hfem_peer_connect(peer, handles[world][64])            maps the other ranks' windows (own entry ignored); world == 1
+ *                                                          needs neither call.  Barrier before the first put.
+ * Per step, stream-ordered, STRICTLY alternating on every rank:
+ *   hfem_plan_iface_put(...)   = hfem_plan_iface_pack with out = slot (puts so far) & 1 of my lane in every window, then a
+ *                                system-scope fence and flag = puts + 1 in every window
+ *   hfem_peer_iface_get(...)   = waits until every rank's flag of that slot has arrived in MY window, then
+ *                                hfem_iface_unpack from it (src indices as for the gathered [world][stride] payload).
+ * The wait is bounded: after timeout_ticks (100 MHz: 1e8 = 1 s) without a flag the kernel sets the sticky status bit 1 and
+ * goes on (later gets no longer wait) -- a lost peer is an error the host reads with hfem_peer_status (which synchronises
+ * with the device), never a hung GPU.  hfem_peer_status: status_out = sticky bits, puts_out = completed puts (either may
+ * be NULL).                                                                                                       */
+typedef struct hfem_peer hfem_peer;
+int hfem_peer_create(int device, int32_t rank, int32_t world, int64_t stride, hfem_peer **out);
+int hfem_peer_ipc_handle(hfem_peer *peer, void *handle_out_64_bytes);
+int hfem_peer_connect(hfem_peer *peer, const void *handles_world_x_64_bytes);
+int hfem_peer_destroy(hfem_peer *peer);
+int hfem_peer_status(hfem_peer *peer, int32_t *status_out, int64_t *puts_out);
+int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end, const double *x_free,
+                        const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, int64_t loss_slot,
+                        int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
+int hfem_peer_iface_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u, double *x_free,
+                        double *u_free, int64_t loss_slot, double *loss_out, int64_t timeout_ticks, void *stream);
 
 /* In-library collectives: one RCCL communicator per rank (one process per GPU).  Rank 0 calls
  * hfem_mg_unique_id and broadcasts the 128 bytes by any side channel (torch.distributed, a file, MPI); every rank

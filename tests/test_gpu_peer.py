@@ -1,0 +1,207 @@
+"""Peer-window interface exchange (csrc/peer.hip, sharded.PeerWindows): the owner-sharded steps with the interface rows
+stored by the pack launch into every rank's receive window instead of an all_gather.
+
+* one rank (the window is the rank's own): every ``owner_*`` step, eager and captured, against the same step over the
+  in-library RCCL communicator -- the same parameters and energies;
+* TWO PROCESSES sharing the one GPU of the box (IPC-mapped windows, gloo only for the handle exchange and as the
+  reference transport): world-2 trajectories over peer windows == over all_gather, plain / overlapped / fused, eager and
+  captured; and the bounded wait -- a rank whose peer never puts gets the sticky status bit, not a hang.
+  (Stores into a window on ANOTHER GPU go over xGMI; that leg needs the driver's multi-GPU node.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F64 = torch.float64
+LR_X, LR_U = 1e-6, 1e-8
+
+
+def _model(d, nx=201, ny=151):
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(nx, ny, jitter=0.2, seed=8, dtype=F64)
+    torch.manual_seed(4)
+    return PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                    neumann_edges=edges).to(d)
+
+
+def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0):
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    m = _model(d)
+    sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm, group=group)
+    sh.setup_interfaces()
+    sh.init_owner_adam(LR_X, LR_U, fused=fused)
+    if split is not None:
+        sh.mid = split(sh)
+    if peer:
+        sh.enable_peer_exchange(timeout_s=timeout_s)
+    return sh
+
+
+def _close(a, b):
+    """Same trajectory: the energy kernel's LDS atomics are order-dependent, so two runs agree to rounding, not to the bit
+    (the tolerance of tests/test_gpu_sharded.py)."""
+    a, b = torch.as_tensor(a, dtype=F64), torch.as_tensor(b, dtype=F64)
+    return a.shape == b.shape and bool((a - b).abs().max().item() <= 1e-12 * b.abs().max().item())
+
+
+def _run(sh, name, n, overlapped):
+    step = getattr(sh, name)
+    out = []
+    for k in range(n):
+        step()
+        if not overlapped:
+            out.append(sh.loss_global.item())
+        elif k:
+            out.append(sh.loss_global.item())
+    if overlapped:
+        out.append(sh.finish_overlapped().item())
+    torch.cuda.synchronize()
+    return out
+
+
+STEPS = (("owner_train_step", False, False), ("owner_train_step_overlapped", False, True),
+         ("owner_train_step_fused", True, False), ("owner_train_step_fused_overlapped", True, True))
+
+
+@pytest.mark.gpu
+def test_peer_windows_one_rank_every_step_matches_the_collective_path():
+    from hidenn_fem_amd.sharded import LibraryComm
+    d = torch.device("cuda:0")
+    comm = LibraryComm(d)
+    third = lambda sh: sh.plan.n_tiles // 3
+    n = 8
+    for name, fused, over in STEPS:
+        ref = _trainer(d, False, comm=comm, fused=fused, split=third if over else None)
+        l_ref = _run(ref, name, n, over)
+        got = _trainer(d, True, fused=fused, split=third if over else None)
+        assert got.peer is not None and got.comm is None
+        l_got = _run(got, name, n, over)
+        assert _close(l_got, l_ref), (name, l_got, l_ref)
+        for a, b in zip(got.model.parameters(), ref.model.parameters()):
+            assert _close(a.detach(), b.detach()), name
+        assert got.peer.status() == (0, n)
+        assert int(got._adam["step"].item()) == n
+        # captured: 4 steps per hipGraph, two replays, on top of the 8 eager ones -> 16 steps; the reference goes on eagerly
+        g = torch.cuda.CUDAGraph()
+        step = getattr(got, name)
+        with torch.cuda.graph(g):
+            for _ in range(4):
+                step()
+            if over:
+                got.finish_overlapped()
+        g.replay(); g.replay()
+        torch.cuda.synchronize()
+        # capture itself executes nothing: 8 eager + 2 x 4 replayed
+        l_more = _run(ref, name, 8, over)
+        assert got.peer.status() == (0, 16)
+        assert int(got._adam["step"].item()) == 16
+        assert _close(got.loss_global.item(), l_more[-1]), name
+        for a, b in zip(got.model.parameters(), ref.model.parameters()):
+            assert _close(a.detach(), b.detach()), name + " (captured)"
+        got.peer.close()
+    # evaluation-only steps
+    ref = _trainer(d, False, comm=comm, split=third)
+    got = _trainer(d, True, split=third)
+    l0, gx0, gu0 = ref.owner_step()
+    l1, gx1, gu1 = got.owner_step()
+    assert l0.item() == l1.item() and _close(gx1, gx0) and _close(gu1, gu0)
+    for _ in range(3):
+        got.owner_step_overlapped()
+    assert got.finish_overlapped().item() == l0.item()          # the energy itself is summed in a fixed order
+    assert got.peer.status() == (0, 4) and int(got._adam["step"].item()) == 0
+    comm.close()
+
+
+def _worker_two_ranks(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = torch.device("cuda:0")                         # both ranks on the box's one GPU
+        torch.cuda.set_device(d)
+        n = 6
+        report = {}
+        for name, fused, over in STEPS:
+            ref = _trainer(d, False, fused=fused)          # torch.distributed (gloo) all_gather as the reference transport
+            assert ref.world == 2 and ref.lo < ref.mid < ref.hi, "boundary and interior tiles exist"
+            got = _trainer(d, True, fused=fused)
+            ref_name = name.replace("_overlapped", "")     # same launches in another order: bit-equal (test_gpu_sharded.py)
+            l_ref = _run(ref, ref_name, n, False)
+            l_got = _run(got, name, n, over)
+            own_x, own_u = ref.owned_rows()
+            seen_x = torch.unique(torch.cat([own_x, ref._need_dst[:ref._need_n[0]].long()]))
+            seen_u = torch.unique(torch.cat([own_u, ref._need_dst[ref._need_n[0]:].long()]))
+            same = (_close(l_got, l_ref) and _close(got.model.node_coords_free[seen_x].detach(), ref.model.node_coords_free[seen_x].detach())
+                    and _close(got.model.u_free[seen_u].detach(), ref.model.u_free[seen_u].detach()))
+            st = got.peer.status()
+            # captured: an even number of steps per graph (the fused steps alternate between two parameter buffers)
+            dist.barrier()
+            g = torch.cuda.CUDAGraph()
+            step = getattr(got, name)
+            with torch.cuda.graph(g):
+                for _ in range(4):
+                    step()
+                if over:
+                    got.finish_overlapped()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            l_more = _run(ref, ref_name, 4, False)
+            same_g = (_close(got.loss_global.item(), l_more[-1])
+                      and _close(got.model.node_coords_free[seen_x].detach(), ref.model.node_coords_free[seen_x].detach())
+                      and _close(got.model.u_free[seen_u].detach(), ref.model.u_free[seen_u].detach()))
+            report[name] = (bool(same), bool(same_g), st, got.peer.status(), l_got)
+            dist.barrier()
+            got.peer.close()
+        # the bounded wait: rank 1 never puts; rank 0's get gives up after 0.3 s with the sticky status bit
+        lone = _trainer(d, True, timeout_s=0.3)
+        if rank == 0:
+            lone.owner_step()
+            torch.cuda.synchronize()
+            st = lone.peer.status()
+            try:
+                lone.peer.check()
+                raised = False
+            except RuntimeError:
+                raised = True
+            report["timeout"] = (st, raised)
+        dist.barrier()
+        lone.peer.close()
+        q.put((rank, report))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_peer_windows_two_processes_on_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_two_ranks, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name, _, _ in STEPS:
+        for r in (0, 1):
+            same, same_g, st, st_g, losses = res[r][name]
+            assert same, f"rank {r} {name}: peer-window trajectory differs from the all_gather one"
+            assert same_g, f"rank {r} {name}: captured peer-window steps differ"
+            assert st == (0, 6) and st_g == (0, 10), (r, name, st, st_g)
+        assert res[0][name][4] == res[1][name][4], "ranks disagree on the global energies (summed in rank order on both)"
+    assert res[0]["timeout"] == ((1, 1), True)

@@ -186,49 +186,71 @@ __global__ __launch_bounds__(kLb) void pair_reduce_kernel(LbfgsArrays A, int nb,
     }
 }
 
-// ---- one pass over the history: block b owns chunk b (kLbChunk elements); per active slot five dots
-template <typename T>
+// ---- one pass over the history: block b owns chunk b (kLbChunk elements); per active slot five dots.
+// The pass is latency-bound unless loads stay in flight across the per-slot reduction (five wave sums, a barrier, a store):
+// the next slot's 2 x kLbPer values are requested BEFORE the current slot is reduced (two register sets, the slot loop unrolled
+// by two; the partials buffer in LDS alternates so that one barrier per slot is enough).  10^6-element mesh (2 x 10^6 fp64
+// parameters), 100 pairs, 3.2 GB per pass: 936 -> 598 us (5.35 TB/s); 4 or 2 elements per thread are slower (1.39 / 1.86 ms per
+// L-BFGS iteration against 1.35).
+template <typename T, int PER>
 __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
                                                        const T *__restrict__ Yring, int64_t n, int M1) {
-    __shared__ double red[5][kLb / 64];
+    __shared__ double red[2][5][kLb / 64];
     const LbfgsState &S = *A.st;
     const int count = S.count, head = S.head, ns = S.new_slot;
-    const int64_t base = (int64_t)blockIdx.x * kLbChunk + threadIdx.x;
-    double gv[kLbPer], sv[kLbPer], yv[kLbPer];
+    const int64_t base = (int64_t)blockIdx.x * (kLb * PER) + threadIdx.x;
+    double gv[PER], sv[PER], yv[PER];
 #pragma unroll
-    for (int k = 0; k < kLbPer; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const int64_t i = base + (int64_t)k * kLb;
         gv[k] = i < n ? (double)g[i] : 0.0;
         sv[k] = (ns >= 0 && i < n) ? (double)Sring[(int64_t)ns * n + i] : 0.0;
         yv[k] = (ns >= 0 && i < n) ? (double)Yring[(int64_t)ns * n + i] : 0.0;
     }
-    // gridDim.y workgroups share a chunk and take the slots l = blockIdx.y, + gridDim.y, ...: short vectors (few
-    // chunks) still fill the chip; each (chunk, slot) partial is produced by exactly one workgroup, in the same order
-    for (int l = blockIdx.y; l < count; l += gridDim.y) {
+    auto load = [&](int l, T (&y)[PER], T (&s)[PER]) {
         const int slot = (head + l) % M1;
         const T *Yj = Yring + (int64_t)slot * n, *Sj = Sring + (int64_t)slot * n;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t i = base + (int64_t)k * kLb;
+            y[k] = i < n ? Yj[i] : (T)0;
+            s[k] = i < n ? Sj[i] : (T)0;
+        }
+    };
+    auto reduce_store = [&](int l, const T (&yr)[PER], const T (&sr)[PER], int buf) {
         double acc[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < kLbPer; ++k) {
-            const int64_t i = base + (int64_t)k * kLb;
-            if (i < n) {
-                const double y = (double)Yj[i], s = (double)Sj[i];
-                acc[0] += y * gv[k]; acc[1] += s * gv[k];
-                acc[2] += y * sv[k]; acc[3] += y * yv[k]; acc[4] += s * yv[k];
-            }
+        for (int k = 0; k < PER; ++k) {                      // out-of-range lanes hold zeros: same sums as a guarded loop
+            const double y = (double)yr[k], s = (double)sr[k];
+            acc[0] += y * gv[k]; acc[1] += s * gv[k];
+            acc[2] += y * sv[k]; acc[3] += y * yv[k]; acc[4] += s * yv[k];
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             const double w = wave_sum(acc[q]);
-            if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = w;
+            if ((threadIdx.x & 63) == 0) red[buf][q][threadIdx.x >> 6] = w;
         }
         __syncthreads();
         if (threadIdx.x < 5) {
             double r = 0.0;
-            for (int w = 0; w < kLb / 64; ++w) r += red[threadIdx.x][w];
-            A.part[((int64_t)blockIdx.x * M1 + slot) * 5 + threadIdx.x] = r;
+            for (int w = 0; w < kLb / 64; ++w) r += red[buf][threadIdx.x][w];
+            A.part[((int64_t)blockIdx.x * M1 + (head + l) % M1) * 5 + threadIdx.x] = r;
         }
-        __syncthreads();
+    };
+    // gridDim.y workgroups share a chunk and take the slots l = blockIdx.y, + gridDim.y, ...: short vectors (few
+    // chunks) still fill the chip; each (chunk, slot) partial is produced by exactly one workgroup, in the same order
+    const int gy = gridDim.y;
+    T ya[PER], sa[PER], yb[PER], sb[PER];
+    int l = blockIdx.y;
+    if (l < count) load(l, ya, sa);
+    for (; l < count; l += 2 * gy) {
+        const int l2 = l + gy;
+        if (l2 < count) load(l2, yb, sb);
+        reduce_store(l, ya, sa, 0);
+        if (l2 < count) {
+            if (l2 + gy < count) load(l2 + gy, ya, sa);
+            reduce_store(l2, yb, sb, 1);
+        }
     }
 }
 
@@ -318,117 +340,100 @@ __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, d
 // newer row k takes w_k += c_i s_i.y_k (rank-1 updates); a sequential step is then one LDS read, a few flops and a
 // broadcast, and the Gram entries it needs are fetched four steps ahead (their addresses do not depend on the values).
 // Logical index l = 0 (oldest) .. count-1; thread k owns rows k and k + 128.
-constexpr int kRecT = 128, kRecMax = 256;
+// Thread k owns row k and keeps its running sums t_k, w_k in REGISTERS; the owner of row i computes al_i (c_i) itself and
+// publishes it through LDS: one barrier per sequential step (the first version kept the sums in LDS for thread 0 to read
+// and paid two: 105 us at 100 pairs; this one 52 us; a single wavefront with four rows per lane 170 us -- the step is
+// bound by the LDS round trips per row, not by the barrier).
+constexpr int kRecT = 256, kRecMax = 256;
 __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, int M1, double lr, double tol_change) {
-    __shared__ double t_[kRecMax], w_[kRecMax], v_[kRecMax], al_[kRecMax], c_[kRecMax], ro_[kRecMax], sg_[kRecMax], yg_[kRecMax];
+    __shared__ double al_[kRecMax], c_[kRecMax];
     __shared__ int slot_[kRecMax];
     __shared__ double red[kRecT / 64];
     LbfgsState &S = *A.st;
-    const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x;
-    if (ns >= 0) {                                        // Gram row / column of the new pair
-        for (int l = tid; l < count; l += kRecT) {
-            const int j = (head + l) % M1;
-            A.SY[ns * M1 + j] = A.dots[j * 5 + 2];
-            A.SY[j * M1 + ns] = A.dots[j * 5 + 4];
-            A.YY[ns * M1 + j] = A.dots[j * 5 + 3];
-            A.YY[j * M1 + ns] = A.dots[j * 5 + 3];
-        }
+    const int count = S.count, head = S.head, ns = S.new_slot, k = threadIdx.x;
+    if (ns >= 0 && k < count) {                           // Gram row / column of the new pair
+        const int j = (head + k) % M1;
+        A.SY[ns * M1 + j] = A.dots[j * 5 + 2];
+        A.SY[j * M1 + ns] = A.dots[j * 5 + 4];
+        A.YY[ns * M1 + j] = A.dots[j * 5 + 3];
+        A.YY[j * M1 + ns] = A.dots[j * 5 + 3];
     }
-    for (int l = tid; l < count; l += kRecT) {
-        const int j = (head + l) % M1;
-        slot_[l] = j; ro_[l] = A.ro[j]; sg_[l] = A.dots[j * 5 + 1]; yg_[l] = A.dots[j * 5];
-        t_[l] = 0.0; w_[l] = 0.0;
-    }
-    __syncthreads();
+    const bool live = k < count;
+    const int sk = live ? (head + k) % M1 : 0;
+    const double ro = live ? A.ro[sk] : 0.0, sg = live ? A.dots[sk * 5 + 1] : 0.0, yg = live ? A.dots[sk * 5] : 0.0;
+    slot_[k] = sk;
+    __syncthreads();                                      // also orders the Gram writes above before the reads below (one block)
+    __threadfence_block();
     const double H = S.H_diag;
-    const int k0 = tid, k1 = tid + kRecT;
-    const int s0 = k0 < count ? slot_[k0] : 0, s1 = k1 < count ? slot_[k1] : 0;
+    double t = 0.0, w = 0.0, al_k = 0.0, c_k = 0.0;
     // ---- first loop, i = count-1 .. 0, four steps per prefetch group: column i of S^T Y
     {
-        double a0[4], a1[4], b0[4], b1[4];
-        auto fetch = [&](int i_hi, double (&x0)[4], double (&x1)[4]) {
+        double a[4], b[4];
+        auto fetch = [&](int i_hi, double (&x)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = i_hi - q;
-                const int si = i >= 0 ? slot_[i] : 0;
-                x0[q] = (i >= 0 && k0 < i) ? A.SY[s0 * M1 + si] : 0.0;
-                x1[q] = (i >= 0 && k1 < i) ? A.SY[s1 * M1 + si] : 0.0;
+                x[q] = (i >= 0 && k < i) ? A.SY[sk * M1 + slot_[i]] : 0.0;
             }
         };
-        fetch(count - 1, a0, a1);
+        fetch(count - 1, a);
         for (int ih = count - 1; ih >= 0; ih -= 4) {
-            fetch(ih - 4, b0, b1);                        // next group's entries land under this group's steps
+            fetch(ih - 4, b);                             // next group's entries land under this group's steps
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = ih - q;
                 if (i >= 0) {                             // uniform
-                    if (tid == 0) al_[i] = ro_[i] * (-sg_[i] - t_[i]);
+                    if (k == i) { al_k = ro * (-sg - t); al_[i] = al_k; }
                     __syncthreads();
-                    const double ai = al_[i];
-                    if (k0 < i) t_[k0] += ai * a0[q];
-                    if (k1 < i) t_[k1] += ai * a1[q];
-                    __syncthreads();
+                    if (k < i) t += al_[i] * a[q];
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { a0[q] = b0[q]; a1[q] = b1[q]; }
+            for (int q = 0; q < 4; ++q) a[q] = b[q];
         }
-    }
-    // ---- v_k = sum_j al_j y_k.y_j : every row streams its own Gram row (no dependence between rows)
-    {
-        double v0 = 0.0, v1 = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < count; ++j) {
-            const int sj = slot_[j];
-            const double aj = al_[j];
-            if (k0 < count) v0 += aj * A.YY[s0 * M1 + sj];
-            if (k1 < count) v1 += aj * A.YY[s1 * M1 + sj];
-        }
-        if (k0 < count) v_[k0] = v0;
-        if (k1 < count) v_[k1] = v1;
     }
     __syncthreads();
+    // ---- v_k = sum_j al_j y_k.y_j : every row streams its own Gram row (no dependence between rows)
+    double v = 0.0;
+    if (live) {
+#pragma unroll 8
+        for (int j = 0; j < count; ++j) v += al_[j] * A.YY[sk * M1 + slot_[j]];
+    }
     // ---- second loop, i = 0 .. count-1: row i of S^T Y
     {
-        double a0[4], a1[4], b0[4], b1[4];
-        auto fetch = [&](int i_lo, double (&x0)[4], double (&x1)[4]) {
+        double a[4], b[4];
+        auto fetch = [&](int i_lo, double (&x)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = i_lo + q;
-                const int si = i < count ? slot_[i] : 0;
-                x0[q] = (i < count && k0 > i && k0 < count) ? A.SY[si * M1 + s0] : 0.0;
-                x1[q] = (i < count && k1 > i && k1 < count) ? A.SY[si * M1 + s1] : 0.0;
+                x[q] = (i < count && k > i && live) ? A.SY[slot_[i] * M1 + sk] : 0.0;
             }
         };
-        fetch(0, a0, a1);
+        fetch(0, a);
         for (int il = 0; il < count; il += 4) {
-            fetch(il + 4, b0, b1);
+            fetch(il + 4, b);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = il + q;
                 if (i < count) {                          // uniform
-                    if (tid == 0) c_[i] = al_[i] - ro_[i] * (H * (-yg_[i] - v_[i]) + w_[i]);
+                    if (k == i) { c_k = al_k - ro * (H * (-yg - v) + w); c_[i] = c_k; }
                     __syncthreads();
-                    const double ci = c_[i];
-                    if (k0 > i && k0 < count) w_[k0] += ci * a0[q];
-                    if (k1 > i && k1 < count) w_[k1] += ci * a1[q];
-                    __syncthreads();
+                    if (k > i && live) w += c_[i] * a[q];
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { a0[q] = b0[q]; a1[q] = b1[q]; }
+            for (int q = 0; q < 4; ++q) a[q] = b[q];
         }
     }
     // ---- coefficients by slot, g.d, step, break flag
-    double v = 0.0;
-    for (int l = tid; l < count; l += kRecT) {
-        const int j = slot_[l];
-        const double cyj = -H * al_[l];
-        A.al[j] = al_[l]; A.cy[j] = cyj; A.cs[j] = c_[l];
-        v += cyj * yg_[l] + c_[l] * sg_[l];
+    double part = 0.0;
+    if (live) {
+        const double cyj = -H * al_k;
+        A.al[sk] = al_k; A.cy[sk] = cyj; A.cs[sk] = c_k;
+        part = cyj * yg + c_k * sg;
     }
-    const double sum = block_sum(v, red);
-    if (tid == 0) {
+    const double sum = block_sum(part, red);
+    if (k == 0) {
         S.cg = -H;
         S.gtd = -H * S.gg + sum;
         S.t = S.n_iter == 1 ? fmin(1.0, 1.0 / S.g_abssum) * lr : lr;
@@ -524,6 +529,7 @@ using namespace hfem;
 
 struct hfem_lbfgs {
     int device = -1, M1 = 0, dtype = 0, nb_stream = 0, nb_chunk = 0;
+    int per = kLbPer, nb_md = 0;                    // multidot: elements per thread (8 measured best of 2 / 4 / 8), its chunk count
     int64_t n = 0;
     bool first = true;              // no pair yet (torch state["n_iter"] == 0)
     void *Sring = nullptr, *Yring = nullptr, *g_prev = nullptr, *d = nullptr;
@@ -561,6 +567,7 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     const size_t esz = dtype == 0 ? 8 : 4, M1 = (size_t)o->M1;
     o->nb_chunk = (int)((n + kLbChunk - 1) / kLbChunk);
     o->nb_stream = (int)std::min<int64_t>((n + kLb - 1) / kLb, 2048);
+    o->nb_md = (int)((n + (int64_t)kLb * o->per - 1) / ((int64_t)kLb * o->per));
     int rc = 0;
     char *ring = nullptr;
     if (!rc) rc = lb_malloc(&ring, M1 * (size_t)n * esz); o->Sring = ring; ring = nullptr;
@@ -570,7 +577,7 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     const size_t nscal = 4 * M1 + 5 * M1 + 2 * M1 * M1;
     if (!rc) rc = lb_malloc(&o->scal, nscal);
     if (!rc) rc = lb_malloc(&o->status, 8);
-    const size_t npart = std::max<size_t>({(size_t)o->nb_chunk * M1 * 5, (size_t)o->nb_stream * 3, (size_t)o->nb_chunk,
+    const size_t npart = std::max<size_t>({(size_t)o->nb_md * M1 * 5, (size_t)o->nb_stream * 3, (size_t)o->nb_chunk,
                                            (size_t)((n + kLb - 1) / kLb) < 8192 ? (size_t)((n + kLb - 1) / kLb) : 0});
     if (!rc) rc = lb_malloc(&o->A.part, npart);
     if (!rc) rc = lb_malloc(&o->A.st, 1);
@@ -614,9 +621,11 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
     if (!first) {
         int gy = 2048 / o->nb_chunk;                      // slot classes: fill the chip when the vectors are short
         gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
-        if (o->dtype == 0) hipLaunchKernelGGL(multidot_kernel<double>, dim3(o->nb_chunk, gy), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, o->n, M1);
-        else hipLaunchKernelGGL(multidot_kernel<float>, dim3(o->nb_chunk, gy), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, o->n, M1);
-        hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_chunk, M1);
+#define HFEM_MD(T, P) hipLaunchKernelGGL((multidot_kernel<T, P>), dim3(o->nb_md, gy), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, o->n, M1)
+        if (o->dtype == 0) HFEM_MD(double, kLbPer);
+        else HFEM_MD(float, kLbPer);
+#undef HFEM_MD
+        hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_md, M1);
     }
     if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
     else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);

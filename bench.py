@@ -938,6 +938,41 @@ def main():
         except Exception as e:  # noqa: BLE001
             note(f"train_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
 
+    # ---- N = 1: Example 4's optimiser at full size -- LBFGS as the reference drives it (examples/example4.py:68-78: lr 1, max_iter 20,
+    #      history 100, no line search) on T1M.  With the history full an inner iteration streams the 2 x 100 history vectors twice
+    #      (multidot + direction passes, csrc/lbfgs.hip): 4 h n 8 B = 6.4 GB -- the optimiser, not the 9 us energy launch, is the iteration.
+    lbfgs1 = None
+    if world == 1 and not a.no_extra and not only and not a.only_extra:
+        try:
+            from hidenn_fem_amd.optim import FusedLBFGS
+
+            def lbfgs_run(cls, outer):
+                m_ = build_model(mesh6)
+                lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+                opt = cls(m_.parameters())
+                n_par = sum(p.numel() for p in m_.parameters())
+                ts = []
+                for _ in range(outer):
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    opt.step(lambda: lf_.value_and_grad_(m_))
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0_)
+                del opt, m_
+                torch.cuda.empty_cache()
+                return n_par, ts
+            n_par, ts = lbfgs_run(FusedLBFGS, 8)              # history (100 pairs) is full from outer step 5 on
+            it = sorted(ts[5:])[1] / 20.0
+            byts = 4.0 * 100 * n_par * 8
+            lbfgs1 = dict(workload="T1M, FusedLBFGS as examples/example4.py drives torch.optim.LBFGS (20 inner iterations per step, history 100), "
+                                   "history full", parameters=n_par, ms_per_inner_iteration=it * 1e3,
+                          alg_bytes_per_iteration=byts, achieved=byts / it / 1e9, unit="GB/s", frac=byts / it / 1e9 / HBM_PEAK_GBS,
+                          bytes_rule="4 h n 8 B: the 2 h history vectors read once by the multidot pass and once by the direction pass")
+            _, tt = lbfgs_run(torch.optim.LBFGS, 7)
+            lbfgs1["torch_optim_LBFGS_ms_per_inner_iteration"] = sorted(tt[5:])[len(tt[5:]) // 2] / 20.0 * 1e3
+        except Exception as e:  # noqa: BLE001
+            note(f"lbfgs_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
+
     # ---- N = 1: what the owner-sharded step machinery costs on ONE rank (no peer to talk to: every microsecond above the
     #      plain iteration is overhead of the exchange path) -- all_gather stand-in on one stream, the side-stream overlap,
     #      and the peer-window put / get; plain and fused (Adam inside the energy launch); K iterations per hipGraph.
@@ -1038,6 +1073,8 @@ def main():
             out["config"]["peer_exchange"] = dict(state=peer_state, **(peer_legs or {}))
         if shard1 is not None:
             out["config"]["sharded_step_1gpu"] = shard1
+        if lbfgs1 is not None:
+            out["config"]["lbfgs_step_1gpu"] = lbfgs1
         if notes:
             out["config"]["notes"] = notes
         if cpu is not None:

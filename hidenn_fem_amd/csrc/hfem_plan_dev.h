@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <vector>
 
 #include "hfem_device.h"
 
@@ -21,11 +22,107 @@ struct PlanDev {
     unsigned long long *span;       // span stamps (hfem_plan_set_span_stamps): {start, end} s_memrealtime ticks per tile, or NULL
 };
 
+// peer.hip: the interface payload written straight into every rank's receive window (no collective); layout in peer.hip
+constexpr int kMaxPeers = 16;
+constexpr size_t kPeerFlags = 0, kPeerData = 256;
+constexpr int kPeerGetBlocks = 8;    // in-launch get: service workgroups in front of the tiles (a multiple of the 8 XCDs)
+struct PeerView {                    // kernel argument: every rank's window as mapped into THIS process
+    char *win[kMaxPeers];
+    char *ctl;                       // this rank's private control block: [0] u64 puts, [8] u32 put ticket, [12] u32 status,
+    int rank, world;                 //   [16] u64 unpacked (the put count whose rows the in-launch get has copied in), [24] u32 get ticket
+};
+struct PeerGetDev {                  // device-resident arguments of the in-launch get (hfem_peer_attach_get)
+    PeerView pv;
+    const int32_t *src, *dst;        // unpack tables of hfem_iface_unpack
+    int n_x, n_u;
+    int64_t stride, loss_slot, timeout_ticks;
+    double *loss_out;
+};
+
 struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
     const double *prev = nullptr;    // partials bank the previous launch wrote (offset to its first tile)
     int prev_n = 0;
     double *out = nullptr;           // receives their sum (same order and bits as sum_partials_kernel)
+    // HFEM_FLAG_PEER_GET (paired-slot kernel only): the first pg_blocks workgroups of the launch are the peer-window get
+    // (wait for the flags, unpack into this launch's x_free / u_free, publish `unpacked`); tiles [wait_begin, wait_end) -- the
+    // rank's boundary tiles, the only ones that read rows another rank owns -- wait for it before they gather
+    const PeerGetDev *pg = nullptr;
+    int pg_blocks = 0, wait_begin = 0, wait_end = 0;
 };
+
+// One service workgroup of the in-launch get (256 threads of a tile kernel's block): iface_get_kernel's wait + unpack with
+// a block-stride loop, then -- rows visible device-wide -- the last of the nblk workgroups publishes unpacked = puts.
+__device__ __forceinline__ void peer_get_block(const PeerGetDev &G, int bid, int nblk, double2 *x_free, double2 *u_free) {
+    __shared__ int pg_last;
+    char *self = G.pv.win[G.pv.rank], *ctl = G.pv.ctl;
+    const int tid = threadIdx.x;
+    // only as many workgroups as there are rows to copy take part (the grid always carries kPeerGetBlocks of them so that the
+    // tiles keep their XCDs): fewer tickets on the boundary tiles' critical path
+    const int need = (G.n_x + G.n_u + 255) / 256;
+    nblk = need < 1 ? 1 : (need < nblk ? need : nblk);
+    if (bid >= nblk) return;
+    const uint64_t want = __hip_atomic_load((uint64_t *)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (want != 0 && tid < 256) {
+        const int par = (int)((want - 1) & 1);
+        unsigned *status = (unsigned *)(ctl + 12);
+        if (tid < G.pv.world) {
+            const uint64_t *flag = (const uint64_t *)(self + kPeerFlags) + par * kMaxPeers + tid;
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            // relaxed polls (an acquire load invalidates the caches EVERY time -- other tiles of this launch are running);
+            // one acquire fence after the barrier below
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) break;
+                if ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) > G.timeout_ticks) {
+                    atomicOr(status, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+    }
+    __syncthreads();
+    if (want != 0 && tid < 256) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);               // system scope, once per wave: the window's rows
+        const int par = (int)((want - 1) & 1);
+        const double2 *recv = (const double2 *)(self + kPeerData + (size_t)par * G.pv.world * (size_t)G.stride * sizeof(double2));
+        for (int i = bid * 256 + tid; i < G.n_x + G.n_u; i += nblk * 256) {
+            if (i < G.n_x) x_free[G.dst[i]] = recv[G.src[i]];
+            else u_free[G.dst[i]] = recv[G.src[i]];
+        }
+        if (bid == 0 && tid == 0 && G.loss_out) {
+            double tot = 0.0;
+            for (int r = 0; r < G.pv.world; ++r) tot += recv[(int64_t)r * G.stride + G.loss_slot].x;
+            G.loss_out[0] = tot;
+        }
+    }
+    __threadfence();                                       // agent scope: the rows reach memory before the ticket
+    __syncthreads();
+    if (tid == 0) pg_last = atomicAdd((unsigned *)(ctl + 24), 1u) == (unsigned)(nblk - 1);
+    __syncthreads();
+    if (pg_last && tid == 0) {
+        *(unsigned *)(ctl + 24) = 0u;
+        __hip_atomic_store((uint64_t *)(ctl + 16), want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// A boundary tile of the same launch: wait (bounded) until the get workgroups have published the rows of the current put count.
+__device__ __forceinline__ void peer_wait_unpacked(const PeerGetDev &G) {
+    if (threadIdx.x == 0) {
+        char *ctl = G.pv.ctl;
+        const uint64_t want = __hip_atomic_load((uint64_t *)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load((uint64_t *)(ctl + 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) > 2 * G.timeout_ticks) {
+                atomicOr((unsigned *)(ctl + 12), 2u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // once: the rows the get workgroups wrote are visible to this CU
+    }
+    __syncthreads();
+}
+
 
 
 struct AdamFuse {                    // arguments of the fused optimiser write-out (ADAM instances only)
@@ -107,6 +204,8 @@ struct hfem_plan {
     int64_t span_slots = 0, span_next = 0;
     int64_t device_bytes = 0;
     double row_line_factor = 1.0; // distinct 128-byte lines per tile's coordinate rows / the minimum (hfem_plan_create)
+    const hfem::PeerGetDev *peer_get = nullptr;   // hfem_plan_set_peer_get: in-launch get of HFEM_FLAG_PEER_GET launches
+    int peer_wait_begin = 0, peer_wait_end = 0;   // the tiles that wait for it (the rank's boundary tiles)
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
 };
@@ -164,29 +263,22 @@ int det_prepare(hfem_plan *plan, hipStream_t s);   // adjacency of the fixed-ord
 int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
                           int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
                           double beta2, double *bc_next, hipStream_t s);
-// peer.hip: the interface payload written straight into every rank's receive window (no collective); layout in peer.hip
-constexpr int kMaxPeers = 16;
-constexpr size_t kPeerFlags = 0, kPeerData = 256;
-struct PeerView {                    // kernel argument: every rank's window as mapped into THIS process
-    char *win[kMaxPeers];
-    char *ctl;                       // this rank's private control block (seq, ticket, status)
-    int rank, world;
-};
+int launch_iface_put(const hfem_peer *peer, const double *x_free, const double *u_free, const int32_t *rows, int n_x,
+                     int n_u, int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
+                     double beta2, double *bc_next, hipStream_t s);
 }  // namespace hfem
 struct hfem_peer {
     int device = -1;
     int64_t stride = 0;              // double2 units per rank and slot: interface rows + the loss entry
     size_t bytes = 0;
     char *local = nullptr;           // this rank's window (hipExtMallocWithFlags, uncached)
-    char *ctl = nullptr;             // seq / ticket / status (hipMalloc)
+    char *ctl = nullptr;             // puts / tickets / status / unpacked (hipMalloc)
+    hfem::PeerGetDev *get_dev = nullptr;   // arguments of the in-launch get (hfem_peer_attach_get), or NULL
     std::vector<void *> opened;      // hipIpcOpenMemHandle results (the peers' windows)
     bool connected = false;
     hfem::PeerView view{};
 };
 namespace hfem {
-int launch_iface_put(const hfem_peer *peer, const double *x_free, const double *u_free, const int32_t *rows, int n_x,
-                     int n_u, int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
-                     double beta2, double *bc_next, hipStream_t s);
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
 extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
 

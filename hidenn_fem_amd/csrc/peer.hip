@@ -13,7 +13,13 @@
 // and the get are chains of dependent loads):
 //     [0]    u64 seq      puts this rank has completed
 //     [8]    u32 ticket   block counter of the running put
-//     [12]   u32 status   sticky error bits (1: a get timed out waiting for a peer)
+//     [12]   u32 status   sticky error bits (1: a get timed out waiting for a peer, 2: a boundary tile timed out waiting for
+//                         the in-launch get)
+//     [16]   u64 unpacked the put count whose rows the in-launch get has copied in     [24] u32 its block counter
+// The in-launch get (hfem_peer_attach_get + hfem_plan_set_peer_get + HFEM_FLAG_PEER_GET; device code in hfem_plan_dev.h):
+// the get runs as the first 8 workgroups of the NEXT energy launch instead of a launch of its own -- the rank's boundary tiles,
+// the only ones that read rows another rank owns, wait for `unpacked` inside the kernel while every other tile runs.  One
+// energy launch per step, no get launch, and the link latency is still hidden.
 // Put k (seq == k) of rank s writes data[k & 1][s] of EVERY rank's window, fences at system scope, and its last workgroup
 // stores k + 1 into flags[k & 1][s] of every window, then bumps its own seq.  Get k waits (bounded: timeout in 100 MHz
 // ticks, then status |= 1 and it proceeds -- never a hang) until flags[k & 1][*] >= k + 1 in its OWN window, then unpacks.
@@ -200,6 +206,25 @@ extern "C" int hfem_peer_connect(hfem_peer *peer, const void *handles_world_x_64
     return 0;
 }
 
+// Arguments of the in-launch get (HFEM_FLAG_PEER_GET launches of a plan, hfem_plan_set_peer_get): the unpack tables and the
+// loss slot hfem_peer_iface_get takes per call, kept in device memory so that a tile kernel needs one pointer.
+extern "C" int hfem_peer_attach_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
+                                    int64_t loss_slot, double *loss_out, int64_t timeout_ticks) {
+    HFEM_ARG_CHECK(peer, "null pointer");
+    HFEM_ARG_CHECK(peer->connected, "hfem_peer_connect has not been called");
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && loss_slot >= 0 && loss_slot < peer->stride && timeout_ticks > 0, "bad sizes");
+    HFEM_ARG_CHECK(n_x + n_u == 0 || (src && dst), "null pointer");
+    if (int rc = use_device(peer->device)) return rc;
+    PeerGetDev g;
+    g.pv = peer->view; g.src = src; g.dst = dst; g.n_x = n_x; g.n_u = n_u;
+    g.stride = peer->stride; g.loss_slot = loss_slot; g.timeout_ticks = timeout_ticks; g.loss_out = loss_out;
+    hipError_t e = hipSuccess;
+    if (!peer->get_dev) e = hipMalloc((void **)&peer->get_dev, sizeof(PeerGetDev));
+    if (e == hipSuccess) e = hipMemcpy(peer->get_dev, &g, sizeof(PeerGetDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "hfem_peer_attach_get");
+    return 0;
+}
+
 extern "C" int hfem_peer_destroy(hfem_peer *peer) {
     if (!peer) return 0;
     (void)use_device(peer->device);
@@ -207,6 +232,7 @@ extern "C" int hfem_peer_destroy(hfem_peer *peer) {
     for (void *o : peer->opened) (void)hipIpcCloseMemHandle(o);
     if (peer->local) (void)hipFree(peer->local);
     if (peer->ctl) (void)hipFree(peer->ctl);
+    if (peer->get_dev) (void)hipFree(peer->get_dev);
     delete peer;
     return 0;
 }

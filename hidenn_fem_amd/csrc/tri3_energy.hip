@@ -873,6 +873,12 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         lag.prev_n = plan->prev_n;
         lag.out = loss_out;
     }
+    if (flags & HFEM_FLAG_PEER_GET) {
+        HFEM_ARG_CHECK(plan->peer_get, "HFEM_FLAG_PEER_GET: hfem_plan_set_peer_get has not been called");
+        HFEM_ARG_CHECK(h.paired && !hasb && !phys && n > 0, "HFEM_FLAG_PEER_GET: paired-slot plans, default forces and convention, a non-empty tile range");
+        lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
+        lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
+    }
     int n_partials = n;
     if (n > 0) {
         Tri3Launch A;
@@ -886,7 +892,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         HFEM_LAB_TRI3_LAUNCH(plan, A, n, hasb, phys, lag, n_partials, launched)
         if (!launched && h.paired) {      // paired plan (plan_elem_order 5, the default): its records are the pair kernel's
             PairLaunch P;
-            P.grid = n + (lag.prev ? 1 : 0); P.tile_begin = (int)tile_begin;
+            P.grid = n + (lag.prev ? 1 : 0) + lag.pg_blocks; P.tile_begin = (int)tile_begin;
             P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
             P.k = A.k; P.T_edge = A.T_edge; P.tc = tc; P.partials = A.partials; P.gx = A.gx; P.gu = A.gu;
             P.skip_edges = A.skip_edges; P.s = s;
@@ -1059,6 +1065,12 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
         lag.prev_n = plan->prev_n;
         lag.out = loss_out;
     }
+    if (flags & HFEM_FLAG_PEER_GET) {
+        HFEM_ARG_CHECK(plan->peer_get, "HFEM_FLAG_PEER_GET: hfem_plan_set_peer_get has not been called");
+        HFEM_ARG_CHECK(h.paired && dtype == 0 && n > 0, "HFEM_FLAG_PEER_GET: paired-slot plans, fp64 rows, a non-empty tile range");
+        lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
+        lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
+    }
     if (n > 0) {
         AdamFuse af;
         af.x_out = x_out; af.u_out = u_out;
@@ -1072,7 +1084,7 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
         A.partials = pbase;
         A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
         A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
-        const int grid = n + (lag_consume ? 1 : 0);
+        const int grid = n + (lag_consume ? 1 : 0) + lag.pg_blocks;
         if (h.paired) {
             PairLaunch P;
             P.grid = grid; P.tile_begin = tile_begin;
@@ -1167,6 +1179,22 @@ extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t
     return launch_iface_pack_sum(x_free, u_free, rows, n_x, n_u, out, loss_slot,
                                  plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, counter,
                                  beta1, beta2, bc_next, (hipStream_t)stream);
+}
+
+// The in-launch get: launches of this plan with HFEM_FLAG_PEER_GET start with kPeerGetBlocks service workgroups that wait for
+// the peers' flags and copy the interface rows in, while tiles [wait_begin, wait_end) -- the rank's boundary tiles -- wait
+// for them and every other tile runs (csrc/peer.hip, hfem_peer_attach_get).  peer == NULL detaches.
+extern "C" int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t wait_begin, int32_t wait_end) {
+    HFEM_ARG_CHECK(plan, "null pointer");
+    PlanLock lock(plan);
+    if (!peer) { plan->peer_get = nullptr; return 0; }
+    HFEM_ARG_CHECK(peer->connected && peer->get_dev, "hfem_peer_connect / hfem_peer_attach_get first");
+    HFEM_ARG_CHECK(peer->device == plan->device, "plan and peer windows live on different devices");
+    const int32_t nt = (int32_t)plan->host.tiles.size();
+    HFEM_ARG_CHECK(wait_begin >= 0 && wait_begin <= wait_end && wait_end <= nt, "bad tile range");
+    HFEM_ARG_CHECK(plan->host.paired, "the in-launch get is implemented by the paired-slot kernel only");
+    plan->peer_get = peer->get_dev; plan->peer_wait_begin = wait_begin; plan->peer_wait_end = wait_end;
+    return 0;
 }
 
 // hfem_plan_iface_pack whose payload goes straight into every rank's receive window (csrc/peer.hip): pack + energy sum +

@@ -13,6 +13,8 @@
 // HBM-bound, no MFMA (2x2 / 2x3 contractions).  Algorithmic bytes per launch: 12 Ne + 64 Nn + 8.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "hfem_device.h"
 #include "hfem_plan_dev.h"
 
@@ -44,8 +46,17 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     double *red = acc3 + cap_owned;
 
     const int tid = threadIdx.x;
-    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0);
-    if (lag.prev && (int)blockIdx.x == n_launch) {      // HFEM_FLAG_SUM_PREVIOUS: reduce the previous launch's tile energies
+    int bid = (int)blockIdx.x;
+    if (lag.pg_blocks) {                                // HFEM_FLAG_PEER_GET: the first workgroups are the peer-window get (peer.hip)
+        if (bid < lag.pg_blocks) {
+            if constexpr (std::is_same<V2, double2>::value)
+                peer_get_block(*lag.pg, bid, lag.pg_blocks, const_cast<double2 *>(x_free), const_cast<double2 *>(u_free));
+            return;
+        }
+        bid -= lag.pg_blocks;                           // a multiple of 8: the block -> XCD mapping of the tiles is unchanged
+    }
+    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0) - lag.pg_blocks;
+    if (lag.prev && bid == n_launch) {                  // HFEM_FLAG_SUM_PREVIOUS: reduce the previous launch's tile energies
         double v = 0.0;
         if (tid < 256)
             for (int i = tid; i < lag.prev_n; i += 256) v += lag.prev[i];
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         if (tid == 0) lag.out[0] = tot;
         return;
     }
-    const int slot = xcd_tile(blockIdx.x, n_launch);
+    const int slot = xcd_tile(bid, n_launch);
     // span stamps (hfem_plan_set_span_stamps, off by default): when this workgroup started -- scalar registers only
     unsigned long long t_start = 0;
     if (pd.span) t_start = __builtin_amdgcn_s_memrealtime();
@@ -74,6 +85,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         w0[j] = pd.elem_pack[i];
         w1[j] = pd.elem_pack_hi[i];
     }
+    if (lag.pg_blocks && tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end)
+        peer_wait_unpacked(*lag.pg);                    // a boundary tile: the rows it reads from other ranks are being copied in
+                                                        // (its row maps and slot records are already on their way)
     // ---- gather through the row maps: issued before anything that needs the descriptor (program order = vmcnt order)
     V2 vx[NPT], vu[NPT];
 #pragma unroll

@@ -155,6 +155,7 @@ class ShardedTri3Energy:
         (hipGraph-capturable); ``None`` -> ``torch.distributed`` on ``group`` (any backend; what the CPU tests use)."""
         self.model, self.loss_fn, self.group, self.comm = model, loss_fn, group, comm
         self.peer: Optional[PeerWindows] = None          # enable_peer_exchange(): interface rows by stores into peer windows
+        self.inkernel_get = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is not None and world is not None:      # planning / single-process tests: act as rank of world
@@ -309,18 +310,38 @@ class ShardedTri3Energy:
                                     need_u=self._need_n[1], payload_bytes=int(self.iface_stride * 16))
         return self
 
-    def enable_peer_exchange(self, timeout_s: float = 5.0):
+    def enable_peer_exchange(self, timeout_s: float = 5.0, inkernel_get: Optional[bool] = None):
         """Exchange the interface rows by PEER WRITES instead of an all_gather (``PeerWindows``; HIP evaluator only): the
         pack launch stores the payload into every rank's window and the unpack launch waits for the arrival flags in its
         own -- same payload, same unpack tables, same numbers.  Every ``owner_*`` step then runs on ONE stream; the
         ``*_overlapped`` steps keep their launch order (the flags arrive while the interior tiles run).  Collective over
-        the group: call it on every rank, after ``setup_interfaces`` and before any graph capture."""
+        the group: call it on every rank, after ``setup_interfaces`` and before any graph capture.  ``inkernel_get`` (default:
+        whenever the plan is a paired-slot one): the ``*_overlapped`` steps run the get as the first workgroups of their ONE
+        energy launch (``HFEM_FLAG_PEER_GET``) instead of a launch of its own."""
         if not self._hip or self._unpack != self._unpack_hip:
             raise RuntimeError("enable_peer_exchange needs the HIP evaluator and the HIP pack / unpack")
         self.peer = PeerWindows(self.send.device, self.iface_stride, self.group, rank=self.rank, world=self.world,
                                 timeout_s=timeout_s)
         self._step_cache = None
+        # the get INSIDE the next energy launch (paired-slot plans): the overlapped steps then are one energy launch per step --
+        # its first workgroups wait for the flags and unpack, the boundary tiles wait for them in the kernel, the rest runs
+        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else self.plan.is_paired())
+        if self.inkernel_get:
+            if not self.plan.is_paired():
+                raise RuntimeError("inkernel_get needs a paired-slot plan")
+            _lib.check(_lib.lib().hfem_peer_attach_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
+                                                       self._need_n[0], self._need_n[1], self.iface_rows,
+                                                       self._loss_slots[0].data_ptr(), self.peer.timeout_ticks),
+                       "hfem_peer_attach_get")
+            self._wait_range = None
         return self
+
+    def _bind_peer_get(self):
+        """(Re)bind the in-launch get to the plan with the rank's CURRENT boundary range [lo, mid)."""
+        if self._wait_range != (self.lo, self.mid):
+            _lib.check(_lib.lib().hfem_plan_set_peer_get(self.plan.handle, self.peer.handle, int(self.lo), int(self.mid)),
+                       "hfem_plan_set_peer_get")
+            self._wait_range = (self.lo, self.mid)
 
     def _pack_hip(self):
         m, dev = self.model, self.send.device
@@ -456,7 +477,7 @@ class ShardedTri3Energy:
             a["mu"].data_ptr(), a["vu"].data_ptr(), a["rows_u"].data_ptr(), a["rows_u"].numel(), a["lr"][1],
             a["betas"][0], a["betas"][1], a["eps"], a["step"].data_ptr(), 1, _lib.stream_ptr(dev)), "hfem_adam_step_rows2_dev")
 
-    def _eval_range(self, lo, hi, part, cont):
+    def _eval_range(self, lo, hi, part, cont, peer_get=False):
         """Energy + gradients over ONE tile range of an evaluation; ``cont``: an earlier range of the same evaluation was
         launched.  The tile energies stay in the plan (HIP: HFEM_FLAG_NO_LOSS_SUM, later ranges HFEM_FLAG_SAME_BANK; seam
         evaluators: ``_e_parts[part]``) until ``_pack_loss`` sums them."""
@@ -466,7 +487,9 @@ class ShardedTri3Energy:
             if hi > lo:
                 self._evaluate(lo, hi, self._e_parts[part:part + 1], gx_v, gu_v)
         elif hi > lo:
-            self._evaluate_hip(lo, hi, self.loss_global, gx_v, gu_v, 8 | (256 if cont else 0))
+            if peer_get:
+                self._bind_peer_get()
+            self._evaluate_hip(lo, hi, self.loss_global, gx_v, gu_v, 8 | (256 if cont else 0) | (512 if peer_get else 0))
 
     def _pack_loss(self, count_step=True):
         """Interface rows + this rank's energy into the payload, step counter += 1 (HIP: one launch)."""
@@ -519,16 +542,20 @@ class ShardedTri3Energy:
         ``owner_train_step``.  ``loss_global`` lags: after step k returns it holds the energy of step k - 1;
         ``finish_overlapped()`` joins the last exchange (call it before reading parameters or the loss, and at the end
         of every captured graph)."""
-        self._eval_range(self.mid, self.hi, 0, False)              # interior: depends on nothing another rank produces
-        self._join_exchange()                                      # foreign interface rows of the previous step are in
-        self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)   # boundary tiles, same evaluation
+        if self.inkernel_get:                                      # ONE energy launch: get workgroups + waiting boundary tiles inside
+            self._inkernel_begin()
+            self._eval_range(self.lo, self.hi, 0, False, peer_get=True)
+        else:
+            self._eval_range(self.mid, self.hi, 0, False)          # interior: depends on nothing another rank produces
+            self._join_exchange()                                  # foreign interface rows of the previous step are in
+            self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)   # boundary tiles, same evaluation
         self._adam_step()
         self._pack_loss()
         self._fork_exchange()
         return self.loss_global
 
     # ---- fused steps: the energy launch applies Adam's update to the rows its tiles own (no gradient traffic, no Adam launch)
-    def _fused_range(self, lo, hi, cont):
+    def _fused_range(self, lo, hi, cont, peer_get=False):
         """Energy over tiles [lo, hi) with the fused Adam write-out: reads the current parameter buffers, writes the new rows of
         the nodes those tiles own into the other buffers.  HIP only; fp64 models; default forces."""
         if hi <= lo:
@@ -537,13 +564,16 @@ class ShardedTri3Energy:
         dev = self.send.device
         mat, W, Bk, Tc, _ = self._hip_consts()
         i, o = fz["k"] & 1, (fz["k"] + 1) & 1
+        if peer_get:
+            self._bind_peer_get()
         xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()
         _lib.check(_lib.lib().hfem_tri3_energy_adam_step_ex(
             self.plan.handle, 0, fz["x"][i].data_ptr(), xfix.data_ptr() if xfix.numel() else None, fz["u"][i].data_ptr(),
             ufix.data_ptr() if ufix.numel() else None, mat, W, None, None, Tc, fz["x"][o].data_ptr(), fz["u"][o].data_ptr(),
             a["mx"].data_ptr(), a["vx"].data_ptr(), a["mu"].data_ptr(), a["vu"].data_ptr(), a["lr"][0], a["lr"][1],
             a["betas"][0], a["betas"][1], a["eps"], fz["bc"].data_ptr(), int(lo), int(hi), self.loss_global.data_ptr(),
-            8 | (256 if cont else 0) | (0 if m.N_edges else 4), _lib.stream_ptr(dev)), "hfem_tri3_energy_adam_step_ex")
+            8 | (256 if cont else 0) | (0 if m.N_edges else 4) | (512 if peer_get else 0), _lib.stream_ptr(dev)),
+            "hfem_tri3_energy_adam_step_ex")
 
     def _fused_swap(self):
         """The new rows become the model's parameters (``param.data`` alternates between the two buffers: capture an EVEN
@@ -573,9 +603,13 @@ class ShardedTri3Energy:
         the other, so the boundary tiles still see the step's input values of the rows interior tiles own)."""
         if self._fused is None or not self._hip:
             raise RuntimeError("owner_train_step_fused_overlapped needs init_owner_adam(..., fused=True) and the HIP evaluator")
-        self._fused_range(self.mid, self.hi, False)
-        self._join_exchange()
-        self._fused_range(self.lo, self.mid, self.hi > self.mid)
+        if self.inkernel_get:
+            self._inkernel_begin()
+            self._fused_range(self.lo, self.hi, False, peer_get=True)
+        else:
+            self._fused_range(self.mid, self.hi, False)
+            self._join_exchange()
+            self._fused_range(self.lo, self.mid, self.hi > self.mid)
         self._fused_swap()
         self._pack_loss()
         self._fork_exchange()
@@ -586,9 +620,13 @@ class ShardedTri3Energy:
         under the interior tiles of step k + 1 -- the evaluation-only counterpart of ``owner_train_step_overlapped``.
         Gradients of the owned rows are in the send buffer when it returns; ``loss_global`` lags one step
         (``finish_overlapped()`` joins the last exchange).  Needs ``init_owner_adam`` (its streams and buffers)."""
-        self._eval_range(self.mid, self.hi, 0, False)
-        self._join_exchange()
-        self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)
+        if self.inkernel_get:
+            self._inkernel_begin()
+            self._eval_range(self.lo, self.hi, 0, False, peer_get=True)
+        else:
+            self._eval_range(self.mid, self.hi, 0, False)
+            self._join_exchange()
+            self._eval_range(self.lo, self.mid, 1, self.hi > self.mid)
         self._pack_loss(count_step=False)
         self._fork_exchange()
         return self.loss_global
@@ -598,7 +636,7 @@ class ShardedTri3Energy:
         not looking at; ``_join_exchange`` makes it ``loss_global``."""
         slot = self._loss_slots[1] if self.loss_global.data_ptr() == self._loss_slots[0].data_ptr() else self._loss_slots[0]
         if self.peer is not None:                                  # the put is on its way; the get runs at the join
-            self._pending = ("peer", slot)
+            self._pending = ("peer", self._loss_slots[0] if self.inkernel_get else slot)   # the in-launch get has ONE loss slot
             return
         if self._side is not None:                                 # GPU: all_gather + unpack on the side stream
             if self._unpack != self._unpack_hip:
@@ -619,6 +657,13 @@ class ShardedTri3Energy:
         else:
             self._gather_payloads()
             self._pending = (None, slot)
+
+    def _inkernel_begin(self):
+        """The energy launch that follows contains the get of the pending exchange: the global energy lands in loss slot 0."""
+        if self._pending is not None:
+            self.loss_global = self._loss_slots[0]
+            self._step_cache = None
+            self._pending = None
 
     def _join_exchange(self):
         if self._pending is None:

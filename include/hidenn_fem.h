@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HFEM_VERSION 111   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
+#define HFEM_VERSION 112   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
 
 int hfem_version(void);
 const char *hfem_last_error(void);
@@ -149,6 +149,9 @@ int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t ca
                                    * reduction + kernel boundary leave the critical path.  hfem_plan_loss_sum
                                    * delivers the last one.  TRI3 default kernel path only.                    */
 
+#define HFEM_FLAG_PEER_GET 512  /* paired-slot plans, after hfem_plan_set_peer_get: the launch starts with 8 service workgroups that
+                                 * ARE the peer-window get (hfem_peer_iface_get's wait + unpack into this launch's x_free / u_free)
+                                 * and the tiles named there (the rank's boundary tiles) wait for them inside the kernel        */
 #define HFEM_FLAG_SAME_BANK 256 /* with NO_LOSS_SUM: another tile range of the SAME evaluation as the previous NO_LOSS_SUM
                                  * launch on this plan (a rank's boundary tiles after its interior tiles): the tile energies
                                  * go to the bank that launch wrote, so one hfem_plan_loss_sum / hfem_plan_iface_pack over
@@ -428,6 +431,14 @@ int hfem_peer_ipc_handle(hfem_peer *peer, void *handle_out_64_bytes);
 int hfem_peer_connect(hfem_peer *peer, const void *handles_world_x_64_bytes);
 int hfem_peer_destroy(hfem_peer *peer);
 int hfem_peer_status(hfem_peer *peer, int32_t *status_out, int64_t *puts_out);
+/* The get INSIDE the next energy launch (one launch less per step, and no tile that does not need foreign rows waits):
+ * hfem_peer_attach_get stores hfem_peer_iface_get's tables / loss slot / timeout in device memory, hfem_plan_set_peer_get
+ * binds them to a plan together with the tile range [wait_begin, wait_end) that must wait (the rank's boundary tiles:
+ * hfem_plan_export id 10), and hfem_tri3_energy_plan / hfem_tri3_energy_adam_step_ex with HFEM_FLAG_PEER_GET then run the
+ * get as their first workgroups.  Status bit 2: a boundary tile gave up waiting (after 2 x timeout_ticks).           */
+int hfem_peer_attach_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
+                         int64_t loss_slot, double *loss_out, int64_t timeout_ticks);
+int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t wait_begin, int32_t wait_end);
 int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end, const double *x_free,
                         const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, int64_t loss_slot,
                         int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);

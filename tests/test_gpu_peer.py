@@ -1,5 +1,6 @@
 """Peer-window interface exchange (csrc/peer.hip, sharded.PeerWindows): the owner-sharded steps with the interface rows
-stored by the pack launch into every rank's receive window instead of an all_gather.
+stored by the pack launch into every rank's receive window instead of an all_gather; the ``*_overlapped`` steps run the get
+INSIDE their one energy launch (HFEM_FLAG_PEER_GET: service workgroups + boundary tiles that wait in the kernel).
 
 * one rank (the window is the rank's own): every ``owner_*`` step, eager and captured, against the same step over the
   in-library RCCL communicator -- the same parameters and energies;

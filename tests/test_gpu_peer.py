@@ -32,7 +32,7 @@ def _model(d, nx=201, ny=151):
                                     neumann_edges=edges).to(d)
 
 
-def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0):
+def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0, inkernel=None):
     from hidenn_fem_amd.loss import EnergyLoss2D
     from hidenn_fem_amd.sharded import ShardedTri3Energy
     m = _model(d)
@@ -42,7 +42,8 @@ def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=
     if split is not None:
         sh.mid = split(sh)
     if peer:
-        sh.enable_peer_exchange(timeout_s=timeout_s)
+        sh.enable_peer_exchange(timeout_s=timeout_s, inkernel_get=inkernel)
+        assert sh.inkernel_get == (sh.plan.is_paired() if inkernel is None else inkernel)
     return sh
 
 
@@ -107,6 +108,17 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
         assert _close(got.loss_global.item(), l_more[-1]), name
         for a, b in zip(got.model.parameters(), ref.model.parameters()):
             assert _close(a.detach(), b.detach()), name + " (captured)"
+        got.peer.close()
+    # the overlapped steps with the get as a launch of its own (what plans without paired slots use)
+    for name, fused, over in STEPS:
+        if not over:
+            continue
+        ref = _trainer(d, False, comm=comm, fused=fused, split=third)
+        got = _trainer(d, True, fused=fused, split=third, inkernel=False)
+        assert _close(_run(got, name, n, True), _run(ref, name, n, True)), name
+        for a, b in zip(got.model.parameters(), ref.model.parameters()):
+            assert _close(a.detach(), b.detach()), name
+        assert got.peer.status() == (0, n)
         got.peer.close()
     # evaluation-only steps
     ref = _trainer(d, False, comm=comm, split=third)

@@ -4,8 +4,8 @@ INSIDE their one energy launch (HFEM_FLAG_PEER_GET: service workgroups + boundar
 
 * one rank (the window is the rank's own): every ``owner_*`` step, eager and captured, against the same step over the
   in-library RCCL communicator -- the same parameters and energies;
-* TWO PROCESSES sharing the one GPU of the box (IPC-mapped windows, gloo only for the handle exchange and as the
-  reference transport): world-2 trajectories over peer windows == over all_gather, plain / overlapped / fused, eager and
+* TWO and THREE PROCESSES sharing the one GPU of the box (IPC-mapped windows, gloo only for the handle exchange and as the
+  reference transport): world-2 and world-3 trajectories over peer windows == over all_gather, plain / overlapped / fused, eager and
   captured; and the bounded wait -- a rank whose peer never puts gets the sticky status bit, not a hang.
   (Stores into a window on ANOTHER GPU go over xGMI; that leg needs the driver's multi-GPU node.)"""
 import os
@@ -145,7 +145,7 @@ def _worker_two_ranks(rank, world, port, q):
         report = {}
         for name, fused, over in STEPS:
             ref = _trainer(d, False, fused=fused)          # torch.distributed (gloo) all_gather as the reference transport
-            assert ref.world == 2 and ref.lo < ref.mid < ref.hi, "boundary and interior tiles exist"
+            assert ref.world == world and ref.lo < ref.mid < ref.hi, "boundary and interior tiles exist"
             got = _trainer(d, True, fused=fused)
             ref_name = name.replace("_overlapped", "")     # same launches in another order: bit-equal (test_gpu_sharded.py)
             l_ref = _run(ref, ref_name, n, False)
@@ -175,7 +175,7 @@ def _worker_two_ranks(rank, world, port, q):
             report[name] = (bool(same), bool(same_g), st, got.peer.status(), l_got)
             dist.barrier()
             got.peer.close()
-        # the bounded wait: rank 1 never puts; rank 0's get gives up after 0.3 s with the sticky status bit
+        # the bounded wait: only rank 0 puts; its get gives up after 0.3 s with the sticky status bit
         lone = _trainer(d, True, timeout_s=0.3)
         if rank == 0:
             lone.owner_step()
@@ -196,25 +196,26 @@ def _worker_two_ranks(rank, world, port, q):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-def test_peer_windows_two_processes_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_windows_processes_sharing_one_gpu(world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_two_ranks, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_two_ranks, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=500) for _ in range(2))
+    res = dict(q.get(timeout=500) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     for name, _, _ in STEPS:
-        for r in (0, 1):
+        for r in range(world):
             same, same_g, st, st_g, losses = res[r][name]
             assert same, f"rank {r} {name}: peer-window trajectory differs from the all_gather one"
             assert same_g, f"rank {r} {name}: captured peer-window steps differ"
             assert st == (0, 6) and st_g == (0, 10), (r, name, st, st_g)
-        assert res[0][name][4] == res[1][name][4], "ranks disagree on the global energies (summed in rank order on both)"
+        assert all(res[r][name][4] == res[0][name][4] for r in range(world)), "ranks disagree on the global energies (summed in rank order everywhere)"
     assert res[0]["timeout"] == ((1, 1), True)

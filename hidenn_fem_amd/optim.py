@@ -252,13 +252,27 @@ class FusedLBFGS(torch.optim.Optimizer):
             self._h = h
         return self._h
 
+    def _adopt_grads(self):
+        """Let ``p.grad`` BE the parameter's segment of the flat gradient vector wherever no gradient tensor exists yet: a
+        closure that writes gradients in place (``EnergyLoss2D.value_and_grad_``; autograd's accumulation into an existing
+        ``.grad``) then fills the optimiser's vector directly and ``_gather_flat_grad`` has nothing to copy.  A closure that
+        replaces ``.grad`` (``zero_grad(set_to_none=True)`` + ``backward()``) simply takes the copy path."""
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is None and p.is_contiguous():
+                p.grad = self._flat_g[off:off + n].view_as(p)
+            off += n
+
     def _gather_flat_grad(self):
         off = 0
+        esz = self._flat_g.element_size()
+        base = self._flat_g.data_ptr()
         for p in self._params:
             n = p.numel()
             if p.grad is None:
                 self._flat_g[off:off + n].zero_()
-            else:
+            elif not (p.grad.data_ptr() == base + off * esz and p.grad.is_contiguous() and p.grad.dtype == self._flat_g.dtype):
                 self._flat_g[off:off + n].copy_(p.grad.reshape(-1))
             off += n
 
@@ -279,6 +293,7 @@ class FusedLBFGS(torch.optim.Optimizer):
         state = self.state[self._params[0]]
         state.setdefault("func_evals", 0)
         state.setdefault("n_iter", 0)
+        self._adopt_grads()
         # snapshot: a closure may hand back a static tensor that later calls overwrite (EnergyLoss2D.value_and_grad_
         # does); torch.optim.LBFGS.step returns the loss of the FIRST evaluation (torch/optim/lbfgs.py), so must we
         orig_loss = closure().detach().clone()

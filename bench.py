@@ -537,8 +537,7 @@ def main():
         ok = torch.tensor([1.0 if (st[0] == 0 and l_got == l_ref) else 0.0], dtype=f64, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() != 1.0:
-            sh_.peer.close()
-            sh_.peer = None
+            sh_.close_peer_exchange()
             raise RuntimeError(f"{tag}: peer-window exchange disagrees with the collective path on some rank "
                                f"(this rank: status {st}, energy {l_got!r} vs {l_ref!r})")
 
@@ -574,9 +573,7 @@ def main():
             peer_legs = None
             peer_state = f"unavailable: {type(e).__name__}: {str(e)[:200]}"
             note("peer-window exchange " + peer_state)
-            if sh.peer is not None:
-                sh.peer.close()
-                sh.peer = None
+            sh.close_peer_exchange()
         peer_on[0] = False
 
     # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
@@ -631,8 +628,7 @@ def main():
                 res["peer_exchange"]["status"] = sh_s.peer.status()[0]
             except Exception as e:  # noqa: BLE001
                 note(f"peer-window exchange on {name[:12]}: {type(e).__name__}: {str(e)[:160]}")
-            if sh_s.peer is not None:
-                sh_s.peer.close()
+            sh_s.close_peer_exchange()
             peer_on[0] = False
         del sh_s, m_s, ko
         return res
@@ -1004,7 +1000,7 @@ def main():
                                           train_step_fused=us(sh_.owner_train_step_fused),
                                           train_step_fused_overlap=us(sh_.owner_train_step_fused_overlapped, sh_.finish_overlapped))
             shard1["peer_windows"]["status"] = sh_.peer.status()[0]
-            sh_.peer.close()
+            sh_.close_peer_exchange()
             del sh_, m_
         except Exception as e:  # noqa: BLE001
             note(f"sharded_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")

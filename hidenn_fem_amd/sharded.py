@@ -336,6 +336,16 @@ class ShardedTri3Energy:
             self._wait_range = None
         return self
 
+    def close_peer_exchange(self):
+        """Back to the collective path: detach the in-launch get from the plan (it holds a pointer into the windows' device
+        memory), then free / unmap the windows.  Collective in effect: every rank must have finished its last get."""
+        if self.peer is None:
+            return
+        if self.inkernel_get:
+            _lib.check(_lib.lib().hfem_plan_set_peer_get(self.plan.handle, None, 0, 0), "hfem_plan_set_peer_get")
+        self.peer.close()
+        self.peer, self.inkernel_get, self._wait_range, self._step_cache = None, False, None, None
+
     def _bind_peer_get(self):
         """(Re)bind the in-launch get to the plan with the rank's CURRENT boundary range [lo, mid)."""
         if self._wait_range != (self.lo, self.mid):

@@ -108,7 +108,7 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
         assert _close(got.loss_global.item(), l_more[-1]), name
         for a, b in zip(got.model.parameters(), ref.model.parameters()):
             assert _close(a.detach(), b.detach()), name + " (captured)"
-        got.peer.close()
+        got.close_peer_exchange()
     # the overlapped steps with the get as a launch of its own (what plans without paired slots use)
     for name, fused, over in STEPS:
         if not over:
@@ -119,7 +119,7 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
         for a, b in zip(got.model.parameters(), ref.model.parameters()):
             assert _close(a.detach(), b.detach()), name
         assert got.peer.status() == (0, n)
-        got.peer.close()
+        got.close_peer_exchange()
     # evaluation-only steps
     ref = _trainer(d, False, comm=comm, split=third)
     got = _trainer(d, True, split=third)
@@ -174,7 +174,7 @@ def _worker_two_ranks(rank, world, port, q):
                       and _close(got.model.u_free[seen_u].detach(), ref.model.u_free[seen_u].detach()))
             report[name] = (bool(same), bool(same_g), st, got.peer.status(), l_got)
             dist.barrier()
-            got.peer.close()
+            got.close_peer_exchange()
         # the bounded wait: only rank 0 puts; its get gives up after 0.3 s with the sticky status bit
         lone = _trainer(d, True, timeout_s=0.3)
         if rank == 0:
@@ -188,7 +188,7 @@ def _worker_two_ranks(rank, world, port, q):
                 raised = True
             report["timeout"] = (st, raised)
         dist.barrier()
-        lone.peer.close()
+        lone.close_peer_exchange()
         q.put((rank, report))
     finally:
         dist.destroy_process_group()

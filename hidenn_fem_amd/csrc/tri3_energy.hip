@@ -1192,7 +1192,8 @@ extern "C" int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t 
     HFEM_ARG_CHECK(peer->device == plan->device, "plan and peer windows live on different devices");
     const int32_t nt = (int32_t)plan->host.tiles.size();
     HFEM_ARG_CHECK(wait_begin >= 0 && wait_begin <= wait_end && wait_end <= nt, "bad tile range");
-    HFEM_ARG_CHECK(plan->host.paired, "the in-launch get is implemented by the paired-slot kernel only");
+    HFEM_ARG_CHECK(plan->host.paired && plan->host.n_chained == 0,
+                   "the in-launch get is implemented by the paired-slot kernel's plain slot loop only (no chained records)");
     plan->peer_get = peer->get_dev; plan->peer_wait_begin = wait_begin; plan->peer_wait_end = wait_end;
     return 0;
 }

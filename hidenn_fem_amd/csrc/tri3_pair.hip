@@ -29,7 +29,7 @@ namespace hfem {
 // float2 for fp32 models: widened on load, rounded once on store, fp64 arithmetic); ADAM: the write-out applies
 // torch.optim.Adam's update instead of storing the gradient (AdamFuse, hfem_tri3_energy_adam_step).
 template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
-          bool ADAM = false, bool CHAIN = false, int CAPN = 0, int SP = 16>
+          bool ADAM = false, bool CHAIN = false, int CAPN = 0, int SP = 16, bool PG = false>
 __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
     const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
@@ -46,8 +46,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     double *red = acc3 + cap_owned;
 
     const int tid = threadIdx.x;
+    // PG instances (HFEM_FLAG_PEER_GET launches only -- every other launch runs the PG = false code, which knows nothing of
+    // this): the first lag.pg_blocks workgroups are the peer-window get (peer.hip)
     int bid = (int)blockIdx.x;
-    if (lag.pg_blocks) {                                // HFEM_FLAG_PEER_GET: the first workgroups are the peer-window get (peer.hip)
+    if constexpr (PG) {
         if (bid < lag.pg_blocks) {
             if constexpr (std::is_same<V2, double2>::value)
                 peer_get_block(*lag.pg, bid, lag.pg_blocks, const_cast<double2 *>(x_free), const_cast<double2 *>(u_free));
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         }
         bid -= lag.pg_blocks;                           // a multiple of 8: the block -> XCD mapping of the tiles is unchanged
     }
-    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0) - lag.pg_blocks;
+    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0) - (PG ? lag.pg_blocks : 0);
     if (lag.prev && bid == n_launch) {                  // HFEM_FLAG_SUM_PREVIOUS: reduce the previous launch's tile energies
         double v = 0.0;
         if (tid < 256)
@@ -85,9 +87,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         w0[j] = pd.elem_pack[i];
         w1[j] = pd.elem_pack_hi[i];
     }
-    if (lag.pg_blocks && tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end)
-        peer_wait_unpacked(*lag.pg);                    // a boundary tile: the rows it reads from other ranks are being copied in
-                                                        // (its row maps and slot records are already on their way)
+    if constexpr (PG) {
+        if (tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end)
+            peer_wait_unpacked(*lag.pg);                // a boundary tile: the rows it reads from other ranks are being copied in
+    }                                                   // (its row maps and slot records are already on their way)
     // ---- gather through the row maps: issued before anything that needs the descriptor (program order = vmcnt order)
     V2 vx[NPT], vu[NPT];
 #pragma unroll
@@ -286,6 +289,15 @@ template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2
 static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
     constexpr int CAPN = CAPO > 0 ? kPairCapN : 0;
     const size_t lds = CAPO > 0 ? (size_t)(CAPN * 32 + CAPO * 32 + 128) : A.lds;
+    if constexpr (std::is_same<V2, double2>::value && !HASB && !PHYS && !CHAIN) {
+        if (lag.pg_blocks) {                               // HFEM_FLAG_PEER_GET: the instance with the in-launch get
+            hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN, SP, true>), dim3(A.grid), dim3(BLK), lds, A.s,
+                               A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
+                               (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
+                               CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride);
+            return;
+        }
+    }
     hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN, SP>), dim3(A.grid), dim3(BLK), lds, A.s,
                        A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
                        (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
@@ -369,7 +381,7 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
 #undef HFEM_PAIR_NT
     if (mode == 0) {
         const int sp = plan->tune.store_policy;
-        if (cc && npt == 3 && ept <= 3 && sp != 16 && !A.chain) {        // "store_policy" A/B instances of the default tile shape
+        if (cc && npt == 3 && ept <= 3 && sp != 16 && !A.chain && !lag.pg_blocks) {   // "store_policy" A/B instances of the default tile shape
             const size_t lds = (size_t)(kPairCapN * 32 + kPairCapO * 32 + 128);
 #define HFEM_PAIR_SP(SPV)                                                                                                  \
     hipLaunchKernelGGL((tri3_energy_pair_kernel<256, 3, 3, 4, 560, false, false, double2, false, false, kPairCapN, SPV>),  \

@@ -327,13 +327,17 @@ class ShardedTri3Energy:
         # its first workgroups wait for the flags and unpack, the boundary tiles wait for them in the kernel, the rest runs
         self.inkernel_get = bool(inkernel_get if inkernel_get is not None else self.plan.is_paired())
         if self.inkernel_get:
-            if not self.plan.is_paired():
-                raise RuntimeError("inkernel_get needs a paired-slot plan")
             _lib.check(_lib.lib().hfem_peer_attach_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
                                                        self._need_n[0], self._need_n[1], self.iface_rows,
                                                        self._loss_slots[0].data_ptr(), self.peer.timeout_ticks),
                        "hfem_peer_attach_get")
             self._wait_range = None
+            try:
+                self._bind_peer_get()                  # refuses plans whose kernel has no in-launch get (unpaired / chained records)
+            except RuntimeError:
+                if inkernel_get:
+                    raise
+                self.inkernel_get = False              # default: fall back to the get as a launch of its own
         return self
 
     def close_peer_exchange(self):

@@ -33,7 +33,7 @@ if os.path.exists(os.path.join(src, "kernel_stats_replayed.csv")):
         k = max(sc1 or rows, key=lambda x: float(x["TotalDurationNs"]))
         avg = float(k["AverageNs"]) * 1e-3
         out["regimes"][r] = {"kernel": k["Name"][:90], "calls": int(k["Calls"]), "avg_us": avg, "min_us": float(k["MinNs"]) * 1e-3,
-                             "frac_of_8TBs": ALG / avg * 1e-6 / 8000.0}
+                             "frac_of_8TBs": ALG / (avg * 1e-6) / 1e9 / 8000.0}
         shutil.copy(os.path.join(src, f"kernel_stats_{r}.csv"), os.path.join(dst, f"kernel_stats_{r}.csv"))
     for f in ("kernel_stats_bench_py.csv", "bench_under_rocprof.json"):
         if os.path.exists(os.path.join(src, f)):

@@ -101,16 +101,37 @@ class PeerWindows:
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.timeout_ticks = int(timeout_s * 1e8)                   # s_memrealtime runs at 100 MHz
         self._h = C.c_void_p()
-        _lib.check(L.hfem_peer_create(_lib.dev_index(device), self.rank, self.world, int(stride), C.byref(self._h)),
-                   "hfem_peer_create")
+        # every step of the set-up is agreed on by ALL ranks (a rank that failed alone would leave the others in a barrier)
+        err = None
+        try:
+            _lib.check(L.hfem_peer_create(_lib.dev_index(device), self.rank, self.world, int(stride), C.byref(self._h)),
+                       "hfem_peer_create")
+        except Exception as e:  # noqa: BLE001
+            err = e
         if self.world > 1:
             mine = (C.c_char * 64)()
-            _lib.check(L.hfem_peer_ipc_handle(self._h, mine), "hfem_peer_ipc_handle")
+            if err is None:
+                try:
+                    _lib.check(L.hfem_peer_ipc_handle(self._h, mine), "hfem_peer_ipc_handle")
+                except Exception as e:  # noqa: BLE001
+                    err = e
             box = [None] * self.world
-            dist.all_gather_object(box, bytes(mine.raw), group=group)
-            allh = (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(box))
-            _lib.check(L.hfem_peer_connect(self._h, allh), "hfem_peer_connect")
-            dist.barrier(group=group)                               # every window is mapped everywhere before the first put
+            dist.all_gather_object(box, (err is None, bytes(mine.raw)), group=group)
+            if err is None and all(ok for ok, _ in box):
+                try:
+                    allh = (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(h for _, h in box))
+                    _lib.check(L.hfem_peer_connect(self._h, allh), "hfem_peer_connect")
+                except Exception as e:  # noqa: BLE001
+                    err = e
+            elif err is None:
+                err = RuntimeError("peer windows: set-up failed on rank(s) " + str([r for r, (ok, _) in enumerate(box) if not ok]))
+            box2 = [None] * self.world
+            dist.all_gather_object(box2, err is None, group=group)   # also the barrier: every window is mapped everywhere
+            if err is None and not all(box2):
+                err = RuntimeError("peer windows: mapping the windows failed on rank(s) " + str([r for r, ok in enumerate(box2) if not ok]))
+        if err is not None:
+            self.close()
+            raise RuntimeError(f"peer windows unavailable: {err}")
 
     @property
     def handle(self):

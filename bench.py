@@ -432,6 +432,13 @@ def main():
                 comm = None
                 comm_state = f"torch.distributed nccl (in-library RCCL communicator unavailable: {type(e).__name__}: {str(e)[:120]})"
                 note(comm_state)
+            agreed = torch.tensor([1.0 if comm is not None else 0.0], dtype=f64, device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)      # one verdict for all ranks: a mixed set of transports would hang
+            if agreed.item() != 1.0 and comm is not None:
+                comm.close()
+                comm = None
+                comm_state = "torch.distributed nccl (in-library RCCL communicator failed its check on another rank)"
+                note(comm_state)
     sh = ShardedTri3Energy(model, loss_fn, comm=comm)
     plan = sh.plan
     lo, hi = sh.lo, sh.hi

@@ -25,9 +25,11 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--boundary", type=float, default=0.05)
     ap.add_argument("--legs", default="collective,peer")
+    ap.add_argument("--grid", default="1001x501", help="nodes: NX x NY (2001x1001 = 4 x 10^6 elements: launches of several rounds)")
     a = ap.parse_args()
     dev, f64 = torch.device("cuda:0"), torch.float64
-    coords, conn, geom, bc, mn, edges = structured_tri_mesh(1001, 501, length=2.0, height=1.0, jitter=0.2, seed=0, dtype=f64)
+    gx_, gy_ = (int(v) for v in a.grid.split("x"))
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(gx_, gy_, length=2.0, height=1.0, jitter=0.2, seed=0, dtype=f64)
     torch.manual_seed(0)
     m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(dev)
     sh = ShardedTri3Energy(m, EnergyLoss2D(device=dev, dtype=f64))
@@ -69,7 +71,7 @@ def main():
                     train_step_overlap=us(sh.owner_train_step_overlapped, sh.finish_overlapped),
                     train_step_fused=us(sh.owner_train_step_fused),
                     train_step_fused_overlap=us(sh.owner_train_step_fused_overlapped, sh.finish_overlapped))
-    out = dict(K=K, boundary_tiles=sh.mid - sh.lo, tiles=sh.hi - sh.lo)
+    out = dict(grid=a.grid, K=K, boundary_tiles=sh.mid - sh.lo, tiles=sh.hi - sh.lo)
     if "collective" in a.legs:
         out["collective_path"] = legs()
     if "peer" in a.legs:

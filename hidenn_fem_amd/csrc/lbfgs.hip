@@ -192,38 +192,55 @@ __global__ __launch_bounds__(kLb) void pair_reduce_kernel(LbfgsArrays A, int nb,
 // by two; the partials buffer in LDS alternates so that one barrier per slot is enough).  10^6-element mesh (2 x 10^6 fp64
 // parameters), 100 pairs, 3.2 GB per pass: 936 -> 598 us (5.35 TB/s); 4 or 2 elements per thread are slower (1.39 / 1.86 ms per
 // L-BFGS iteration against 1.35).
-template <typename T, int PER>
+// VEC consecutive elements per load (fp32 histories: 2 -> 8-byte loads like the fp64 ones, needs an even n); a thread owns
+// PER loads = PER * VEC elements of the chunk.
+template <typename T, int VEC>
+__device__ __forceinline__ void lb_load(const T *__restrict__ p, int64_t i, int64_t n, T *out) {
+    if constexpr (VEC == 2) {
+        if (i < n) {                                           // n even, i even: the pair is inside and 2 sizeof(T)-aligned
+            typedef T pair_t __attribute__((ext_vector_type(2)));
+            const pair_t v = *reinterpret_cast<const pair_t *>(p + i);
+            out[0] = v.x; out[1] = v.y;
+        } else { out[0] = (T)0; out[1] = (T)0; }
+    } else {
+        out[0] = i < n ? p[i] : (T)0;
+    }
+}
+
+template <typename T, int PER, int VEC = 1>
 __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
                                                        const T *__restrict__ Yring, int64_t n, int M1) {
+    constexpr int E = PER * VEC;                            // elements per thread
     __shared__ double red[2][5][kLb / 64];
     const LbfgsState &S = *A.st;
     const int count = S.count, head = S.head, ns = S.new_slot;
-    const int64_t base = (int64_t)blockIdx.x * (kLb * PER) + threadIdx.x;
-    double gv[PER], sv[PER], yv[PER];
+    const int64_t base = (int64_t)blockIdx.x * (kLb * E) + (int64_t)threadIdx.x * VEC;
+    T gv[E], sv[E], yv[E];                                  // in the vectors' own type (fp32 histories: half the registers)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int64_t i = base + (int64_t)k * kLb;
-        gv[k] = i < n ? (double)g[i] : 0.0;
-        sv[k] = (ns >= 0 && i < n) ? (double)Sring[(int64_t)ns * n + i] : 0.0;
-        yv[k] = (ns >= 0 && i < n) ? (double)Yring[(int64_t)ns * n + i] : 0.0;
+        const int64_t i = base + (int64_t)k * kLb * VEC;
+        lb_load<T, VEC>(g, i, n, gv + k * VEC);
+        lb_load<T, VEC>(Sring + (int64_t)(ns >= 0 ? ns : 0) * n, ns >= 0 ? i : n, n, sv + k * VEC);
+        lb_load<T, VEC>(Yring + (int64_t)(ns >= 0 ? ns : 0) * n, ns >= 0 ? i : n, n, yv + k * VEC);
     }
-    auto load = [&](int l, T (&y)[PER], T (&s)[PER]) {
+    auto load = [&](int l, T (&y)[E], T (&s)[E]) {
         const int slot = (head + l) % M1;
         const T *Yj = Yring + (int64_t)slot * n, *Sj = Sring + (int64_t)slot * n;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int64_t i = base + (int64_t)k * kLb;
-            y[k] = i < n ? Yj[i] : (T)0;
-            s[k] = i < n ? Sj[i] : (T)0;
+            const int64_t i = base + (int64_t)k * kLb * VEC;
+            lb_load<T, VEC>(Yj, i, n, y + k * VEC);
+            lb_load<T, VEC>(Sj, i, n, s + k * VEC);
         }
     };
-    auto reduce_store = [&](int l, const T (&yr)[PER], const T (&sr)[PER], int buf) {
+    auto reduce_store = [&](int l, const T (&yr)[E], const T (&sr)[E], int buf) {
         double acc[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {                      // out-of-range lanes hold zeros: same sums as a guarded loop
+        for (int k = 0; k < E; ++k) {                        // out-of-range lanes hold zeros: same sums as a guarded loop
             const double y = (double)yr[k], s = (double)sr[k];
-            acc[0] += y * gv[k]; acc[1] += s * gv[k];
-            acc[2] += y * sv[k]; acc[3] += y * yv[k]; acc[4] += s * yv[k];
+            const double gk = (double)gv[k], sk = (double)sv[k], yk = (double)yv[k];
+            acc[0] += y * gk; acc[1] += s * gk;
+            acc[2] += y * sk; acc[3] += y * yk; acc[4] += s * yk;
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *_
     // gridDim.y workgroups share a chunk and take the slots l = blockIdx.y, + gridDim.y, ...: short vectors (few
     // chunks) still fill the chip; each (chunk, slot) partial is produced by exactly one workgroup, in the same order
     const int gy = gridDim.y;
-    T ya[PER], sa[PER], yb[PER], sb[PER];
+    T ya[E], sa[E], yb[E], sb[E];
     int l = blockIdx.y;
     if (l < count) load(l, ya, sa);
     for (; l < count; l += 2 * gy) {
@@ -567,6 +584,9 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     const size_t esz = dtype == 0 ? 8 : 4, M1 = (size_t)o->M1;
     o->nb_chunk = (int)((n + kLbChunk - 1) / kLbChunk);
     o->nb_stream = (int)std::min<int64_t>((n + kLb - 1) / kLb, 2048);
+    // fp32 histories of long vectors: 16 elements per thread as 8 pair loads (the bytes in flight per thread of the fp64 pass;
+    // 0.87 -> 0.79 ms per iteration on 2 x 10^6 parameters with 100 pairs; 8 elements as 4 pair loads: no gain)
+    if (dtype == 1 && n % 2 == 0 && n >= (1 << 20)) o->per = 16;
     o->nb_md = (int)((n + (int64_t)kLb * o->per - 1) / ((int64_t)kLb * o->per));
     int rc = 0;
     char *ring = nullptr;
@@ -621,23 +641,31 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
     if (!first) {
         int gy = 2048 / o->nb_chunk;                      // slot classes: fill the chip when the vectors are short
         gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
-#define HFEM_MD(T, P) hipLaunchKernelGGL((multidot_kernel<T, P>), dim3(o->nb_md, gy), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, o->n, M1)
-        if (o->dtype == 0) HFEM_MD(double, kLbPer);
-        else HFEM_MD(float, kLbPer);
+#define HFEM_MD(T, P, V) hipLaunchKernelGGL((multidot_kernel<T, P, V>), dim3(o->nb_md, gy), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, o->n, M1)
+        if (o->dtype == 0) HFEM_MD(double, kLbPer, 1);
+        else if (o->per == 16) HFEM_MD(float, 8, 2);
+        else HFEM_MD(float, kLbPer, 1);
 #undef HFEM_MD
         hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_md, M1);
     }
     if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
     else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
-    const bool fine = o->nb_chunk < 1024;                 // short vectors: one element per thread, 8x the workgroups
-    const int nb_dir = fine ? (int)((o->n + kLb - 1) / kLb) : o->nb_chunk;
+    // elements per thread of the direction pass: 8 for very long vectors (fewer, fatter workgroups), 1 for short ones (more
+    // workgroups), in between 2 (fp64) / 4 (fp32) -- measured on 2 x 10^6 parameters with 100 pairs: fp64 1.29 -> 1.26 ms, fp32
+    // 0.79 -> 0.77 ms per iteration; 8 x 10^6 parameters: 8 is best (2.08 against 2.13 / 2.17 ms with 2 / 1)
+    const int per_dir = o->nb_chunk >= 1024 ? kLbPer : (o->n >= (1 << 20) ? (o->dtype == 0 ? 2 : 4) : 1);
+    const int nb_dir = (int)((o->n + (int64_t)per_dir * kLb - 1) / ((int64_t)per_dir * kLb));
+#define HFEM_DIR(T, P) hipLaunchKernelGGL((direction_kernel<T, P>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, (T *)o->d, o->n, M1)
     if (o->dtype == 0) {
-        if (fine) hipLaunchKernelGGL((direction_kernel<double, 1>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, (double *)o->d, o->n, M1);
-        else hipLaunchKernelGGL((direction_kernel<double, kLbPer>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->Sring, (const double *)o->Yring, (double *)o->d, o->n, M1);
+        if (per_dir == kLbPer) HFEM_DIR(double, kLbPer);
+        else if (per_dir == 2) HFEM_DIR(double, 2);
+        else HFEM_DIR(double, 1);
     } else {
-        if (fine) hipLaunchKernelGGL((direction_kernel<float, 1>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, (float *)o->d, o->n, M1);
-        else hipLaunchKernelGGL((direction_kernel<float, kLbPer>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->Sring, (const float *)o->Yring, (float *)o->d, o->n, M1);
+        if (per_dir == kLbPer) HFEM_DIR(float, kLbPer);
+        else if (per_dir == 4) HFEM_DIR(float, 4);
+        else HFEM_DIR(float, 1);
     }
+#undef HFEM_DIR
     hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, nb_dir);
     o->first = false;
     return launch_status("hfem_lbfgs_direction");

@@ -878,7 +878,7 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
                                          void *stream) {
     HFEM_ARG_CHECK(plan && mat && loss_out, "null pointer");
     HFEM_ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = fp64 rows, 1 = fp32 rows");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_SUM_PREVIOUS | HFEM_FLAG_SAME_BANK)), "QUAD4 extension: inline or deferred loss sum only");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_SUM_PREVIOUS | HFEM_FLAG_SAME_BANK | HFEM_FLAG_PEER_GET)), "QUAD4 extension: inline or deferred loss sum only, no in-launch get");
     Quad4Body body;
     bool hasb = false;
     for (int q = 0; q < 4; ++q) {

@@ -948,8 +948,8 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS)),
-                   "fp32-storage path: reference convention, atomic accumulation, no lagged loss sum");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS | HFEM_FLAG_PEER_GET)),
+                   "fp32-storage path: reference convention, atomic accumulation, no lagged loss sum, no in-launch get");
     const HostPlan &h = plan->host;
     const int32_t nt = (int32_t)h.tiles.size();
     if (tile_end < 0) tile_end = nt;

@@ -846,7 +846,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         // fixed-order node-centric path (tri3_det.hip); also carries the physical convention for plan shapes the
         // tiled PHYS instance does not hold
         HFEM_ARG_CHECK(tile_begin == 0 && tile_end == nt, "HFEM_FLAG_DETERMINISTIC / physical fallback: whole plan only");
-        HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_LOSS_SUM | HFEM_FLAG_SUM_PREVIOUS)), "HFEM_FLAG_DETERMINISTIC always delivers the loss");
+        HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_LOSS_SUM | HFEM_FLAG_SUM_PREVIOUS | HFEM_FLAG_PEER_GET)), "HFEM_FLAG_DETERMINISTIC always delivers the loss and has no in-launch get");
         return launch_tri3_det(plan, x_free, x_fixed, u_free, u_fixed, make_consts(mat, W, Bk), T_edge, tc, loss_out,
                                (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free, (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free,
                                (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0, phys, s);

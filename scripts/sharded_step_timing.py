@@ -67,7 +67,8 @@ def main():
         return round(sorted(ts)[2], 3)
 
     def legs():
-        return dict(eval_exchange=us(sh.owner_step), train_step=us(sh.owner_train_step),
+        return dict(eval_exchange=us(sh.owner_step), eval_exchange_overlap=us(sh.owner_step_overlapped, sh.finish_overlapped),
+                    train_step=us(sh.owner_train_step),
                     train_step_overlap=us(sh.owner_train_step_overlapped, sh.finish_overlapped),
                     train_step_fused=us(sh.owner_train_step_fused),
                     train_step_fused_overlap=us(sh.owner_train_step_fused_overlapped, sh.finish_overlapped))

@@ -130,6 +130,17 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
         got.owner_step_overlapped()
     assert got.finish_overlapped().item() == l0.item()          # the energy itself is summed in a fixed order
     assert got.peer.status() == (0, 4) and int(got._adam["step"].item()) == 0
+    # life cycle: back to the collective path (the plan lets go of the windows), on again with fresh windows
+    got.close_peer_exchange()
+    assert got.peer is None and not got.inkernel_get
+    l2 = got.owner_step()[0].item()
+    assert l2 == l0.item()
+    got.enable_peer_exchange()
+    assert got.peer.status() == (0, 0)
+    for _ in range(2):
+        got.owner_step_overlapped()
+    assert got.finish_overlapped().item() == l0.item() and got.peer.status() == (0, 2)
+    got.close_peer_exchange()
     comm.close()
 
 

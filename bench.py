@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra / train_step_1gpu / strong_scaling_emulated")
     ap.add_argument("--no-regimes", action="store_true", help="skip the cache-regime legs (roofline = the replayed leg)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip config.strong_scaling")
+    ap.add_argument("--strong-cfg5u", action="store_true", help="N > 1: run the 4.1 M-element Delaunay strong-scaling leg at any N "
+                    "(default: from N = 8; ~2 min of host-side meshing and planning per rank)")
     ap.add_argument("--time-budget", type=float, default=600.0, help="seconds: optional N > 1 legs (the 4.1 M-element strong-scaling "
                     "mesh: ~2 min of host-side meshing and planning per rank) are skipped, with a note, when the run is already "
                     "past half of it")
@@ -644,9 +646,9 @@ def main():
         strong = [strong_leg("T1M FIXED (BASELINE configs[3] as stated): 10^6 TRI3 sharded over the ranks", t1m_mesh(1))]
         spent = torch.tensor([time.perf_counter() - t_start], dtype=f64, device=dev)
         dist.all_reduce(spent, op=dist.ReduceOp.MAX)          # one decision for all ranks (the legs contain collectives)
-        if world >= 8 and spent.item() > 0.5 * a.time_budget:
+        if (world >= 8 or a.strong_cfg5u) and spent.item() > 0.5 * a.time_budget:
             note(f"strong_scaling: cfg5u leg skipped ({spent.item():.0f} s of the {a.time_budget:.0f} s --time-budget already spent)")
-        elif world >= 8:
+        elif world >= 8 or a.strong_cfg5u:
             from hidenn_fem_amd.mesh import unstructured_tri_mesh
             strong.append(strong_leg("cfg5u FIXED (BASELINE configs[4]): ~4.1 x 10^6 TRI3 Delaunay mesh sharded over the ranks",
                                      unstructured_tri_mesh(2_050_000, seed=2, dtype=f64)))

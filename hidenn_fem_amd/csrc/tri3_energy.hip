@@ -18,6 +18,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 
 #include "hfem_device.h"
 #include "hfem_plan_dev.h"
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 // address is then ONE scaled local id plus an immediate offset instead of a runtime base add per array.
 // ADAM: the write-out applies the Adam update instead of storing the gradient (struct AdamFuse below).
 template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2, int CAPN = 0,
-          int CAPO = 0, bool ADAM = false, bool PHYS = false>
+          int CAPO = 0, bool ADAM = false, bool PHYS = false, bool PG = false>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
     PlanDev pd, int tile_begin, const V2 *__restrict__ x_free,
     const V2 *__restrict__ x_fixed, const V2 *__restrict__ u_free,
@@ -255,8 +256,19 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     double *red = acc3 + cap_owned;
 
     const int tid = threadIdx.x;
-    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0);
-    if (lag.prev && (int)blockIdx.x == n_launch) {
+    // PG instances (HFEM_FLAG_PEER_GET launches only): the first lag.pg_blocks workgroups are the peer-window get (peer.hip,
+    // as in tri3_pair.hip); every other launch runs the PG = false code
+    int bid = (int)blockIdx.x;
+    if constexpr (PG) {
+        if (bid < lag.pg_blocks) {
+            if constexpr (std::is_same<V2, double2>::value)
+                peer_get_block(*lag.pg, bid, lag.pg_blocks, const_cast<double2 *>(x_free), const_cast<double2 *>(u_free));
+            return;
+        }
+        bid -= lag.pg_blocks;
+    }
+    const int n_launch = (int)gridDim.x - (lag.prev ? 1 : 0) - (PG ? lag.pg_blocks : 0);
+    if (lag.prev && bid == n_launch) {
         // The launch's one extra workgroup: sum the tile energies the PREVIOUS launch left (other partials bank) --
         // the 1-block reduction and the kernel boundary in front of it leave the critical path.  Same order as
         // sum_partials_kernel (256 adders, shuffle tree, wave sums in wave order): bit-identical result.
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
         if (tid == 0) lag.out[0] = tot;
         return;
     }
-    const int slot = xcd_tile(blockIdx.x, n_launch);
+    const int slot = xcd_tile(bid, n_launch);
     HFEM_LAB_FAST_STAGGER(stagger_ticks, stagger_cfg)
     // ---- row maps and element records from the tile index alone (uniform node / slot strides, plan.cpp), in flight together
     //      with the descriptor; unguarded loads (padding = valid rows / skip records), then the gather, all issued back to back.
@@ -286,6 +298,10 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
         if (tid + j * BLOCK >= d.n_elem) pk[j] = kSkipBit;
+    if constexpr (PG) {
+        if (tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end)
+            peer_wait_unpacked(*lag.pg);                // a boundary tile: the rows it reads from other ranks are being copied in
+    }
     // ---- gather (unguarded loads: the compiler batches as many as the register budget of the instance allows) into LDS,
     //      clear the accumulators
 #pragma unroll
@@ -511,6 +527,15 @@ struct Tri3Launch {
 template <int BLK, int NPT, int EPT, bool HB, int SP, typename V2, int CO, bool ADAM, bool PHYS, bool STAMP = false>
 void launch_fast(const Tri3Launch &A, int grid, const AdamFuse &af, const LagSum &lag) {
     const size_t lds = CO > 0 ? (size_t)(A.max_nodes * 32 + CO * 32 + 128) : A.lds;
+    if constexpr (std::is_same<V2, double2>::value && !HB && !PHYS && !STAMP && BLK == 512 && (SP == 16 || SP == 2)) {
+        if (lag.pg_blocks) {                               // HFEM_FLAG_PEER_GET: the instance with the in-launch get
+            hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, STAMP, SP, V2, 0, CO, ADAM, PHYS, true>), dim3(grid), dim3(BLK),
+                               lds, A.s, A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
+                               (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
+                               CO > 0 ? CO : A.max_owned, A.skip_edges, A.stagger, A.stagger_cfg, A.stamps, af, lag);
+            return;
+        }
+    }
     hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, STAMP, SP, V2, 0, CO, ADAM, PHYS>), dim3(grid), dim3(BLK),
                        lds, A.s, A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
                        (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
@@ -531,7 +556,8 @@ void launch_generic(const Tri3Launch &A, int grid) {
 bool launch_fast_f64(const hfem_plan *plan, const Tri3Launch &A, int n, bool hasb, const LagSum &lag) {
     const HostPlan &h = plan->host;
     const int blk = plan->tune.tiled_block, sp = plan->tune.store_policy;
-    const int n_lag = n + (lag.prev ? 1 : 0);
+    const int n_lag = n + (lag.prev ? 1 : 0) + lag.pg_blocks;
+    if (lag.pg_blocks && !(blk == 512 && !hasb && (sp == 16 || sp == 2))) return false;   // no instance with the in-launch get
     // default shape (auto tile policy: <= 557 owned nodes): compile-time stride of the four accumulator arrays (12 of an
     // element's 18 LDS addresses); the footprint must stay <= 38 912 B (four workgroups per CU)
     if (plan->tune.fast_const_caps && blk == 512 && !hasb && (sp == 16 || sp == 2) && h.max_nodes > 512 && h.max_owned <= 560 &&
@@ -875,7 +901,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
     }
     if (flags & HFEM_FLAG_PEER_GET) {
         HFEM_ARG_CHECK(plan->peer_get, "HFEM_FLAG_PEER_GET: hfem_plan_set_peer_get has not been called");
-        HFEM_ARG_CHECK(h.paired && !hasb && !phys && n > 0, "HFEM_FLAG_PEER_GET: paired-slot plans, default forces and convention, a non-empty tile range");
+        HFEM_ARG_CHECK(!hasb && !phys && n > 0, "HFEM_FLAG_PEER_GET: default forces and convention, a non-empty tile range");
         lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
         lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
     }
@@ -912,6 +938,7 @@ extern "C" int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, cons
         if (!launched && plan->tune.tiled_fast) launched = launch_fast_f64(plan, A, n, hasb, lag);
         if (!launched) {
             HFEM_ARG_CHECK(!lag_consume, "HFEM_FLAG_SUM_PREVIOUS: this plan's tile shape has no register-prefetched instance");
+            HFEM_ARG_CHECK(!lag.pg_blocks, "HFEM_FLAG_PEER_GET: this plan's tile shape has no instance with the in-launch get");
             switch (plan->tune.tiled_block) {
                 case 512: launch_generic<512>(A, n); break;
                 case 1024: launch_generic<1024>(A, n); break;
@@ -1067,7 +1094,7 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
     }
     if (flags & HFEM_FLAG_PEER_GET) {
         HFEM_ARG_CHECK(plan->peer_get, "HFEM_FLAG_PEER_GET: hfem_plan_set_peer_get has not been called");
-        HFEM_ARG_CHECK(h.paired && dtype == 0 && n > 0, "HFEM_FLAG_PEER_GET: paired-slot plans, fp64 rows, a non-empty tile range");
+        HFEM_ARG_CHECK(dtype == 0 && !hasb && n > 0, "HFEM_FLAG_PEER_GET: fp64 rows, zero body force, a non-empty tile range");
         lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
         lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
     }
@@ -1192,8 +1219,11 @@ extern "C" int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t 
     HFEM_ARG_CHECK(peer->device == plan->device, "plan and peer windows live on different devices");
     const int32_t nt = (int32_t)plan->host.tiles.size();
     HFEM_ARG_CHECK(wait_begin >= 0 && wait_begin <= wait_end && wait_end <= nt, "bad tile range");
-    HFEM_ARG_CHECK(plan->host.paired && plan->host.n_chained == 0,
-                   "the in-launch get is implemented by the paired-slot kernel's plain slot loop only (no chained records)");
+    HFEM_ARG_CHECK(plan->host.paired ? plan->host.n_chained == 0
+                                     : (plan->tune.tiled_fast && plan->tune.tiled_block == 512 &&
+                                        (plan->tune.store_policy == 16 || plan->tune.store_policy == 2)),
+                   "the in-launch get needs the paired-slot kernel's plain slot loop (no chained records) or the 512-thread "
+                   "one-element-per-slot kernel with write-through / nt stores");
     plan->peer_get = peer->get_dev; plan->peer_wait_begin = wait_begin; plan->peer_wait_end = wait_end;
     return 0;
 }

@@ -338,7 +338,8 @@ class ShardedTri3Energy:
         ``*_overlapped`` steps keep their launch order (the flags arrive while the interior tiles run).  Collective over
         the group: call it on every rank, after ``setup_interfaces`` and before any graph capture.  ``inkernel_get`` (default:
         whenever the plan is a paired-slot one): the ``*_overlapped`` steps run the get as the first workgroups of their ONE
-        energy launch (``HFEM_FLAG_PEER_GET``) instead of a launch of its own."""
+        energy launch (``HFEM_FLAG_PEER_GET``) instead of a launch of its own (default: whenever the plan's kernel implements
+        it -- paired-slot plans without chained records, 512-thread one-element-per-slot plans)."""
         if not self._hip or self._unpack != self._unpack_hip:
             raise RuntimeError("enable_peer_exchange needs the HIP evaluator and the HIP pack / unpack")
         self.peer = PeerWindows(self.send.device, self.iface_stride, self.group, rank=self.rank, world=self.world,
@@ -346,7 +347,7 @@ class ShardedTri3Energy:
         self._step_cache = None
         # the get INSIDE the next energy launch (paired-slot plans): the overlapped steps then are one energy launch per step --
         # its first workgroups wait for the flags and unpack, the boundary tiles wait for them in the kernel, the rest runs
-        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else self.plan.is_paired())
+        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else True)   # the plan refuses if its kernel has none
         if self.inkernel_get:
             _lib.check(_lib.lib().hfem_peer_attach_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
                                                        self._need_n[0], self._need_n[1], self.iface_rows,

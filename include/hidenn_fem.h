@@ -149,7 +149,7 @@ int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t ca
                                    * reduction + kernel boundary leave the critical path.  hfem_plan_loss_sum
                                    * delivers the last one.  TRI3 default kernel path only.                    */
 
-#define HFEM_FLAG_PEER_GET 512  /* paired-slot plans, after hfem_plan_set_peer_get: the launch starts with 8 service workgroups that
+#define HFEM_FLAG_PEER_GET 512  /* paired-slot plans (no chained records) and 512-thread one-element-per-slot plans, after hfem_plan_set_peer_get: the launch starts with 8 service workgroups that
                                  * ARE the peer-window get (hfem_peer_iface_get's wait + unpack into this launch's x_free / u_free)
                                  * and the tiles named there (the rank's boundary tiles) wait for them inside the kernel        */
 #define HFEM_FLAG_SAME_BANK 256 /* with NO_LOSS_SUM: another tile range of the SAME evaluation as the previous NO_LOSS_SUM

@@ -32,10 +32,19 @@ def _model(d, nx=201, ny=151):
                                     neumann_edges=edges).to(d)
 
 
-def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0, inkernel=None):
+def _model_delaunay(d, n_nodes=40000):
+    from hidenn_fem_amd.mesh import unstructured_tri_mesh
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    coords, conn, geom, bc, mn, edges = unstructured_tri_mesh(n_nodes, seed=3, dtype=F64)
+    torch.manual_seed(4)
+    return PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                    neumann_edges=edges).to(d)
+
+
+def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0, inkernel=None, delaunay=False):
     from hidenn_fem_amd.loss import EnergyLoss2D
     from hidenn_fem_amd.sharded import ShardedTri3Energy
-    m = _model(d)
+    m = _model_delaunay(d) if delaunay else _model(d)
     sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm, group=group)
     sh.setup_interfaces()
     sh.init_owner_adam(LR_X, LR_U, fused=fused)
@@ -43,7 +52,7 @@ def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=
         sh.mid = split(sh)
     if peer:
         sh.enable_peer_exchange(timeout_s=timeout_s, inkernel_get=inkernel)
-        assert sh.inkernel_get == (sh.plan.is_paired() if inkernel is None else inkernel)
+        assert sh.inkernel_get == (True if inkernel is None else inkernel)      # these plans' kernels have the in-launch get
     return sh
 
 
@@ -115,6 +124,18 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
             continue
         ref = _trainer(d, False, comm=comm, fused=fused, split=third)
         got = _trainer(d, True, fused=fused, split=third, inkernel=False)
+        assert _close(_run(got, name, n, True), _run(ref, name, n, True)), name
+        for a, b in zip(got.model.parameters(), ref.model.parameters()):
+            assert _close(a.detach(), b.detach()), name
+        assert got.peer.status() == (0, n)
+        got.close_peer_exchange()
+    # a Delaunay mesh: its plan has one element per slot (no paired records) -- that kernel's in-launch get
+    for name, fused, over in STEPS:
+        if not over:
+            continue
+        ref = _trainer(d, False, comm=comm, fused=fused, split=third, delaunay=True)
+        got = _trainer(d, True, fused=fused, split=third, delaunay=True)
+        assert not got.plan.is_paired() and got.inkernel_get
         assert _close(_run(got, name, n, True), _run(ref, name, n, True)), name
         for a, b in zip(got.model.parameters(), ref.model.parameters()):
             assert _close(a.detach(), b.detach()), name

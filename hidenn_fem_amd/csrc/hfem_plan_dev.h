@@ -39,6 +39,14 @@ struct PeerGetDev {                  // device-resident arguments of the in-laun
     double *loss_out;
 };
 
+// parameter rows of either storage type in the exchange payload (always double2: float -> double -> float is lossless)
+template <typename V> __device__ __forceinline__ double2 row_widen(V v) { return make_double2((double)v.x, (double)v.y); }
+template <typename V> __device__ __forceinline__ V row_narrow(double2 v) {
+    V o;
+    o.x = (decltype(o.x))v.x; o.y = (decltype(o.y))v.y;
+    return o;
+}
+
 struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
     const double *prev = nullptr;    // partials bank the previous launch wrote (offset to its first tile)
     int prev_n = 0;
@@ -260,10 +268,10 @@ int launch_tri3_det(hfem_plan *plan, const double *x_free, const double *x_fixed
 void free_tri3_det(hfem_plan *plan);
 int det_prepare(hfem_plan *plan, hipStream_t s);   // adjacency of the fixed-order kernels (TRI3 and QUAD4), built on first use
 // exchange.hip: interface pack + tile-energy sum + step-counter bump in one launch (hfem_plan_iface_pack)
-int launch_iface_pack_sum(const double *x_free, const double *u_free, const int32_t *rows, int n_x, int n_u, double *out,
+int launch_iface_pack_sum(int dtype, const void *x_free, const void *u_free, const int32_t *rows, int n_x, int n_u, double *out,
                           int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
                           double beta2, double *bc_next, hipStream_t s);
-int launch_iface_put(const hfem_peer *peer, const double *x_free, const double *u_free, const int32_t *rows, int n_x,
+int launch_iface_put(const hfem_peer *peer, int dtype, const void *x_free, const void *u_free, const int32_t *rows, int n_x,
                      int n_u, int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
                      double beta2, double *bc_next, hipStream_t s);
 }  // namespace hfem

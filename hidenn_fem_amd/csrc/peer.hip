@@ -39,7 +39,8 @@ static int hip_fail(hipError_t e, const char *what) {
     return (int)e;
 }
 
-__global__ __launch_bounds__(256) void iface_put_kernel(const double2 *__restrict__ x_free, const double2 *__restrict__ u_free,
+template <typename V>
+__global__ __launch_bounds__(256) void iface_put_kernel(const V *__restrict__ x_free, const V *__restrict__ u_free,
                                                         const int32_t *__restrict__ rows, int n_x, int n_u, int64_t stride,
                                                         int64_t loss_slot, const double *__restrict__ partials,
                                                         int n_partials, int64_t *__restrict__ counter, double beta1,
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void iface_put_kernel(const double2 *__restric
     const size_t slot = kPeerData + ((size_t)par * pv.world + pv.rank) * (size_t)stride * sizeof(double2);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_x + n_u) {
-        const double2 v = i < n_x ? x_free[rows[i]] : u_free[rows[i]];
+        const double2 v = row_widen(i < n_x ? x_free[rows[i]] : u_free[rows[i]]);
         for (int p = 0; p < pv.world; ++p) ((double2 *)(pv.win[p] + slot))[i] = v;
     }
     if (blockIdx.x == 0) {          // the rank's energy: the same bits as sum_partials_kernel / iface_pack_sum_kernel
@@ -85,9 +86,10 @@ __global__ __launch_bounds__(256) void iface_put_kernel(const double2 *__restric
     }
 }
 
+template <typename V>
 __global__ __launch_bounds__(256) void iface_get_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
-                                                        int n_x, int n_u, double2 *__restrict__ x_free,
-                                                        double2 *__restrict__ u_free, int64_t stride, int64_t loss_slot,
+                                                        int n_x, int n_u, V *__restrict__ x_free,
+                                                        V *__restrict__ u_free, int64_t stride, int64_t loss_slot,
                                                         double *__restrict__ loss_out, int64_t timeout_ticks, PeerView pv) {
     char *self = pv.win[pv.rank];
     const uint64_t want = __hip_atomic_load((uint64_t *)pv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void iface_get_kernel(const int32_t *__restric
     __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // system scope: nothing of the window is served from a cache
     const double2 *recv = (const double2 *)(self + kPeerData + (size_t)par * pv.world * (size_t)stride * sizeof(double2));
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_x) x_free[dst[i]] = recv[src[i]];
-    else if (i < n_x + n_u) u_free[dst[i]] = recv[src[i]];
+    if (i < n_x) x_free[dst[i]] = row_narrow<V>(recv[src[i]]);
+    else if (i < n_x + n_u) u_free[dst[i]] = row_narrow<V>(recv[src[i]]);
     if (i == 0 && loss_out) {
         double tot = 0.0;
         for (int r = 0; r < pv.world; ++r) tot += recv[(int64_t)r * stride + loss_slot].x;   // rank order, as iface_unpack
@@ -119,13 +121,18 @@ __global__ __launch_bounds__(256) void iface_get_kernel(const int32_t *__restric
     }
 }
 
-int launch_iface_put(const hfem_peer *peer, const double *x_free, const double *u_free, const int32_t *rows, int n_x,
+int launch_iface_put(const hfem_peer *peer, int dtype, const void *x_free, const void *u_free, const int32_t *rows, int n_x,
                      int n_u, int64_t loss_slot, const double *partials, int n_partials, int64_t *counter, double beta1,
                      double beta2, double *bc_next, hipStream_t s) {
     const int n = n_x + n_u > 0 ? n_x + n_u : 1;
-    hipLaunchKernelGGL(iface_put_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double2 *)x_free,
-                       (const double2 *)u_free, rows, n_x, n_u, peer->stride, loss_slot, partials, n_partials, counter, beta1,
-                       beta2, bc_next, peer->view);
+    if (dtype == 0)
+        hipLaunchKernelGGL(iface_put_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, s, (const double2 *)x_free,
+                           (const double2 *)u_free, rows, n_x, n_u, peer->stride, loss_slot, partials, n_partials, counter,
+                           beta1, beta2, bc_next, peer->view);
+    else
+        hipLaunchKernelGGL(iface_put_kernel<float2>, dim3((n + 255) / 256), dim3(256), 0, s, (const float2 *)x_free,
+                           (const float2 *)u_free, rows, n_x, n_u, peer->stride, loss_slot, partials, n_partials, counter,
+                           beta1, beta2, bc_next, peer->view);
     return launch_status("hfem_plan_iface_put");
 }
 
@@ -252,16 +259,32 @@ extern "C" int hfem_peer_status(hfem_peer *peer, int32_t *status_out, int64_t *p
     return 0;
 }
 
-extern "C" int hfem_peer_iface_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
-                                   double *x_free, double *u_free, int64_t loss_slot, double *loss_out,
-                                   int64_t timeout_ticks, void *stream) {
+static int peer_iface_get_any(int dtype, hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
+                              void *x_free, void *u_free, int64_t loss_slot, double *loss_out, int64_t timeout_ticks,
+                              void *stream) {
     HFEM_ARG_CHECK(peer, "null pointer");
     HFEM_ARG_CHECK(peer->connected, "hfem_peer_connect has not been called");
     HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && loss_slot >= 0 && loss_slot < peer->stride && timeout_ticks > 0, "bad sizes");
     HFEM_ARG_CHECK((n_x + n_u == 0 || (src && dst)) && (n_x == 0 || x_free) && (n_u == 0 || u_free), "null pointer");
     if (int rc = use_device(peer->device)) return rc;
     const int n = n_x + n_u > 0 ? n_x + n_u : 1;
-    hipLaunchKernelGGL(iface_get_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, n_x, n_u,
-                       (double2 *)x_free, (double2 *)u_free, peer->stride, loss_slot, loss_out, timeout_ticks, peer->view);
+    if (dtype == 0)
+        hipLaunchKernelGGL(iface_get_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, n_x, n_u,
+                           (double2 *)x_free, (double2 *)u_free, peer->stride, loss_slot, loss_out, timeout_ticks, peer->view);
+    else
+        hipLaunchKernelGGL(iface_get_kernel<float2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, n_x, n_u,
+                           (float2 *)x_free, (float2 *)u_free, peer->stride, loss_slot, loss_out, timeout_ticks, peer->view);
     return launch_status("hfem_peer_iface_get");
+}
+
+extern "C" int hfem_peer_iface_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
+                                   double *x_free, double *u_free, int64_t loss_slot, double *loss_out,
+                                   int64_t timeout_ticks, void *stream) {
+    return peer_iface_get_any(0, peer, src, dst, n_x, n_u, x_free, u_free, loss_slot, loss_out, timeout_ticks, stream);
+}
+
+extern "C" int hfem_peer_iface_get_f32(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
+                                       float *x_free, float *u_free, int64_t loss_slot, double *loss_out,
+                                       int64_t timeout_ticks, void *stream) {
+    return peer_iface_get_any(1, peer, src, dst, n_x, n_u, x_free, u_free, loss_slot, loss_out, timeout_ticks, stream);
 }

@@ -1190,10 +1190,10 @@ extern "C" int hfem_plan_set_span_stamps(hfem_plan *plan, uint64_t *dev_buf, int
 // (the optimiser's step count: hfem_adam_step_rows2_dev reads it BEFORE this launch with step_offset = 1) and, when bc_next is
 // given too, write the bias-correction scalars {1 - beta1^(c + 1), sqrt(1 - beta2^(c + 1))} of the NEXT step (c = the bumped
 // count) there -- what the fused energy + Adam launch of that step reads (hfem_tri3_energy_adam_step_ex), so no hfem_adam_prep.
-extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
-                                    const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
-                                    int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
-                                    void *stream) {
+static int plan_iface_pack_any(int dtype, hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const void *x_free,
+                               const void *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
+                               int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                               void *stream) {
     HFEM_ARG_CHECK(plan && out, "null pointer");
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0 && loss_slot >= n_x + n_u, "bad sizes");
@@ -1203,9 +1203,26 @@ extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t
     HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
     if (int rc = use_device(plan->device)) return rc;
     PlanLock lock(plan);
-    return launch_iface_pack_sum(x_free, u_free, rows, n_x, n_u, out, loss_slot,
+    return launch_iface_pack_sum(dtype, x_free, u_free, rows, n_x, n_u, out, loss_slot,
                                  plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, counter,
                                  beta1, beta2, bc_next, (hipStream_t)stream);
+}
+
+extern "C" int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
+                                    const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
+                                    int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                                    void *stream) {
+    return plan_iface_pack_any(0, plan, tile_begin, tile_end, x_free, u_free, rows, n_x, n_u, out, loss_slot, counter, beta1, beta2,
+                               bc_next, stream);
+}
+
+// float rows (an fp32 model): widened into the double2 payload
+extern "C" int hfem_plan_iface_pack_f32(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const float *x_free,
+                                        const float *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
+                                        int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                                        void *stream) {
+    return plan_iface_pack_any(1, plan, tile_begin, tile_end, x_free, u_free, rows, n_x, n_u, out, loss_slot, counter, beta1, beta2,
+                               bc_next, stream);
 }
 
 // The in-launch get: launches of this plan with HFEM_FLAG_PEER_GET start with kPeerGetBlocks service workgroups that wait for
@@ -1230,10 +1247,9 @@ extern "C" int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t 
 
 // hfem_plan_iface_pack whose payload goes straight into every rank's receive window (csrc/peer.hip): pack + energy sum +
 // step count + the stores over xGMI + the arrival flags, one launch, no collective
-extern "C" int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end,
-                                   const double *x_free, const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u,
-                                   int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
-                                   void *stream) {
+static int plan_iface_put_any(int dtype, hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end,
+                              const void *x_free, const void *u_free, const int32_t *rows, int32_t n_x, int32_t n_u,
+                              int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next, void *stream) {
     HFEM_ARG_CHECK(plan && peer, "null pointer");
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(peer->connected, "hfem_peer_connect has not been called");
@@ -1245,9 +1261,25 @@ extern "C" int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t til
     HFEM_ARG_CHECK(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nt, "bad tile range");
     if (int rc = use_device(plan->device)) return rc;
     PlanLock lock(plan);
-    return launch_iface_put(peer, x_free, u_free, rows, n_x, n_u, loss_slot,
+    return launch_iface_put(peer, dtype, x_free, u_free, rows, n_x, n_u, loss_slot,
                             plan->d_partials + (size_t)plan->bank * nt + tile_begin, tile_end - tile_begin, counter, beta1,
                             beta2, bc_next, (hipStream_t)stream);
+}
+
+extern "C" int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end,
+                                   const double *x_free, const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u,
+                                   int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                                   void *stream) {
+    return plan_iface_put_any(0, plan, peer, tile_begin, tile_end, x_free, u_free, rows, n_x, n_u, loss_slot, counter, beta1, beta2,
+                              bc_next, stream);
+}
+
+extern "C" int hfem_plan_iface_put_f32(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end,
+                                       const float *x_free, const float *u_free, const int32_t *rows, int32_t n_x, int32_t n_u,
+                                       int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next,
+                                       void *stream) {
+    return plan_iface_put_any(1, plan, peer, tile_begin, tile_end, x_free, u_free, rows, n_x, n_u, loss_slot, counter, beta1, beta2,
+                              bc_next, stream);
 }
 
 // Options.  Product: tiled_block (256 / 512 / 1024 threads per tile), store_policy (0 plain, 16 sc1 write-through),

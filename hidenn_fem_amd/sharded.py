@@ -189,7 +189,10 @@ class ShardedTri3Energy:
         nx, nu = model.node_coords_free.numel(), model.u_free.numel()
         self._nx, self._nu = nx, nu
         dev = model.node_coords_free.device
-        self.send = torch.zeros(nx + nu + 1, dtype=F64, device=dev)      # non-owned rows stay 0 forever
+        # fp32 models (the reference's default dtype): gradient rows in the model's dtype; the owner-sharded modes work (energy,
+        # payloads and Adam in the fused steps have float-row kernels), the dense mode and the unfused Adam step need fp64
+        self._f32 = model.node_coords_free.dtype == torch.float32
+        self.send = torch.zeros(nx + nu + 1, dtype=model.node_coords_free.dtype, device=dev)      # non-owned rows stay 0 forever
         self.recv = torch.empty_like(self.send)
 
     # views into the packed buffers
@@ -201,24 +204,29 @@ class ShardedTri3Energy:
         m = self.model
         dev = m.node_coords_free.device
         mat, W, Bk, Tc, fn = self._hip_consts()
+        if self._f32 and not (flags & 8):
+            raise RuntimeError("sharded evaluation of an fp32 model: owner-sharded modes only (the dense mode keeps its energy in "
+                               "the gradient buffer); use model.double()")
         # fixed rows are looked up on every call (the model caches them and tracks u_fixed._version / device): an
         # in-place edit of u_fixed or model.to(device) is never served from a stale pointer
         xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()
         pxfix, pufix = (xfix.data_ptr() if xfix.numel() else None), (ufix.data_ptr() if ufix.numel() else None)
         rc = fn(self.plan.handle, m.node_coords_free.data_ptr(), pxfix, m.u_free.data_ptr(), pufix, mat, W, Bk, None,
                 Tc, int(lo), int(hi), loss_v.data_ptr(), gx_v.data_ptr(), gu_v.data_ptr(), int(flags), _lib.stream_ptr(dev))
-        _lib.check(rc, "hfem_tri3_energy_plan")
+        _lib.check(rc, "hfem_tri3_energy_plan_f32" if self._f32 else "hfem_tri3_energy_plan")
 
     def _hip_consts(self):
         """Host-side constants of the energy launches (built once: per-step host work is pointer reads only)."""
         c = getattr(self, "_consts", None)
         if c is None:
             m, lf = self.model, self.loss_fn
-            if m.node_coords_free.dtype != F64 or m.u_free.dtype != F64:
-                raise RuntimeError("sharded evaluation needs an fp64 model (model.double())")
+            if m.node_coords_free.dtype != m.u_free.dtype or m.u_free.dtype not in (F64, torch.float32):
+                raise RuntimeError("sharded evaluation needs an fp64 or fp32 model")
             _, Tconst = lf._traction(m, None)
             dv = lambda a: (C.c_double * len(a))(*a)
-            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst), _lib.lib().hfem_tri3_energy_plan)
+            L = _lib.lib()
+            c = self._consts = (dv(lf._mat), lf._W, dv(lf._body_table(None)), dv(Tconst),
+                                L.hfem_tri3_energy_plan_f32 if self._f32 else L.hfem_tri3_energy_plan)
         return c
 
     def evaluate_local(self):
@@ -347,7 +355,9 @@ class ShardedTri3Energy:
         self._step_cache = None
         # the get INSIDE the next energy launch (paired-slot plans): the overlapped steps then are one energy launch per step --
         # its first workgroups wait for the flags and unpack, the boundary tiles wait for them in the kernel, the rest runs
-        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else True)   # the plan refuses if its kernel has none
+        if self._f32 and inkernel_get:
+            raise RuntimeError("the in-launch get unpacks fp64 rows only; fp32 models take the get as a launch of its own")
+        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else not self._f32)   # the plan refuses if its kernel has none
         if self.inkernel_get:
             _lib.check(_lib.lib().hfem_peer_attach_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
                                                        self._need_n[0], self._need_n[1], self.iface_rows,
@@ -389,12 +399,14 @@ class ShardedTri3Energy:
         m, dev = self.model, self.send.device
         loss = self.loss_global if loss is None else loss
         if self.peer is not None:
-            _lib.check(_lib.lib().hfem_peer_iface_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
+            get = _lib.lib().hfem_peer_iface_get_f32 if self._f32 else _lib.lib().hfem_peer_iface_get
+            _lib.check(get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
                                                       self._need_n[0], self._need_n[1], m.node_coords_free.data_ptr(),
                                                       m.u_free.data_ptr(), self.iface_rows, loss.data_ptr(),
                                                       self.peer.timeout_ticks, _lib.stream_ptr(dev)), "hfem_peer_iface_get")
             return
-        _lib.check(_lib.lib().hfem_iface_unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(),
+        unpack = _lib.lib().hfem_iface_unpack_f32 if self._f32 else _lib.lib().hfem_iface_unpack
+        _lib.check(unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(),
                                                 self._need_dst.data_ptr(), self._need_n[0], self._need_n[1],
                                                 m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.world,
                                                 self.iface_stride, self.iface_rows, loss.data_ptr(),
@@ -404,7 +416,7 @@ class ShardedTri3Energy:
         """Kernel over this rank's tiles: gradient rows of the owned nodes into the local (send) buffer, the
         partial energy straight into the payload's loss slot."""
         _, gx_v, gu_v = self._views(self.send)
-        if self.peer is not None:                  # the put launch sums the tile energies itself
+        if self.peer is not None or self._f32:     # the put / pack launch sums the tile energies itself
             return self._eval_range(self.lo, self.hi, 0, False)
         self._evaluate(self.lo, self.hi, self.payload[self.iface_rows, 0:1], gx_v, gu_v)
 
@@ -414,7 +426,7 @@ class ShardedTri3Energy:
         updated the owned rows (and once before the first evaluation if ranks do not start from identical
         parameters).  Returns (global loss, local gx view, local gu view)."""
         _, gx_v, gu_v = self._views(self.send)
-        if self.peer is not None:
+        if self.peer is not None or (self._f32 and self._hip):
             self._pack_loss(count_step=False)
         else:
             self._pack()
@@ -435,7 +447,7 @@ class ShardedTri3Energy:
     def owner_step(self):
         """evaluate_owner() + exchange_halo() with every Python-side lookup hoisted (views, parameter objects, ctypes
         functions, the stream): the N > 1 loop is host-bound, so this is what bench.py times.  HIP evaluator only."""
-        if self.peer is not None:
+        if self.peer is not None or self._f32:
             self.evaluate_owner()
             return self.exchange_halo()
         c = getattr(self, "_step_cache", None)
@@ -506,6 +518,9 @@ class ShardedTri3Energy:
         is (completed steps) + 1 -- the counter is bumped by the pack launch that follows."""
         a, m = self._adam, self.model
         dev = self.send.device
+        if self._f32:
+            raise RuntimeError("the unfused owner-sharded Adam step needs an fp64 model; fp32 models take the fused steps "
+                               "(init_owner_adam(..., fused=True) + owner_train_step_fused[_overlapped])")
         _, gx_v, gu_v = self._views(self.send)
         _lib.check(_lib.lib().hfem_adam_step_rows2_dev(
             _lib.dev_index(dev), m.node_coords_free.data_ptr(), gx_v.data_ptr(), a["mx"].data_ptr(), a["vx"].data_ptr(),
@@ -534,13 +549,15 @@ class ShardedTri3Energy:
             fz = getattr(self, "_fused", None)
             ad = getattr(self, "_adam", None)
             if self.peer is not None:
-                _lib.check(_lib.lib().hfem_plan_iface_put(
+                put = _lib.lib().hfem_plan_iface_put_f32 if self._f32 else _lib.lib().hfem_plan_iface_put
+                _lib.check(put(
                     self.plan.handle, self.peer.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(),
                     m.u_free.data_ptr(), self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.iface_rows,
                     ad["step"].data_ptr() if count_step else None, ad["betas"][0] if ad else 0.0, ad["betas"][1] if ad else 0.0,
                     fz["bc"].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_put")
                 return
-            _lib.check(_lib.lib().hfem_plan_iface_pack(
+            pack = _lib.lib().hfem_plan_iface_pack_f32 if self._f32 else _lib.lib().hfem_plan_iface_pack
+            _lib.check(pack(
                 self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
                 self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
                 self._adam["step"].data_ptr() if count_step else None, self._adam["betas"][0], self._adam["betas"][1],
@@ -604,7 +621,7 @@ class ShardedTri3Energy:
             self._bind_peer_get()
         xfix, ufix = m.node_coords_fixed, m.u_fixed_rows()
         _lib.check(_lib.lib().hfem_tri3_energy_adam_step_ex(
-            self.plan.handle, 0, fz["x"][i].data_ptr(), xfix.data_ptr() if xfix.numel() else None, fz["u"][i].data_ptr(),
+            self.plan.handle, 1 if self._f32 else 0, fz["x"][i].data_ptr(), xfix.data_ptr() if xfix.numel() else None, fz["u"][i].data_ptr(),
             ufix.data_ptr() if ufix.numel() else None, mat, W, None, None, Tc, fz["x"][o].data_ptr(), fz["u"][o].data_ptr(),
             a["mx"].data_ptr(), a["vx"].data_ptr(), a["mu"].data_ptr(), a["vu"].data_ptr(), a["lr"][0], a["lr"][1],
             a["betas"][0], a["betas"][1], a["eps"], fz["bc"].data_ptr(), int(lo), int(hi), self.loss_global.data_ptr(),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HFEM_VERSION 112   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
+#define HFEM_VERSION 113   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
 
 int hfem_version(void);
 const char *hfem_last_error(void);
@@ -406,6 +406,14 @@ int hfem_iface_unpack(int device, const double *recv, const int32_t *src, const 
 int hfem_plan_iface_pack(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const double *x_free,
                          const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
                          int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
+/* The exchange for fp32 models (the reference's default dtype; `_f32` as for the energy entry points): parameter rows are
+ * float2, the payload stays double2 -- widened on the way out, rounded back (losslessly) on the way in.               */
+int hfem_plan_iface_pack_f32(hfem_plan *plan, int32_t tile_begin, int32_t tile_end, const float *x_free,
+                             const float *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, double *out,
+                             int64_t loss_slot, int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
+int hfem_iface_unpack_f32(int device, const double *recv, const int32_t *src, const int32_t *dst, int32_t n_x,
+                          int32_t n_u, float *x_free, float *u_free, int32_t world, int64_t stride,
+                          int64_t loss_slot, double *loss_out, void *stream);
 
 /* Peer-window exchange (csrc/peer.hip): the interface payload of hfem_plan_iface_pack written BY THE PACK KERNEL into a
  * receive window on every rank -- stores over xGMI into IPC-mapped device memory -- with arrival flags, instead of an
@@ -444,6 +452,11 @@ int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, in
                         int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
 int hfem_peer_iface_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u, double *x_free,
                         double *u_free, int64_t loss_slot, double *loss_out, int64_t timeout_ticks, void *stream);
+int hfem_plan_iface_put_f32(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end, const float *x_free,
+                            const float *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, int64_t loss_slot,
+                            int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);
+int hfem_peer_iface_get_f32(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u, float *x_free,
+                            float *u_free, int64_t loss_slot, double *loss_out, int64_t timeout_ticks, void *stream);
 
 /* In-library collectives: one RCCL communicator per rank (one process per GPU).  Rank 0 calls
  * hfem_mg_unique_id and broadcasts the 128 bytes by any side channel (torch.distributed, a file, MPI); every rank

@@ -41,18 +41,20 @@ def _model_delaunay(d, n_nodes=40000):
                                     neumann_edges=edges).to(d)
 
 
-def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0, inkernel=None, delaunay=False):
+def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=5.0, inkernel=None, delaunay=False, f32=False):
     from hidenn_fem_amd.loss import EnergyLoss2D
     from hidenn_fem_amd.sharded import ShardedTri3Energy
     m = _model_delaunay(d) if delaunay else _model(d)
-    sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=F64), comm=comm, group=group)
+    if f32:
+        m = m.float()
+    sh = ShardedTri3Energy(m, EnergyLoss2D(device=d, dtype=torch.float32 if f32 else F64), comm=comm, group=group)
     sh.setup_interfaces()
     sh.init_owner_adam(LR_X, LR_U, fused=fused)
     if split is not None:
         sh.mid = split(sh)
     if peer:
         sh.enable_peer_exchange(timeout_s=timeout_s, inkernel_get=inkernel)
-        assert sh.inkernel_get == (True if inkernel is None else inkernel)      # these plans' kernels have the in-launch get
+        assert sh.inkernel_get == ((not f32) if inkernel is None else inkernel)      # these plans' kernels have the in-launch get (fp64 rows)
     return sh
 
 
@@ -165,6 +167,53 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
     comm.close()
 
 
+def _close32(a, b, tol=2e-5):
+    a, b = torch.as_tensor(a, dtype=F64), torch.as_tensor(b, dtype=F64)
+    return a.shape == b.shape and bool((a - b).abs().max().item() <= tol * b.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_fp32_model_owner_sharded_fused_steps_one_rank():
+    """An fp32 model (the reference's default dtype) in the owner-sharded fused steps: float parameter rows, double2 payload
+    (pack_f32 / unpack_f32, put_f32 / get_f32), Adam inside the energy launch on float rows.  Collective path and peer windows,
+    plain and overlapped, against the unsharded one-launch EnergyAdamStep of the same model; and the evaluation-only step."""
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.optim import EnergyAdamStep
+    from hidenn_fem_amd.sharded import LibraryComm
+    d = torch.device("cuda:0")
+    comm = LibraryComm(d)
+    third = lambda sh: sh.plan.n_tiles // 3
+    n = 8
+    m0 = _model(d).float()
+    tr = EnergyAdamStep(m0, EnergyLoss2D(device=d, dtype=torch.float32), lr_x=LR_X, lr_u=LR_U)
+    l0 = [tr.step().item() for _ in range(n)]
+    for name, over in (("owner_train_step_fused", False), ("owner_train_step_fused_overlapped", True)):
+        for peer in (False, True):
+            sh = _trainer(d, peer, comm=None if peer else comm, fused=True, split=third if over else None, f32=True)
+            assert sh.model.node_coords_free.dtype == torch.float32 and sh.send.dtype == torch.float32
+            got = _run(sh, name, n, over)
+            assert _close32(got, l0, 1e-6), (name, peer, got, l0)       # energies: fp64 sums of the same float rows
+            for a, b in zip(sh.model.parameters(), m0.parameters()):
+                assert _close32(a.detach(), b.detach()), (name, peer)
+            if peer:
+                assert sh.peer.status() == (0, n) and not sh.inkernel_get
+                sh.close_peer_exchange()
+    # evaluation + exchange, and what fp32 models cannot do in this mode
+    sh = _trainer(d, True, fused=True, split=third, f32=True)
+    ref = _trainer(d, False, comm=comm, fused=True, split=third, f32=True)
+    la, lb = sh.owner_step()[0].item(), ref.owner_step()[0].item()
+    assert la == lb
+    for _ in range(2):
+        sh.owner_step_overlapped()
+    assert sh.finish_overlapped().item() == la
+    with pytest.raises(RuntimeError):
+        sh.owner_train_step()                      # unfused Adam on rows: fp64 only
+    with pytest.raises(RuntimeError):
+        sh.evaluate_local()                        # dense mode: fp64 only
+    sh.close_peer_exchange()
+    comm.close()
+
+
 def _worker_two_ranks(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -207,6 +256,20 @@ def _worker_two_ranks(rank, world, port, q):
             report[name] = (bool(same), bool(same_g), st, got.peer.status(), l_got)
             dist.barrier()
             got.close_peer_exchange()
+        # an fp32 model through the fused steps: peer windows against the gloo all_gather
+        ok32 = True
+        for name, over in (("owner_train_step_fused", False), ("owner_train_step_fused_overlapped", True)):
+            ref = _trainer(d, False, fused=True, f32=True)
+            got = _trainer(d, True, fused=True, f32=True)
+            l_ref = _run(ref, "owner_train_step_fused", n, False)
+            l_got = _run(got, name, n, over)
+            own_x, own_u = ref.owned_rows()
+            ok32 = ok32 and _close32(l_got, l_ref, 1e-6) and got.peer.status() == (0, n) \
+                and _close32(got.model.node_coords_free[own_x].detach(), ref.model.node_coords_free[own_x].detach()) \
+                and _close32(got.model.u_free[own_u].detach(), ref.model.u_free[own_u].detach())
+            dist.barrier()
+            got.close_peer_exchange()
+        report["f32"] = bool(ok32)
         # the bounded wait: only rank 0 puts; its get gives up after 0.3 s with the sticky status bit
         lone = _trainer(d, True, timeout_s=0.3)
         if rank == 0:
@@ -250,4 +313,5 @@ def test_peer_windows_processes_sharing_one_gpu(world):
             assert same_g, f"rank {r} {name}: captured peer-window steps differ"
             assert st == (0, 6) and st_g == (0, 10), (r, name, st, st_g)
         assert all(res[r][name][4] == res[0][name][4] for r in range(world)), "ranks disagree on the global energies (summed in rank order everywhere)"
+    assert all(res[r]["f32"] for r in range(world)), "fp32 model: peer-window fused steps differ from the all_gather ones"
     assert res[0]["timeout"] == ((1, 1), True)

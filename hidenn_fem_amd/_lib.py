@@ -108,6 +108,8 @@ PROTOTYPES = {
     "hfem_plan_iface_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _f64, _f64, _vp, _vp]),
     "hfem_adam_step_rows2_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _f64,
                                            _f64, _f64, _f64, _vp, _i64, _vp]),
+    "hfem_adam_step_rows2_dev_f32": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _f64,
+                                               _f64, _f64, _f64, _vp, _i64, _vp]),
     "hfem_quad4_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_energy_plan_body": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_quad4_energy_plan_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -131,6 +131,33 @@ __global__ __launch_bounds__(256) void adam_step_rows2_dev_kernel(double2 *__res
     m[r] = mi; v[r] = vi; p[r] = pi;
 }
 
+// float rows (an fp32 model): torch's fp32 arithmetic, component by component (adam_one<float>)
+__global__ __launch_bounds__(256) void adam_step_rows2_dev_f32_kernel(float2 *__restrict__ px, const float2 *__restrict__ gx,
+                                                                      float2 *__restrict__ mx, float2 *__restrict__ vx,
+                                                                      const int32_t *__restrict__ rows_x, int64_t n_x, double lr_x,
+                                                                      float2 *__restrict__ pu, const float2 *__restrict__ gu,
+                                                                      float2 *__restrict__ mu, float2 *__restrict__ vu,
+                                                                      const int32_t *__restrict__ rows_u, int64_t n_u, double lr_u,
+                                                                      double b1, double b2, double eps,
+                                                                      const int64_t *__restrict__ step_dev, int64_t step_offset) {
+    const double step = (double)(step_dev[0] + step_offset);
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const double sqrt_bc2 = sqrt(bc2), w1 = 1.0 - b1, w2 = 1.0 - b2;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_x + n_u) return;
+    const bool isx = i < n_x;
+    if (!isx) i -= n_x;
+    float2 *p = isx ? px : pu, *m = isx ? mx : mu, *v = isx ? vx : vu;
+    const float2 *g = isx ? gx : gu;
+    const double step_size = (isx ? lr_x : lr_u) / bc1;
+    const int32_t r = (isx ? rows_x : rows_u)[i];
+    const float2 gi = g[r];
+    float2 mi = m[r], vi = v[r], pi = p[r];
+    adam_one<float>(pi.x, gi.x, mi.x, vi.x, w1, b2, w2, step_size, sqrt_bc2, eps);
+    adam_one<float>(pi.y, gi.y, mi.y, vi.y, w1, b2, w2, step_size, sqrt_bc2, eps);
+    m[r] = mi; v[r] = vi; p[r] = pi;
+}
+
 // ---- multi-tensor form: ONE launch for every parameter tensor of the optimiser.  table[t] (device memory) describes tensor
 // t and the first block that works on it; block b finds its tensor by a scan of the (few) table entries and updates one
 // contiguous chunk of 16-byte vectors.  The step count: step_dev[0] holds the number of COMPLETED steps, every block reads
@@ -290,6 +317,23 @@ extern "C" int hfem_adam_step_rows2_dev(int device, double *px, const double *gx
                        (const double2 *)gu, (double2 *)mu, (double2 *)vu, rows_u, n_u, lr_u, beta1, beta2, eps, step_dev,
                        step_offset);
     return launch_status("hfem_adam_step_rows2_dev");
+}
+
+extern "C" int hfem_adam_step_rows2_dev_f32(int device, float *px, const float *gx, float *mx, float *vx,
+                                            const int32_t *rows_x, int64_t n_x, double lr_x, float *pu, const float *gu,
+                                            float *mu, float *vu, const int32_t *rows_u, int64_t n_u, double lr_u,
+                                            double beta1, double beta2, double eps, const int64_t *step_dev,
+                                            int64_t step_offset, void *stream) {
+    HFEM_ARG_CHECK(n_x >= 0 && n_u >= 0, "negative row count");
+    if (n_x + n_u == 0) return 0;
+    HFEM_ARG_CHECK(step_dev && (n_x == 0 || (px && gx && mx && vx && rows_x)) && (n_u == 0 || (pu && gu && mu && vu && rows_u)),
+                   "null pointer");
+    if (int rc = use_device(device)) return rc;
+    hipLaunchKernelGGL(adam_step_rows2_dev_f32_kernel, dim3((int)((n_x + n_u + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float2 *)px, (const float2 *)gx, (float2 *)mx, (float2 *)vx, rows_x, n_x, lr_x, (float2 *)pu,
+                       (const float2 *)gu, (float2 *)mu, (float2 *)vu, rows_u, n_u, lr_u, beta1, beta2, eps, step_dev,
+                       step_offset);
+    return launch_status("hfem_adam_step_rows2_dev_f32");
 }
 
 extern "C" int hfem_adam_multi_dev(int device, const hfem_adam_tensor *table_dev, int32_t n_tensors, int32_t n_blocks,

@@ -190,7 +190,7 @@ class ShardedTri3Energy:
         self._nx, self._nu = nx, nu
         dev = model.node_coords_free.device
         # fp32 models (the reference's default dtype): gradient rows in the model's dtype; the owner-sharded modes work (energy,
-        # payloads and Adam in the fused steps have float-row kernels), the dense mode and the unfused Adam step need fp64
+        # payloads and both Adam forms have float-row kernels), the dense mode needs fp64
         self._f32 = model.node_coords_free.dtype == torch.float32
         self.send = torch.zeros(nx + nu + 1, dtype=model.node_coords_free.dtype, device=dev)      # non-owned rows stay 0 forever
         self.recv = torch.empty_like(self.send)
@@ -518,11 +518,9 @@ class ShardedTri3Energy:
         is (completed steps) + 1 -- the counter is bumped by the pack launch that follows."""
         a, m = self._adam, self.model
         dev = self.send.device
-        if self._f32:
-            raise RuntimeError("the unfused owner-sharded Adam step needs an fp64 model; fp32 models take the fused steps "
-                               "(init_owner_adam(..., fused=True) + owner_train_step_fused[_overlapped])")
         _, gx_v, gu_v = self._views(self.send)
-        _lib.check(_lib.lib().hfem_adam_step_rows2_dev(
+        fn = _lib.lib().hfem_adam_step_rows2_dev_f32 if self._f32 else _lib.lib().hfem_adam_step_rows2_dev
+        _lib.check(fn(
             _lib.dev_index(dev), m.node_coords_free.data_ptr(), gx_v.data_ptr(), a["mx"].data_ptr(), a["vx"].data_ptr(),
             a["rows_x"].data_ptr(), a["rows_x"].numel(), a["lr"][0], m.u_free.data_ptr(), gu_v.data_ptr(),
             a["mu"].data_ptr(), a["vu"].data_ptr(), a["rows_u"].data_ptr(), a["rows_u"].numel(), a["lr"][1],

@@ -485,6 +485,11 @@ int hfem_adam_step_rows2_dev(int device, double *px, const double *gx, double *m
                              int64_t n_x, double lr_x, double *pu, const double *gu, double *mu, double *vu,
                              const int32_t *rows_u, int64_t n_u, double lr_u, double beta1, double beta2, double eps,
                              const int64_t *step_dev, int64_t step_offset, void *stream);
+/* The same on float rows (an fp32 model): torch's fp32 arithmetic. */
+int hfem_adam_step_rows2_dev_f32(int device, float *px, const float *gx, float *mx, float *vx, const int32_t *rows_x,
+                                 int64_t n_x, double lr_x, float *pu, const float *gu, float *mu, float *vu,
+                                 const int32_t *rows_u, int64_t n_u, double lr_u, double beta1, double beta2, double eps,
+                                 const int64_t *step_dev, int64_t step_offset, void *stream);
 
 /* ------------------------------------------------------------------ 1D / structured
  * Grid parametrisation softplus -> clamp(1e-6) -> cumsum -> renormalise

@@ -173,8 +173,8 @@ def _close32(a, b, tol=2e-5):
 
 
 @pytest.mark.gpu
-def test_fp32_model_owner_sharded_fused_steps_one_rank():
-    """An fp32 model (the reference's default dtype) in the owner-sharded fused steps: float parameter rows, double2 payload
+def test_fp32_model_owner_sharded_steps_one_rank():
+    """An fp32 model (the reference's default dtype) in the owner-sharded steps: float parameter rows, double2 payload
     (pack_f32 / unpack_f32, put_f32 / get_f32), Adam inside the energy launch on float rows.  Collective path and peer windows,
     plain and overlapped, against the unsharded one-launch EnergyAdamStep of the same model; and the evaluation-only step."""
     from hidenn_fem_amd.loss import EnergyLoss2D
@@ -207,10 +207,25 @@ def test_fp32_model_owner_sharded_fused_steps_one_rank():
         sh.owner_step_overlapped()
     assert sh.finish_overlapped().item() == la
     with pytest.raises(RuntimeError):
-        sh.owner_train_step()                      # unfused Adam on rows: fp64 only
-    with pytest.raises(RuntimeError):
         sh.evaluate_local()                        # dense mode: fp64 only
     sh.close_peer_exchange()
+    # the unfused steps (energy -> Adam on the owned float rows -> exchange) against value_and_grad_ + FusedAdam
+    from hidenn_fem_amd.optim import FusedAdam
+    m1 = _model(d).float()
+    lf = EnergyLoss2D(device=d, dtype=torch.float32)
+    opt = FusedAdam([dict(params=[m1.node_coords_free], lr=LR_X), dict(params=[m1.u_free], lr=LR_U)])
+    l1 = []
+    for _ in range(n):
+        l1.append(lf.value_and_grad_(m1).item())
+        opt.step()
+    for name, over in (("owner_train_step", False), ("owner_train_step_overlapped", True)):
+        sh = _trainer(d, True, split=third if over else None, f32=True)
+        got = _run(sh, name, n, over)
+        assert _close32(got, l1, 1e-6), (name, got, l1)
+        for a, b in zip(sh.model.parameters(), m1.parameters()):
+            assert _close32(a.detach(), b.detach()), name
+        assert sh.peer.status() == (0, n)
+        sh.close_peer_exchange()
     comm.close()
 
 

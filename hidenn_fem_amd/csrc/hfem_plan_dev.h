@@ -60,7 +60,8 @@ struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgr
 
 // One service workgroup of the in-launch get (256 threads of a tile kernel's block): iface_get_kernel's wait + unpack with
 // a block-stride loop, then -- rows visible device-wide -- the last of the nblk workgroups publishes unpacked = puts.
-__device__ __forceinline__ void peer_get_block(const PeerGetDev &G, int bid, int nblk, double2 *x_free, double2 *u_free) {
+template <typename V>
+__device__ __forceinline__ void peer_get_block(const PeerGetDev &G, int bid, int nblk, V *x_free, V *u_free) {
     __shared__ int pg_last;
     char *self = G.pv.win[G.pv.rank], *ctl = G.pv.ctl;
     const int tid = threadIdx.x;
@@ -94,8 +95,8 @@ __device__ __forceinline__ void peer_get_block(const PeerGetDev &G, int bid, int
         const int par = (int)((want - 1) & 1);
         const double2 *recv = (const double2 *)(self + kPeerData + (size_t)par * G.pv.world * (size_t)G.stride * sizeof(double2));
         for (int i = bid * 256 + tid; i < G.n_x + G.n_u; i += nblk * 256) {
-            if (i < G.n_x) x_free[G.dst[i]] = recv[G.src[i]];
-            else u_free[G.dst[i]] = recv[G.src[i]];
+            if (i < G.n_x) x_free[G.dst[i]] = row_narrow<V>(recv[G.src[i]]);
+            else u_free[G.dst[i]] = row_narrow<V>(recv[G.src[i]]);
         }
         if (bid == 0 && tid == 0 && G.loss_out) {
             double tot = 0.0;

@@ -261,8 +261,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     int bid = (int)blockIdx.x;
     if constexpr (PG) {
         if (bid < lag.pg_blocks) {
-            if constexpr (std::is_same<V2, double2>::value)
-                peer_get_block(*lag.pg, bid, lag.pg_blocks, const_cast<double2 *>(x_free), const_cast<double2 *>(u_free));
+            peer_get_block<V2>(*lag.pg, bid, lag.pg_blocks, const_cast<V2 *>(x_free), const_cast<V2 *>(u_free));
             return;
         }
         bid -= lag.pg_blocks;
@@ -527,7 +526,7 @@ struct Tri3Launch {
 template <int BLK, int NPT, int EPT, bool HB, int SP, typename V2, int CO, bool ADAM, bool PHYS, bool STAMP = false>
 void launch_fast(const Tri3Launch &A, int grid, const AdamFuse &af, const LagSum &lag) {
     const size_t lds = CO > 0 ? (size_t)(A.max_nodes * 32 + CO * 32 + 128) : A.lds;
-    if constexpr (std::is_same<V2, double2>::value && !HB && !PHYS && !STAMP && BLK == 512 && (SP == 16 || SP == 2)) {
+    if constexpr (!HB && !PHYS && !STAMP && BLK == 512 && (SP == 16 || SP == 2)) {
         if (lag.pg_blocks) {                               // HFEM_FLAG_PEER_GET: the instance with the in-launch get
             hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, STAMP, SP, V2, 0, CO, ADAM, PHYS, true>), dim3(grid), dim3(BLK),
                                lds, A.s, A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
@@ -975,8 +974,8 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS | HFEM_FLAG_PEER_GET)),
-                   "fp32-storage path: reference convention, atomic accumulation, no lagged loss sum, no in-launch get");
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS)),
+                   "fp32-storage path: reference convention, atomic accumulation, no lagged loss sum");
     const HostPlan &h = plan->host;
     const int32_t nt = (int32_t)h.tiles.size();
     if (tile_end < 0) tile_end = nt;
@@ -991,16 +990,22 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     hipStream_t s = (hipStream_t)stream;
     const int n = tile_end - tile_begin;
     double *pbase = plan->d_partials + (size_t)plan->bank * nt + tile_begin;
+    LagSum lag;
+    if (flags & HFEM_FLAG_PEER_GET) {
+        HFEM_ARG_CHECK(plan->peer_get && n > 0, "HFEM_FLAG_PEER_GET: hfem_plan_set_peer_get first, and a non-empty tile range");
+        lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
+        lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
+    }
     if (n > 0 && h.paired) {
         PairLaunch P;
-        P.grid = n; P.tile_begin = (int)tile_begin;
+        P.grid = n + lag.pg_blocks; P.tile_begin = (int)tile_begin;
         P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
         P.k = make_consts(mat, W, Bk); P.T_edge = (const double4 *)T_edge;
         P.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
         P.partials = pbase;
         P.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; P.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
         P.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0; P.s = s;
-        HFEM_ARG_CHECK(launch_tri3_pair(plan, P, 2, false, false, LagSum{}, AdamFuse{}) == 1,
+        HFEM_ARG_CHECK(launch_tri3_pair(plan, P, 2, false, false, lag, AdamFuse{}) == 1,
                        "paired plan: tile shape outside the pair kernel's instances");
         if (int rc = launch_status("hfem_tri3_energy_plan_f32")) return rc;
     } else if (n > 0) {
@@ -1013,8 +1018,8 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
         A.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; A.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
         A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0;
         A.stamps = plan->d_stamps; A.lds = (size_t)plan->lds_bytes; A.s = s;
-        if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, float2, 0, false, false>(A, n, AdamFuse{}, LagSum{});
-        else launch_fast<512, 2, 4, false, 16, float2, 0, false, false>(A, n, AdamFuse{}, LagSum{});
+        if (h.max_elems <= 3 * 512) launch_fast<512, 2, 3, false, 16, float2, 0, false, false>(A, n + lag.pg_blocks, AdamFuse{}, lag);
+        else launch_fast<512, 2, 4, false, 16, float2, 0, false, false>(A, n + lag.pg_blocks, AdamFuse{}, lag);
         if (int rc = launch_status("hfem_tri3_energy_plan_f32")) return rc;
     }
     if (flags & HFEM_FLAG_NO_LOSS_SUM) return 0;
@@ -1094,7 +1099,7 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
     }
     if (flags & HFEM_FLAG_PEER_GET) {
         HFEM_ARG_CHECK(plan->peer_get, "HFEM_FLAG_PEER_GET: hfem_plan_set_peer_get has not been called");
-        HFEM_ARG_CHECK(dtype == 0 && !hasb && n > 0, "HFEM_FLAG_PEER_GET: fp64 rows, zero body force, a non-empty tile range");
+        HFEM_ARG_CHECK(!hasb && n > 0, "HFEM_FLAG_PEER_GET: zero body force, a non-empty tile range");
         lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
         lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
     }

@@ -51,8 +51,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     int bid = (int)blockIdx.x;
     if constexpr (PG) {
         if (bid < lag.pg_blocks) {
-            if constexpr (std::is_same<V2, double2>::value)
-                peer_get_block(*lag.pg, bid, lag.pg_blocks, const_cast<double2 *>(x_free), const_cast<double2 *>(u_free));
+            peer_get_block<V2>(*lag.pg, bid, lag.pg_blocks, const_cast<V2 *>(x_free), const_cast<V2 *>(u_free));
             return;
         }
         bid -= lag.pg_blocks;                           // a multiple of 8: the block -> XCD mapping of the tiles is unchanged
@@ -289,7 +288,7 @@ template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2
 static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
     constexpr int CAPN = CAPO > 0 ? kPairCapN : 0;
     const size_t lds = CAPO > 0 ? (size_t)(CAPN * 32 + CAPO * 32 + 128) : A.lds;
-    if constexpr (std::is_same<V2, double2>::value && !HASB && !PHYS && !CHAIN) {
+    if constexpr (!HASB && !PHYS && !CHAIN) {
         if (lag.pg_blocks) {                               // HFEM_FLAG_PEER_GET: the instance with the in-launch get
             hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN, SP, true>), dim3(A.grid), dim3(BLK), lds, A.s,
                                A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,

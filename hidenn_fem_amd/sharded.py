@@ -355,9 +355,7 @@ class ShardedTri3Energy:
         self._step_cache = None
         # the get INSIDE the next energy launch (paired-slot plans): the overlapped steps then are one energy launch per step --
         # its first workgroups wait for the flags and unpack, the boundary tiles wait for them in the kernel, the rest runs
-        if self._f32 and inkernel_get:
-            raise RuntimeError("the in-launch get unpacks fp64 rows only; fp32 models take the get as a launch of its own")
-        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else not self._f32)   # the plan refuses if its kernel has none
+        self.inkernel_get = bool(inkernel_get if inkernel_get is not None else True)   # the plan refuses if its kernel has none
         if self.inkernel_get:
             _lib.check(_lib.lib().hfem_peer_attach_get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
                                                        self._need_n[0], self._need_n[1], self.iface_rows,

@@ -54,7 +54,7 @@ def _trainer(d, peer, comm=None, group=None, fused=False, split=None, timeout_s=
         sh.mid = split(sh)
     if peer:
         sh.enable_peer_exchange(timeout_s=timeout_s, inkernel_get=inkernel)
-        assert sh.inkernel_get == ((not f32) if inkernel is None else inkernel)      # these plans' kernels have the in-launch get (fp64 rows)
+        assert sh.inkernel_get == (True if inkernel is None else inkernel)      # these plans' kernels have the in-launch get
     return sh
 
 
@@ -196,7 +196,7 @@ def test_fp32_model_owner_sharded_steps_one_rank():
             for a, b in zip(sh.model.parameters(), m0.parameters()):
                 assert _close32(a.detach(), b.detach()), (name, peer)
             if peer:
-                assert sh.peer.status() == (0, n) and not sh.inkernel_get
+                assert sh.peer.status() == (0, n) and sh.inkernel_get
                 sh.close_peer_exchange()
     # evaluation + exchange, and what fp32 models cannot do in this mode
     sh = _trainer(d, True, fused=True, split=third, f32=True)

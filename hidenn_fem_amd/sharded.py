@@ -380,6 +380,12 @@ class ShardedTri3Energy:
         self.peer.close()
         self.peer, self.inkernel_get, self._wait_range, self._step_cache = None, False, None, None
 
+    def __del__(self):
+        try:                       # the plan outlives this object (the model caches it): do not leave it a dangling pointer
+            self.close_peer_exchange()
+        except Exception:
+            pass
+
     def _bind_peer_get(self):
         """(Re)bind the in-launch get to the plan with the rank's CURRENT boundary range [lo, mid)."""
         if self._wait_range != (self.lo, self.mid):

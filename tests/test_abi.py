@@ -39,6 +39,16 @@ def test_argument_errors_are_reported_not_raised_across_the_abi():
     assert L.hfem_plan_export(None, 0, None, 0) < 0
     with pytest.raises(RuntimeError, match="rc=-1"):
         _lib.check(rc, "hfem_plan_create")
+    # the peer-window entry points check their arguments before they touch a device
+    peer = C.c_void_p()
+    assert L.hfem_peer_create(0, 3, 2, 8, C.byref(peer)) < 0 and b"rank / world" in L.hfem_last_error()
+    assert L.hfem_peer_create(0, 0, 17, 8, C.byref(peer)) < 0                    # at most 16 ranks
+    assert L.hfem_peer_create(0, 0, 1, 0, C.byref(peer)) < 0 and b"stride" in L.hfem_last_error()
+    assert L.hfem_peer_status(None, None, None) < 0
+    assert L.hfem_peer_connect(None, None) < 0 and L.hfem_peer_ipc_handle(None, None) < 0
+    assert L.hfem_peer_iface_get(None, None, None, 0, 0, None, None, 0, None, 1, None) < 0
+    assert L.hfem_plan_iface_put(None, None, 0, -1, None, None, None, 0, 0, 0, None, 0.9, 0.999, None, None) < 0
+    assert L.hfem_plan_set_peer_get(None, None, 0, 0) < 0 and L.hfem_peer_destroy(None) == 0
 
 
 def test_models_construct_on_cpu_but_compute_raises():

@@ -344,10 +344,10 @@ class ShardedTri3Energy:
         pack launch stores the payload into every rank's window and the unpack launch waits for the arrival flags in its
         own -- same payload, same unpack tables, same numbers.  Every ``owner_*`` step then runs on ONE stream; the
         ``*_overlapped`` steps keep their launch order (the flags arrive while the interior tiles run).  Collective over
-        the group: call it on every rank, after ``setup_interfaces`` and before any graph capture.  ``inkernel_get`` (default:
-        whenever the plan is a paired-slot one): the ``*_overlapped`` steps run the get as the first workgroups of their ONE
-        energy launch (``HFEM_FLAG_PEER_GET``) instead of a launch of its own (default: whenever the plan's kernel implements
-        it -- paired-slot plans without chained records, 512-thread one-element-per-slot plans)."""
+        the group: call it on every rank, after ``setup_interfaces`` and before any graph capture.  ``inkernel_get``: the
+        ``*_overlapped`` steps run the get as the first workgroups of their ONE energy launch (``HFEM_FLAG_PEER_GET``) instead
+        of a launch of its own (default: whenever the plan's kernel implements it -- paired-slot plans without chained
+        records, 512-thread one-element-per-slot plans; fp64 and fp32 rows)."""
         if not self._hip or self._unpack != self._unpack_hip:
             raise RuntimeError("enable_peer_exchange needs the HIP evaluator and the HIP pack / unpack")
         self.peer = PeerWindows(self.send.device, self.iface_stride, self.group, rank=self.rank, world=self.world,
@@ -404,17 +404,14 @@ class ShardedTri3Energy:
         loss = self.loss_global if loss is None else loss
         if self.peer is not None:
             get = _lib.lib().hfem_peer_iface_get_f32 if self._f32 else _lib.lib().hfem_peer_iface_get
-            _lib.check(get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(),
-                                                      self._need_n[0], self._need_n[1], m.node_coords_free.data_ptr(),
-                                                      m.u_free.data_ptr(), self.iface_rows, loss.data_ptr(),
-                                                      self.peer.timeout_ticks, _lib.stream_ptr(dev)), "hfem_peer_iface_get")
+            _lib.check(get(self.peer.handle, self._need_src.data_ptr(), self._need_dst.data_ptr(), self._need_n[0],
+                           self._need_n[1], m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.iface_rows, loss.data_ptr(),
+                           self.peer.timeout_ticks, _lib.stream_ptr(dev)), "hfem_peer_iface_get")
             return
         unpack = _lib.lib().hfem_iface_unpack_f32 if self._f32 else _lib.lib().hfem_iface_unpack
-        _lib.check(unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(),
-                                                self._need_dst.data_ptr(), self._need_n[0], self._need_n[1],
-                                                m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.world,
-                                                self.iface_stride, self.iface_rows, loss.data_ptr(),
-                                                _lib.stream_ptr(dev)), "hfem_iface_unpack")
+        _lib.check(unpack(_lib.dev_index(dev), self.gathered.data_ptr(), self._need_src.data_ptr(), self._need_dst.data_ptr(),
+                          self._need_n[0], self._need_n[1], m.node_coords_free.data_ptr(), m.u_free.data_ptr(), self.world,
+                          self.iface_stride, self.iface_rows, loss.data_ptr(), _lib.stream_ptr(dev)), "hfem_iface_unpack")
 
     def evaluate_owner(self):
         """Kernel over this rank's tiles: gradient rows of the owned nodes into the local (send) buffer, the
@@ -562,7 +559,7 @@ class ShardedTri3Energy:
             _lib.check(pack(
                 self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
                 self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
-                self._adam["step"].data_ptr() if count_step else None, self._adam["betas"][0], self._adam["betas"][1],
+                ad["step"].data_ptr() if count_step else None, ad["betas"][0] if ad else 0.0, ad["betas"][1] if ad else 0.0,
                 fz["bc"].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
         else:
             self._pack()

@@ -209,6 +209,12 @@ def test_fp32_model_owner_sharded_steps_one_rank():
     with pytest.raises(RuntimeError):
         sh.evaluate_local()                        # dense mode: fp64 only
     sh.close_peer_exchange()
+    # evaluation + exchange without any optimiser state (the pieces one by one, as a caller with its own optimiser uses them)
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    bare = ShardedTri3Energy(_model(d).float(), EnergyLoss2D(device=d, dtype=torch.float32)).setup_interfaces()
+    bare.evaluate_owner()
+    lc = bare.exchange_halo()[0].item()
+    assert lc == la
     # the unfused steps (energy -> Adam on the owned float rows -> exchange) against value_and_grad_ + FusedAdam
     from hidenn_fem_amd.optim import FusedAdam
     m1 = _model(d).float()

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--boundary", type=float, default=0.05)
     ap.add_argument("--legs", default="collective,peer")
+    ap.add_argument("--fp32", action="store_true", help="an fp32 model (the reference's default dtype): float rows, double2 payload")
     ap.add_argument("--grid", default="1001x501", help="nodes: NX x NY (2001x1001 = 4 x 10^6 elements: launches of several rounds)")
     a = ap.parse_args()
     dev, f64 = torch.device("cuda:0"), torch.float64
@@ -32,7 +33,9 @@ def main():
     coords, conn, geom, bc, mn, edges = structured_tri_mesh(gx_, gy_, length=2.0, height=1.0, jitter=0.2, seed=0, dtype=f64)
     torch.manual_seed(0)
     m = PiecewiseLinearShapeNN2D(coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).to(dev)
-    sh = ShardedTri3Energy(m, EnergyLoss2D(device=dev, dtype=f64))
+    if a.fp32:
+        m = m.float()
+    sh = ShardedTri3Energy(m, EnergyLoss2D(device=dev, dtype=torch.float32 if a.fp32 else f64))
     sh.setup_interfaces()
     sh.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)
     sh.mid = sh.lo + max(1, int((sh.hi - sh.lo) * a.boundary))
@@ -72,7 +75,7 @@ def main():
                     train_step_overlap=us(sh.owner_train_step_overlapped, sh.finish_overlapped),
                     train_step_fused=us(sh.owner_train_step_fused),
                     train_step_fused_overlap=us(sh.owner_train_step_fused_overlapped, sh.finish_overlapped))
-    out = dict(grid=a.grid, K=K, boundary_tiles=sh.mid - sh.lo, tiles=sh.hi - sh.lo)
+    out = dict(grid=a.grid, dtype="fp32" if a.fp32 else "fp64", K=K, boundary_tiles=sh.mid - sh.lo, tiles=sh.hi - sh.lo)
     if "collective" in a.legs:
         out["collective_path"] = legs()
     if "peer" in a.legs:

@@ -3,7 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).
+N > 1: one rank per GPU over RCCL -- either launched as ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+...`` or, given plain ``python bench.py --gpus N``, bench.py starts its N ranks itself as child processes (self_launch: the
+parent never touches the GPU and never execs).  Every host plan is built ONCE per job (rank 0 writes the plan blob to the
+job's plan cache, the other ranks deserialise it).
 A *step* is one pass of the hot path over the synthetic mesh: loss + d/d node_coords_free + d/d u_free, inputs resident
 in HBM.  The timed region is ONE hipGraph of exactly K steps, bracketed by barrier + synchronize on both sides; it is
 replayed ``--repeats`` (5) times and the MEDIAN replay is reported (max over ranks per replay).
@@ -28,11 +31,14 @@ At N = 1 `config.strong_scaling_emulated` rehearses those shards on the one GPU:
 N would evaluate (`--emulate-shard r/N` runs just that).
 
 One JSON line on stdout (rank 0).  ``roofline`` is for the dominant kernel (tri3_energy_pair_kernel): algorithmic bytes
-(12 Ne + 64 Nn + 8) over its average launch time, HIP events on the launch stream.  Top level = the
-ROTATING-SETS regime (10 parameter / gradient sets, 313 MB > the 256 MB Infinity Cache: the only regime whose reads
-really come from HBM); `regimes` holds the cache-resident `replayed` leg (what the timed headline step is) and the
-`rewritten_inputs` leg; every regime also carries the kernel's in-run span from s_memrealtime stamps
-(hfem_plan_set_span_stamps) and, labelled `rocprof_*`, the profiler's average from the committed run.
+(12 Ne + 64 Nn + 8) over its average launch time, HIP events on the launch stream.  ONE regime per line:
+the top level is the regime the timed step itself runs in (`replayed`: the same buffers every launch, a 44 MB working set the
+256 MB Infinity Cache holds -- what a training loop on this mesh sees), so `roofline.kernel_us <= ms_per_step`; the regime whose
+reads really come from HBM (`rotating_sets`: 10 parameter / gradient sets, 313 MB) is `roofline.hbm_regime`, with the whole
+K-step region timed there as well (`hbm_regime.step`); `regimes` keeps every leg (replayed, rewritten_inputs, rotating_sets),
+each with the kernel's in-run span from s_memrealtime stamps (hfem_plan_set_span_stamps) and, labelled `rocprof_*`, the
+profiler's average from the committed run.  `roofline.traffic` is measured IN THE RUN (two `rocprofv3 --pmc` child passes of the
+replayed leg: FETCH_SIZE x 2 + WRITE_SIZE) when rocprofv3 is present, else the committed figure, labelled "committed".
 ``cpu_baseline`` times the oracle's op-for-op PyTorch restatement of the reference chain on the host cores.
 """
 import argparse
@@ -45,11 +51,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+np = torch = None            # imported by main(): the self-launching parent of an N > 1 run needs neither (and must not touch the GPU)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")      # committed rocprofv3 summaries of this round (r03 as fallback)
 
 
 def parse():
@@ -76,6 +81,8 @@ def parse():
     ap.add_argument("--time-budget", type=float, default=600.0, help="seconds: optional N > 1 legs (the 4.1 M-element strong-scaling "
                     "mesh: ~2 min of host-side meshing and planning per rank) are skipped, with a note, when the run is already "
                     "past half of it")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic in the run (two rocprofv3 --pmc child "
+                    "passes of the replayed leg, ~15 s each); the committed figure is reported instead, labelled so")
     ap.add_argument("--no-peer", action="store_true", help="skip the peer-window exchange legs (config.peer_exchange / sharded_step_1gpu)")
     ap.add_argument("--only-regime", default="", help="profiler helper: run ONLY this roofline leg (replayed | "
                     "rewritten_inputs | rotating_sets) and exit")
@@ -112,15 +119,111 @@ def cpu_baseline(mesh6, u_free, n_evals):
                        f"after 1 warm-up, {best:.3f} s/eval"), loss.item()
 
 
+def pmc_traffic_in_run(kernel_substr, timeout_s=150.0):
+    """FETCH_SIZE / WRITE_SIZE per launch of the dominant kernel, measured now: this script is run twice as a CHILD under
+    ``rocprofv3 --kernel-trace --pmc <counter>`` (one counter per pass, nothing but --kernel-trace beside it, the program itself
+    after ``--``), on the replayed leg only.  Returns (dict, None) or (None, reason).  Never raises; a pass that hangs is
+    killed with its process group."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hfem_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--no-cpu-baseline", "--steps", "50", "--only-regime", "replayed", "--prewarm", "0.02"]
+        try:
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return None, f"the {ctr} pass exceeded {timeout_s:.0f} s"
+            if rc != 0:
+                return None, f"the {ctr} pass exited with {rc}"
+            vals = []
+            for root, _, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, fn)) as f:
+                            for r in csv.DictReader(f):
+                                if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                                    vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"the {ctr} pass recorded no launch of {kernel_substr}"
+            out[ctr + "_KB"] = sum(vals) / len(vals)
+            out["launches"] = len(vals)
+        except Exception as e:  # noqa: BLE001
+            return None, f"{type(e).__name__}: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["read_bytes_corrected"] = 2.0 * out["FETCH_SIZE_KB"] * 1024.0
+    out["write_bytes"] = out["WRITE_SIZE_KB"] * 1024.0
+    out["traffic_bytes_per_launch"] = out["read_bytes_corrected"] + out["write_bytes"]
+    return out, None
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` (N > 1) without a launcher: THIS process -- which has made no GPU call and makes none --
+    starts the N ranks as CHILDREN through ``torch.distributed.run`` (one process per GPU, rendezvous on 127.0.0.1), relays
+    rank 0's JSON line and returns the launcher's exit code (non-zero if any rank failed).  Never an exec.  The plan cache
+    directory is created here, so that the N ranks build every host plan ONCE (TilePlan(cache_dir=...))."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL / peer windows across processes
+    made = None
+    if not env.get("HFEM_PLAN_CACHE"):
+        base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+        made = env["HFEM_PLAN_CACHE"] = tempfile.mkdtemp(prefix="hfem_plans_", dir=base)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {a.gpus} without WORLD_SIZE: starting {a.gpus} rank processes as children ({' '.join(cmd[1:8])} ...)",
+          file=sys.stderr, flush=True)
+    try:
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through (progress, notes)
+        line = None
+        for ln in pr.stdout:
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln.strip()                                                  # rank 0's one JSON line
+            else:
+                sys.stderr.write(ln)
+        rc = pr.wait()
+    finally:
+        if made:
+            shutil.rmtree(made, ignore_errors=True)
+    if rc == 0 and line is None:
+        print("[bench] the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     t_start = time.perf_counter()
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    global np, torch
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a ROCm device; there is no CPU fallback"
     ndev = torch.cuda.device_count()
@@ -161,6 +264,27 @@ def main():
     for kv in a.option:
         name, val = kv.split("=")
         _lib.check(L.hfem_set_option(name.encode(), int(val)), "hfem_set_option")
+
+    # ---- N > 1: the job's plan cache.  A host plan costs ~1 s per 10^6 elements; every rank needs the same ones (the model's
+    #      default tiling for its row order, the plan sharded N ways), so rank 0 builds them and writes the blobs, the other
+    #      ranks deserialise (TilePlan(cache_dir=$HFEM_PLAN_CACHE), hfem_plan_deserialize).  The self-launching parent made the
+    #      directory; under an external launcher rank 0 makes it here.
+    cache_made = None
+    if world > 1:
+        box = [os.environ.get("HFEM_PLAN_CACHE") or None]
+        if rank == 0 and box[0] is None:
+            import tempfile
+            box[0] = cache_made = tempfile.mkdtemp(prefix="hfem_plans_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+        dist.broadcast_object_list(box, src=0)
+        os.environ["HFEM_PLAN_CACHE"] = box[0]
+
+    def staged(fn):
+        """fn() on rank 0 first (it builds and caches the host plans), then on the other ranks (cache hits)."""
+        if world == 1:
+            return fn()
+        out = fn() if rank == 0 else None
+        dist.barrier()
+        return out if rank == 0 else fn()
 
     # ------------------------------------------------------------------------------------------------ timing helpers
     def sync_all():
@@ -364,12 +488,31 @@ def main():
             self.gx, self.gu = torch.empty_like(self.xf), torch.empty_like(self.uf)
             self.loss = torch.zeros((), dtype=f64, device=dev)
 
-        def __call__(self, bufs=None):
+        def __call__(self, bufs=None, flags=8, stream=None):
             x_, u_, gx_, gu_ = bufs if bufs is not None else (self.xf, self.uf, self.gx, self.gu)
             _lib.check(L.hfem_tri3_energy_plan(self.plan.handle, x_.data_ptr(), self.xfix.data_ptr() if self.xfix.numel() else None,
                                                u_.data_ptr(), self.ufix.data_ptr() if self.ufix.numel() else None, self.mat,
                                                self.W, self.Bk, None, self.Tc, self.lo, self.hi, self.loss.data_ptr(),
-                                               gx_.data_ptr(), gu_.data_ptr(), 8, stream_box[0].cuda_stream), "hfem_tri3_energy_plan")
+                                               gx_.data_ptr(), gu_.data_ptr(), flags,
+                                               stream if stream is not None else stream_box[0].cuda_stream), "hfem_tri3_energy_plan")
+
+    class RotatingStep:
+        """The headline step (lagged loss sum and all) on R rotating parameter / gradient sets: step i reads set i mod R."""
+
+        def __init__(self, ko, sets):
+            self.ko, self.sets, self.i, self.lag = ko, sets, 0, False
+
+        def begin(self):
+            self.i, self.lag = 0, False
+
+        def __call__(self):
+            self.ko(self.sets[self.i % len(self.sets)], flags=8 | (32 if self.lag else 0), stream=torch.cuda.current_stream().cuda_stream)
+            self.i, self.lag = self.i + 1, True
+
+        def end(self):
+            _lib.check(L.hfem_plan_loss_sum(self.ko.plan.handle, self.ko.lo, self.ko.hi if self.ko.hi >= 0 else self.ko.plan.n_tiles,
+                                            self.ko.loss.data_ptr(), torch.cuda.current_stream().cuda_stream), "hfem_plan_loss_sum")
+            self.lag = False
 
     def range_work(plan, lo, hi):
         """(home elements, owned nodes, algorithmic bytes) of a launch over tiles [lo, hi)."""
@@ -409,7 +552,8 @@ def main():
     mesh6 = t1m_mesh(world)
     coords, conn, geom, bc, mn, edges = mesh6
     ne, nn = conn.shape[0], coords.shape[0]
-    model = build_model(mesh6)
+    t_plan0 = time.perf_counter()
+    model = staged(lambda: build_model(mesh6))
     loss_fn = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
     comm, comm_state = None, "none (N = 1)"
     if world > 1:
@@ -441,9 +585,17 @@ def main():
                 comm = None
                 comm_state = "torch.distributed nccl (in-library RCCL communicator failed its check on another rank)"
                 note(comm_state)
-    sh = ShardedTri3Energy(model, loss_fn, comm=comm)
+    sh = staged(lambda: ShardedTri3Energy(model, loss_fn, comm=comm))
     plan = sh.plan
     lo, hi = sh.lo, sh.hi
+    plan_cache_state = None
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, (getattr(model, "plan_cache", None), plan.cache))
+        plan_cache_state = dict(how="rank 0 builds each host plan and writes its blob, the other ranks deserialise it "
+                                    "(hfem_plan_serialize / hfem_plan_deserialize)",
+                                per_rank_model_plan_and_sharded_plan=got, blob_bytes=int(plan.to_bytes().size) if rank == 0 else None,
+                                model_and_plans_s=round(time.perf_counter() - t_plan0, 2))
 
     if world > 1:
         sh.setup_interfaces()
@@ -546,7 +698,7 @@ def main():
         ok = torch.tensor([1.0 if (st[0] == 0 and l_got == l_ref) else 0.0], dtype=f64, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() != 1.0:
-            sh_.close_peer_exchange()
+            sh_.close_peer_exchange(check=False)
             raise RuntimeError(f"{tag}: peer-window exchange disagrees with the collective path on some rank "
                                f"(this rank: status {st}, energy {l_got!r} vs {l_ref!r})")
 
@@ -582,14 +734,14 @@ def main():
             peer_legs = None
             peer_state = f"unavailable: {type(e).__name__}: {str(e)[:200]}"
             note("peer-window exchange " + peer_state)
-            sh.close_peer_exchange()
+            sh.close_peer_exchange(check=False)
         peer_on[0] = False
 
     # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
     def strong_leg(name, mesh6_s):
-        m_s = build_model(mesh6_s)
+        m_s = staged(lambda: build_model(mesh6_s))
         lf_s = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
-        sh_s = ShardedTri3Energy(m_s, lf_s, comm=comm)
+        sh_s = staged(lambda: ShardedTri3Energy(m_s, lf_s, comm=comm))
         sh_s.setup_interfaces()
         sh_s.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)
         ne_s, nn_s = mesh6_s[1].shape[0], mesh6_s[0].shape[0]
@@ -637,7 +789,7 @@ def main():
                 res["peer_exchange"]["status"] = sh_s.peer.status()[0]
             except Exception as e:  # noqa: BLE001
                 note(f"peer-window exchange on {name[:12]}: {type(e).__name__}: {str(e)[:160]}")
-            sh_s.close_peer_exchange()
+            sh_s.close_peer_exchange(check=False)
             peer_on[0] = False
         del sh_s, m_s, ko
         return res
@@ -689,6 +841,11 @@ def main():
             regimes["rotating_sets"] = dict(kernel_us=t_rot, kernel_us_regions=[round(v, 3) for v in rot_regions], wg_span_us=sp,
                                             launch_gap_us=gap, sets=R,
                                             working_set_mb=round(R * 4 * xf.numel() * 8 / 2 ** 20 + plan.stats["device_bytes"] / 2 ** 20, 1))
+            if not only and lagged:      # the WHOLE timed step (same K, same lagged loss sum, same bracketing) in this regime
+                rs = RotatingStep(ko_main, sets)
+                el_, regs_, ln_ = timed_steps(rs, a.steps, rs.begin, rs.end)
+                regimes["rotating_sets"]["step"] = dict(ms_per_step=el_ / a.steps * 1e3, value=ne / (el_ / a.steps), launch=ln_,
+                                                        ms_per_step_replays=[round(r_ / a.steps * 1e3, 6) for r_ in regs_])
             # for information: the same leg on a plan created with "store_policy" = 2 (nt gradient stores) -- what plans of
             # >= 750 k nodes take by default and what a caller whose T1M-sized buffers are NOT cache-resident should set
             try:
@@ -724,11 +881,14 @@ def main():
     # Cache are counted, so `traffic` is an UPPER bound on HBM bytes in the cache-resident regimes.
     prof = {}
     for fn in ("regimes_rocprof.json", "traffic.json"):
-        try:
-            with open(os.path.join(PROFILE_DIR, fn)) as f:
-                prof[fn] = json.load(f)
-        except (OSError, ValueError):
-            prof[fn] = {}
+        prof[fn] = {}
+        for d_ in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r03")):
+            try:
+                with open(os.path.join(d_, fn)) as f:
+                    prof[fn] = json.load(f)
+                break
+            except (OSError, ValueError):
+                pass
     shape_key = f"{ne}/{nn}/{plan.stats['n_tiles']}"
     traffic_tab = prof["traffic.json"].get("workloads", {})
     traffic = traffic_tab.get("T1M", {}).get("traffic_bytes_per_launch") if world == 1 and traffic_tab.get("T1M", {}).get("shape") == shape_key else None
@@ -757,19 +917,44 @@ def main():
             r["rocprof_kernel_us"] = rocprof_us[name]
             r["rocprof_frac"] = alg_bytes / (rocprof_us[name] * 1e-6) / 1e9 / HBM_PEAK_GBS
     kname = "tri3_energy_pair_kernel" if plan.is_paired() else "tri3_energy_fast_kernel"
-    top = regimes.get("rotating_sets")
-    if top is not None:
+    # counter traffic of the dominant kernel, measured IN THIS RUN when rocprofv3 is at hand: two child passes of this very
+    # script (--only-regime replayed) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes,
+    # MI355X_MICROARCH.md; gfx950: FETCH_SIZE x 2); else the committed passes of the same shape, labelled as such
+    traffic_kind = ("committed: FETCH_SIZE x2 + WRITE_SIZE of the rocprofv3 --pmc passes under profiles/ (same workload shape), "
+                    "not measured in this run") if traffic is not None else None
+    if world == 1 and not a.no_pmc and not a.no_regimes:
+        got, why = pmc_traffic_in_run(kname)
+        if got is not None:
+            traffic, traffic_kind = got["traffic_bytes_per_launch"], (
+                "measured in this run: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, two separate rocprofv3 --pmc child passes of "
+                f"`bench.py --only-regime replayed` ({got['launches']} launches of {kname}); requests on the L2's fabric side "
+                "(Infinity-Cache hits included): an upper bound on HBM bytes")
+            regimes.setdefault("replayed", {})["pmc"] = got
+        else:
+            note(f"in-run PMC traffic unavailable ({why}); roofline.traffic is the committed figure")
+    # ONE regime per line: the top level is the regime the timed headline step runs in (replayed: the same buffers every
+    # launch -- a 44 MB working set, Infinity-Cache resident, as in a training loop on this mesh), so kernel_us <= ms_per_step
+    # holds inside this object; the regime whose reads really come from HBM (rotating sets) sits beside it as `hbm_regime`,
+    # with the whole step timed there too (hbm_regime.step)
+    top = regimes.get("replayed")
+    if top is not None and "kernel_us" in top:
+        rot = regimes.get("rotating_sets")
         roofline = dict(bound="hbm", achieved=top["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=top["frac"], traffic=traffic,
-                        traffic_kind="FETCH_SIZE x2 + WRITE_SIZE of the committed rocprofv3 --pmc passes: requests on the L2's fabric "
-                                     "side (Infinity-Cache hits included); identical in the replayed and rotating regimes",
-                        kernel=kname, kernel_us=top["kernel_us"], kernel_us_regions=top.get("kernel_us_regions"),
-                        regime="rotating_sets: 10 parameter / gradient sets, 313 MB > the 256 MB Infinity Cache -- reads of x, u and "
-                               "the gradient lines go to HBM (the cache-resident leg the timed step runs in is regimes.replayed)",
-                        alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch, regimes=regimes)
+                        traffic_kind=traffic_kind, kernel=kname, kernel_us=top["kernel_us"],
+                        kernel_us_regions=[round(v, 3) for v in samples],
+                        regime="replayed: the same buffers every launch -- the regime the timed step (ms_per_step) runs in; the 44 MB "
+                               "working set is Infinity-Cache resident, so `achieved` is cache-fed algorithmic bandwidth held "
+                               "against the HBM peak; hbm_regime is the leg whose reads come from HBM",
+                        alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch,
+                        hbm_regime=None if rot is None else dict(
+                            regime=f"rotating_sets: {rot['sets']} parameter / gradient sets, {rot['working_set_mb']} MB > the 256 MB "
+                                   "Infinity Cache -- reads of x, u and the gradient lines go to HBM",
+                            kernel_us=rot["kernel_us"], achieved=rot["achieved"], frac=rot["frac"], step=rot.get("step")),
+                        regimes=regimes)
     else:
         achieved = alg_bytes / (k_us * 1e-6) / 1e9
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                        kernel=kname, kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
+                        traffic_kind=traffic_kind, kernel=kname, kernel_us=k_us, kernel_us_regions=[round(v, 3) for v in samples],
                         regime="replayed: the same buffers every launch (cache-resident working set)" + ("" if world == 1 else
                                "; this rank's tile range of the weak-scaling mesh"),
                         alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
@@ -1049,6 +1234,7 @@ def main():
         )
         if world > 1:
             out["config"]["collectives"] = comm_state
+            out["config"]["plan_cache"] = plan_cache_state
         if extras:
             out["config"]["extra"] = extras
         if inline_step is not None:
@@ -1088,6 +1274,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if cache_made:
+        import shutil
+        shutil.rmtree(cache_made, ignore_errors=True)
     return out
 
 

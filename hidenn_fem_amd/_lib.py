@@ -28,7 +28,7 @@ class PlanStats(C.Structure):
         ("max_tile_elems", _i32), ("max_tile_edges", _i32),
         ("device_bytes", _i64), ("lds_bytes", _i32),
         ("shards", _i32), ("threads_per_tile", _i32), ("paired", _i32), ("slot_rows", _i32),
-        ("store_policy", _i32), ("reserved0", _i32), ("row_line_factor", _f64),
+        ("store_policy", _i32), ("nodes_per_elem", _i32), ("row_line_factor", _f64),
     ]
 
     def as_dict(self):
@@ -53,6 +53,8 @@ PROTOTYPES = {
     "hfem_plan_destroy": (C.c_int, [_vp]),
     "hfem_plan_get_stats": (C.c_int, [_vp, C.POINTER(PlanStats)]),
     "hfem_plan_export": (_i64, [_vp, C.c_int, _vp, _i64]),
+    "hfem_plan_serialize": (_i64, [_vp, _vp, _i64]),
+    "hfem_plan_deserialize": (C.c_int, [C.c_int, _vp, _i64, C.POINTER(_vp)]),
     "hfem_tri3_energy_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_tri3_energy_plan_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "hfem_set_option": (C.c_int, [C.c_char_p, C.c_int]),

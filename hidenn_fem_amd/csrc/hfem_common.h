@@ -99,6 +99,10 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
                     int64_t ned, int32_t tile_elems, int32_t node_cap, int elem_order, int32_t chunk_cap,
                     HostPlan &out, int32_t pair_block = 256, int32_t shards = 1);
 
+// Plan blobs (hfem_plan_serialize / hfem_plan_deserialize): `trailer` = the launch options the plan captured (opaque here)
+void serialize_host_plan(const HostPlan &h, const void *trailer, size_t trailer_bytes, std::vector<unsigned char> &blob);
+int deserialize_host_plan(const void *blob, size_t n, HostPlan &h, void *trailer, size_t trailer_bytes);
+
 void set_plan_curve(int c);   // 0 Morton, 1 Hilbert (default)
 void set_plan_read_pack(int v);     // paired slots packed against ds_read_b128 bank conflicts as well (default 1)
 void set_plan_snap(int percent);   // tile cuts snap back to coarse curve-cell boundaries by up to this share of a tile (0 off)

@@ -975,17 +975,26 @@ int try_build(const int64_t *conn, int npe, int64_t ne, int64_t nn, const double
     P.shard_desc.clear();
     {
         std::vector<TileDesc> sorted_tiles;
+        std::vector<int32_t> sorted_chunks;          // per-tile records indexed by tile (chunked order) move with their tile
+        const bool has_chunks = P.tile_chunks.size() == (size_t)4 * nt;
         sorted_tiles.reserve(nt);
+        auto take = [&](int32_t t) {
+            sorted_tiles.push_back(P.tiles[t]);
+            if (has_chunks) sorted_chunks.insert(sorted_chunks.end(), P.tile_chunks.begin() + 4 * (size_t)t, P.tile_chunks.begin() + 4 * (size_t)t + 4);
+        };
         for (int32_t r = 0; r < shards; ++r) {
             const int32_t lo = (int32_t)(((int64_t)nt * r) / shards), hi = (int32_t)(((int64_t)nt * (r + 1)) / shards);
             for (int32_t t = lo; t < hi; ++t)
-                if (bnd[t]) sorted_tiles.push_back(P.tiles[t]);
+                if (bnd[t]) take(t);
             const int32_t mid = (int32_t)sorted_tiles.size();
             for (int32_t t = lo; t < hi; ++t)
-                if (!bnd[t]) sorted_tiles.push_back(P.tiles[t]);
+                if (!bnd[t]) take(t);
             P.shard_desc.insert(P.shard_desc.end(), {lo, mid, hi, 0});
         }
-        if (shards > 1) P.tiles.swap(sorted_tiles);
+        if (shards > 1) {
+            P.tiles.swap(sorted_tiles);
+            if (has_chunks) P.tile_chunks.swap(sorted_chunks);
+        }
     }
     // owned node ids in (final tile order, local order): every node exactly once -- the TILE-MAJOR node order a caller can store
     // its parameter rows in (hfem_plan_export 11; hidenn_fem_amd/models.py reorder="tile")
@@ -1122,6 +1131,132 @@ int build_host_plan(const int64_t *conn, int npe, int64_t ne, int64_t nn, const 
     }
     set_error("plan: could not fit a tile into 1024 local nodes / element slots (node valence too high?)");
     return -1;
+}
+
+// ---- plan blobs ----------------------------------------------------------------------------------------------------
+// A HostPlan as ONE relocatable byte string (hfem_plan_serialize / hfem_plan_deserialize): a planner run costs ~1 s per
+// 10^6 elements, and the ranks of a multi-GPU job (or repeated runs on one mesh) all need the same plan -- one builds,
+// the others load.  Layout: "HFEMPLAN", format version, the scalar fields, every array as {count, bytes padded to 8},
+// the caller's trailer (launch options of the plan), and an FNV-1a checksum of everything before it.  Native endianness
+// (a blob is a cache entry of one machine, not an interchange format).
+namespace {
+constexpr uint32_t kBlobVersion = 1;
+struct BlobScalars {
+    int64_t ne, nn, ned, elem_records, node_records, n_pairs, n_chained;
+    int32_t tile_elems, npe, node_stride, elem_stride, col_stride, max_nodes, max_owned, max_elems, max_edges, max_rows,
+        max_chunk_elems, shards, pair_block, paired;
+};
+uint64_t fnv1a(const unsigned char *p, size_t n) {
+    // 8 bytes per step (a word-wise variant of FNV-1a): a corruption check, not a cryptographic hash
+    uint64_t h = 1469598103934665603ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 1099511628211ull;
+    }
+    for (; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+template <typename T>
+void put_vec(std::vector<unsigned char> &b, const std::vector<T> &v) {
+    const uint64_t n = v.size();
+    const size_t nb = (size_t)n * sizeof(T), at = b.size();
+    b.resize(at + 8 + ((nb + 7) & ~(size_t)7), 0);
+    std::memcpy(b.data() + at, &n, 8);
+    if (nb) std::memcpy(b.data() + at + 8, v.data(), nb);
+}
+template <typename T>
+bool get_vec(const unsigned char *p, size_t n, size_t &at, std::vector<T> &v) {
+    if (at + 8 > n) return false;
+    uint64_t cnt;
+    std::memcpy(&cnt, p + at, 8);
+    if (cnt > (n - at - 8) / sizeof(T)) return false;
+    const size_t nb = (size_t)cnt * sizeof(T);
+    v.resize((size_t)cnt);
+    if (nb) std::memcpy(v.data(), p + at + 8, nb);
+    at += 8 + ((nb + 7) & ~(size_t)7);
+    return at <= n;
+}
+}  // namespace
+
+void serialize_host_plan(const HostPlan &h, const void *trailer, size_t trailer_bytes, std::vector<unsigned char> &b) {
+    b.clear();
+    b.insert(b.end(), {'H', 'F', 'E', 'M', 'P', 'L', 'A', 'N'});
+    const uint32_t head[2] = {kBlobVersion, (uint32_t)trailer_bytes};
+    b.insert(b.end(), (const unsigned char *)head, (const unsigned char *)head + 8);
+    BlobScalars sc{};
+    sc.ne = h.ne; sc.nn = h.nn; sc.ned = h.ned; sc.elem_records = h.elem_records; sc.node_records = h.node_records;
+    sc.n_pairs = h.n_pairs; sc.n_chained = h.n_chained; sc.tile_elems = h.tile_elems; sc.npe = h.npe;
+    sc.node_stride = h.node_stride; sc.elem_stride = h.elem_stride; sc.col_stride = h.col_stride; sc.max_nodes = h.max_nodes;
+    sc.max_owned = h.max_owned; sc.max_elems = h.max_elems; sc.max_edges = h.max_edges; sc.max_rows = h.max_rows;
+    sc.max_chunk_elems = h.max_chunk_elems; sc.shards = h.shards; sc.pair_block = h.pair_block; sc.paired = h.paired ? 1 : 0;
+    b.insert(b.end(), (const unsigned char *)&sc, (const unsigned char *)&sc + sizeof(sc));
+    b.resize((b.size() + 7) & ~(size_t)7, 0);
+    std::vector<int32_t> td((const int32_t *)h.tiles.data(), (const int32_t *)h.tiles.data() + 8 * h.tiles.size());
+    put_vec(b, td);
+    put_vec(b, h.elem_pack); put_vec(b, h.elem_pack_hi); put_vec(b, h.elem_gid); put_vec(b, h.elem_gid_b);
+    put_vec(b, h.node_src); put_vec(b, h.edge_pack); put_vec(b, h.edge_gid); put_vec(b, h.tile_chunks);
+    put_vec(b, h.conn32); put_vec(b, h.x_src_g); put_vec(b, h.u_src_g); put_vec(b, h.edges32);
+    put_vec(b, h.shard_desc); put_vec(b, h.owned_gid);
+    const size_t at = b.size();
+    b.resize(at + ((trailer_bytes + 7) & ~(size_t)7), 0);
+    if (trailer_bytes) std::memcpy(b.data() + at, trailer, trailer_bytes);
+    const uint64_t sum = fnv1a(b.data(), b.size());
+    b.insert(b.end(), (const unsigned char *)&sum, (const unsigned char *)&sum + 8);
+}
+
+int deserialize_host_plan(const void *blob, size_t n, HostPlan &h, void *trailer, size_t trailer_bytes) {
+    const unsigned char *p = (const unsigned char *)blob;
+    if (!p || n < 24 + sizeof(BlobScalars) || std::memcmp(p, "HFEMPLAN", 8) != 0) { set_error("plan blob: not a plan blob"); return -1; }
+    uint32_t head[2];
+    std::memcpy(head, p + 8, 8);
+    if (head[0] != kBlobVersion) { set_error("plan blob: written by another format version"); return -1; }
+    if (head[1] != trailer_bytes) { set_error("plan blob: written by another library version (trailer size)"); return -1; }
+    uint64_t sum;
+    std::memcpy(&sum, p + n - 8, 8);
+    if (sum != fnv1a(p, n - 8)) { set_error("plan blob: checksum mismatch (truncated or corrupted)"); return -1; }
+    size_t at = 16;
+    BlobScalars sc;
+    std::memcpy(&sc, p + at, sizeof(sc));
+    at = (at + sizeof(sc) + 7) & ~(size_t)7;
+    h = HostPlan();
+    h.ne = sc.ne; h.nn = sc.nn; h.ned = sc.ned; h.elem_records = sc.elem_records; h.node_records = sc.node_records;
+    h.n_pairs = sc.n_pairs; h.n_chained = sc.n_chained; h.tile_elems = sc.tile_elems; h.npe = sc.npe;
+    h.node_stride = sc.node_stride; h.elem_stride = sc.elem_stride; h.col_stride = sc.col_stride; h.max_nodes = sc.max_nodes;
+    h.max_owned = sc.max_owned; h.max_elems = sc.max_elems; h.max_edges = sc.max_edges; h.max_rows = sc.max_rows;
+    h.max_chunk_elems = sc.max_chunk_elems; h.shards = sc.shards; h.pair_block = sc.pair_block; h.paired = sc.paired != 0;
+    std::vector<int32_t> td;
+    bool ok = get_vec(p, n - 8, at, td) && td.size() % 8 == 0;
+    ok = ok && get_vec(p, n - 8, at, h.elem_pack) && get_vec(p, n - 8, at, h.elem_pack_hi) && get_vec(p, n - 8, at, h.elem_gid) &&
+         get_vec(p, n - 8, at, h.elem_gid_b) && get_vec(p, n - 8, at, h.node_src) && get_vec(p, n - 8, at, h.edge_pack) &&
+         get_vec(p, n - 8, at, h.edge_gid) && get_vec(p, n - 8, at, h.tile_chunks) && get_vec(p, n - 8, at, h.conn32) &&
+         get_vec(p, n - 8, at, h.x_src_g) && get_vec(p, n - 8, at, h.u_src_g) && get_vec(p, n - 8, at, h.edges32) &&
+         get_vec(p, n - 8, at, h.shard_desc) && get_vec(p, n - 8, at, h.owned_gid);
+    ok = ok && at + ((trailer_bytes + 7) & ~(size_t)7) == n - 8;
+    if (!ok) { set_error("plan blob: malformed"); return -1; }
+    h.tiles.resize(td.size() / 8);
+    if (!td.empty()) std::memcpy((void *)h.tiles.data(), td.data(), td.size() * 4);
+    if (trailer_bytes) std::memcpy(trailer, p + at, trailer_bytes);
+    // structural checks a kernel relies on: the blob passed its checksum, but it may come from a build with other limits
+    const size_t nt = h.tiles.size();
+    if ((h.npe != 3 && h.npe != 4) || h.node_stride < 0 || h.elem_stride < 0 || h.max_nodes > kMaxLocal ||
+        h.node_src.size() < 2 * (nt * (size_t)h.node_stride) || h.elem_pack.size() < nt * (size_t)h.elem_stride ||
+        ((h.npe == 4 || h.paired) && h.elem_pack_hi.size() != h.elem_pack.size()) || (int64_t)h.conn32.size() != h.npe * h.ne ||
+        (int64_t)h.x_src_g.size() != h.nn || (int64_t)h.u_src_g.size() != h.nn || (int64_t)h.edges32.size() != 2 * h.ned ||
+        h.shard_desc.size() != 4 * (size_t)std::max(1, h.shards)) {
+        set_error("plan blob: inconsistent array sizes");
+        return -1;
+    }
+    for (const TileDesc &d : h.tiles)
+        if (d.n_node < 0 || d.n_node > h.max_nodes || d.n_owned < 0 || d.n_owned > d.n_node || d.n_elem < 0 || d.n_elem > h.max_elems ||
+            d.node_off < 0 || (size_t)d.node_off + d.n_node > h.node_src.size() / 2 || d.elem_off < 0 ||
+            (size_t)d.elem_off + d.n_elem > h.elem_pack.size() || d.n_edge < 0 || d.edge_off < 0 ||
+            (size_t)d.edge_off + d.n_edge > h.edge_pack.size()) {
+            set_error("plan blob: tile descriptor out of range");
+            return -1;
+        }
+    return 0;
 }
 
 }  // namespace hfem

@@ -666,6 +666,36 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
     return 0;
 }
 
+namespace {
+// LDS footprint + device mirrors of a complete host plan (shared by hfem_plan_create_ex and hfem_plan_deserialize).
+int finalize_plan(std::unique_ptr<hfem_plan> &p, int device) {
+    const HostPlan &h = p->host;
+    p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
+    p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
+    if (device >= 0) {
+        if (int rc = use_device(device)) return rc;
+        p->device = device;
+        hfem_plan *raw = p.get();
+        int rc = 0;
+        if (!rc) rc = hfem_upload(&raw->d_tiles, h.tiles.data(), h.tiles.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_elem_pack, h.elem_pack.data(), h.elem_pack.size(), raw->device_bytes);
+        if (!rc && (h.npe == 4 || h.paired)) rc = hfem_upload(&raw->d_elem_pack_hi, h.elem_pack_hi.data(), h.elem_pack_hi.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
+        if (!rc && !h.tile_chunks.empty()) rc = hfem_upload(&raw->d_tile_chunks, h.tile_chunks.data(), h.tile_chunks.size() / 4, raw->device_bytes);
+        if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
+        HFEM_LAB_UPLOAD_STAMPS(raw, h, rc)
+        if (!rc && p->lds_bytes > 64 * 1024) {
+            set_error("plan: tile needs more than 64 KiB of LDS");
+            rc = -1;
+        }
+        if (rc) { hfem_plan_destroy(p.release()); return rc; }
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" int hfem_plan_create(int device, const int64_t *conn, int64_t ne, int64_t nn,
                                 const double *coords_hint, const int32_t *x_src, const int32_t *u_src,
                                 const int64_t *edges, int64_t ned, int32_t tile_elems, hfem_plan **out) {
@@ -757,28 +787,44 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
         p->row_line_factor = cnt ? acc / (double)cnt : 1.0;
     }
     if (auto_store && p->tune.store_policy == 2 && p->row_line_factor > 2.5) p->tune.store_policy = 16;
-    p->lds_bytes = h.max_nodes * 32 + h.max_owned * 32 + 128;
-    p->lds_bytes_pipe = p->lds_bytes + 32 * kPipeMaxTiles + (h.npe == 4 ? 8 : 4) * ((h.max_elems + 3) & ~3);
-    if (device >= 0) {
-        if (int rc = use_device(device)) return rc;
-        p->device = device;
-        hfem_plan *raw = p.get();
-        int rc = 0;
-        if (!rc) rc = hfem_upload(&raw->d_tiles, h.tiles.data(), h.tiles.size(), raw->device_bytes);
-        if (!rc) rc = hfem_upload(&raw->d_elem_pack, h.elem_pack.data(), h.elem_pack.size(), raw->device_bytes);
-        if (!rc && (h.npe == 4 || h.paired)) rc = hfem_upload(&raw->d_elem_pack_hi, h.elem_pack_hi.data(), h.elem_pack_hi.size(), raw->device_bytes);
-        if (!rc) rc = hfem_upload(&raw->d_node_src, h.node_src.data(), h.node_src.size() / 2, raw->device_bytes);
-        if (!rc) rc = hfem_upload(&raw->d_edge_pack, h.edge_pack.data(), h.edge_pack.size(), raw->device_bytes);
-        if (!rc) rc = hfem_upload(&raw->d_edge_gid, h.edge_gid.data(), h.edge_gid.size(), raw->device_bytes);
-        if (!rc && !h.tile_chunks.empty()) rc = hfem_upload(&raw->d_tile_chunks, h.tile_chunks.data(), h.tile_chunks.size() / 4, raw->device_bytes);
-        if (!rc) rc = hfem_upload(&raw->d_partials, nullptr, 2 * h.tiles.size(), raw->device_bytes);   // two banks
-        HFEM_LAB_UPLOAD_STAMPS(raw, h, rc)
-        if (!rc && p->lds_bytes > 64 * 1024) {
-            set_error("plan: tile needs more than 64 KiB of LDS");
-            rc = -1;
-        }
-        if (rc) { hfem_plan_destroy(p.release()); return rc; }
+    if (int rc = finalize_plan(p, device)) return rc;
+    *out = p.release();
+    return 0;
+}
+
+namespace {
+struct PlanTrailer {   // what hfem_plan_create decided besides the HostPlan: travels in the blob's trailer
+    int32_t tiled_block, store_policy, tiled_fast, fast_const_caps, pair_tiles_per_wg, pair_pipe_wps;
+    int32_t hfem_version, reserved;
+    double row_line_factor;
+};
+}  // namespace
+
+extern "C" int64_t hfem_plan_serialize(const hfem_plan *plan, void *buf, int64_t cap_bytes) {
+    if (!plan) { set_error("hfem_plan_serialize: null plan"); return -1; }
+    PlanTrailer t{plan->tune.tiled_block, plan->tune.store_policy, plan->tune.tiled_fast, plan->tune.fast_const_caps,
+                  plan->tune.pair_tiles_per_wg, plan->tune.pair_pipe_wps, HFEM_VERSION, 0, plan->row_line_factor};
+    std::vector<unsigned char> blob;
+    serialize_host_plan(plan->host, &t, sizeof(t), blob);
+    if (buf) {
+        if (cap_bytes < (int64_t)blob.size()) { set_error("hfem_plan_serialize: buffer too small"); return -1; }
+        std::memcpy(buf, blob.data(), blob.size());
     }
+    return (int64_t)blob.size();
+}
+
+extern "C" int hfem_plan_deserialize(int device, const void *blob, int64_t n_bytes, hfem_plan **out) {
+    HFEM_ARG_CHECK(out, "null out pointer");
+    *out = nullptr;
+    HFEM_ARG_CHECK(blob && n_bytes > 0, "empty blob");
+    std::unique_ptr<hfem_plan> p(new hfem_plan);
+    PlanTrailer t{};
+    if (deserialize_host_plan(blob, (size_t)n_bytes, p->host, &t, sizeof(t))) return -1;
+    HFEM_ARG_CHECK(t.hfem_version == HFEM_VERSION, "plan blob written by another library version: rebuild the plan");
+    p->tune.tiled_block = t.tiled_block; p->tune.store_policy = t.store_policy; p->tune.tiled_fast = t.tiled_fast;
+    p->tune.fast_const_caps = t.fast_const_caps; p->tune.pair_tiles_per_wg = t.pair_tiles_per_wg; p->tune.pair_pipe_wps = t.pair_pipe_wps;
+    p->row_line_factor = t.row_line_factor;
+    if (int rc = finalize_plan(p, device)) return rc;
     *out = p.release();
     return 0;
 }
@@ -801,6 +847,7 @@ extern "C" int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out) 
     out->paired = h.paired ? 1 : 0;
     out->slot_rows = h.paired ? h.max_rows : 0;
     out->store_policy = plan->tune.store_policy;
+    out->nodes_per_elem = h.npe;
     out->row_line_factor = plan->row_line_factor;
     return 0;
 }

@@ -23,11 +23,15 @@ class GraphedTraining:
     ``optimizer.zero_grad(set_to_none=False); loss = closure(); loss.backward(); optimizer.step()``."""
 
     def __init__(self, closure: Callable[[], torch.Tensor], optimizer: torch.optim.Optimizer, steps_per_replay: int = 1,
-                 warmup: int = 3, direct: bool = False, begin: Callable[[], None] = None, end: Callable[[], None] = None):
+                 warmup: int = 3, direct: bool = False, begin: Callable[[], None] = None, end: Callable[[], None] = None,
+                 check: Callable[[], None] = None):
         """``direct=True``: ``closure`` itself leaves the gradients in ``.grad`` (``EnergyLoss2D.value_and_grad_``):
-        an iteration is ``loss = closure(); optimizer.step()`` -- no ``zero_grad``, no autograd."""
+        an iteration is ``loss = closure(); optimizer.step()`` -- no ``zero_grad``, no autograd.  ``check``: a callable that
+        raises when the replayed work went wrong in a way only the device knows (``ShardedTri3Energy.check_exchange``: a
+        peer-window get that timed out); ``synchronize()`` runs it, ``replay()`` stays asynchronous."""
         self.closure, self.optimizer, self.steps_per_replay = closure, optimizer, int(steps_per_replay)
         self.direct = direct
+        self._check = check
         self._begin, self._end = begin or (lambda: None), end or (lambda: None)   # bracket every sequence of iterations
         if optimizer is None and not direct:
             raise ValueError("optimizer=None needs direct=True (a closure that also updates the parameters)")
@@ -78,4 +82,11 @@ class GraphedTraining:
         for _ in range(n):
             self.graph.replay()
         self.steps_done += n * self.steps_per_replay
+        return self.loss
+
+    def synchronize(self) -> torch.Tensor:
+        """Wait for the replays issued so far and run the ``check`` callable (if any); returns the loss tensor."""
+        torch.cuda.synchronize()
+        if self._check is not None:
+            self._check()
         return self.loss

@@ -279,7 +279,7 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
         fm, um = _np_mask(free_mask), _np_mask(u_free_mask)
         # ---- storage order of the parameter rows (see the docstring): node ids of the free rows, in row order
         idx_free, idx_ufree = np.nonzero(fm)[0], np.nonzero(um)[0]
-        self.row_order, self.row_line_factor = "as given", None
+        self.row_order, self.row_line_factor, self.plan_cache = "as given", None, None
         if reorder != "off" and self.Nnodes >= 2:
             from .mesh import _hilbert_keys
             curve = np.argsort(_hilbert_keys(node_coords.detach().cpu().double().numpy()), kind="stable")   # node ids along the curve
@@ -296,6 +296,7 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
                 hp = TilePlan(connectivity, self.Nnodes, coords_hint=node_coords, edges=neumann_edges, device=None,
                               nodes_per_elem=connectivity.shape[1])
                 tm = hp.export("owned_node_ids").astype(np.int64)
+                self.plan_cache = hp.cache                    # "hit" / "miss" under $HFEM_PLAN_CACHE, else None
                 hp.close()
                 idx_free, idx_ufree = tm[fm[tm]], tm[um[tm]]
                 self.row_order = "tile"
@@ -336,6 +337,7 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
             self.register_load_state_dict_pre_hook(TriangularShapeNN2D._state_from_caller_order)
         else:
             self._perm_x = self._perm_u = None
+        self._tag_parameters()
         self.register_buffer("_conn32", connectivity.to(torch.int32).contiguous(), persistent=False)
         e32 = (neumann_edges if neumann_edges is not None else torch.zeros((0, 2), dtype=torch.long))
         self.register_buffer("_edges32", e32.to(torch.int32).contiguous(), persistent=False)
@@ -352,6 +354,31 @@ class TriangularShapeNN2D(PiecewiseLinearShapeNN2D):
     def __setstate__(self, state):
         super().__setstate__(state)
         self.__dict__.setdefault("_plans", {})
+        self._tag_parameters()
+
+    def _tag_parameters(self):
+        """The row permutation travels WITH the parameter objects, so that an optimiser can convert its state without knowing
+        the model (``hidenn_fem_amd.optim.caller_order_hooks``)."""
+        self.node_coords_free._hfem_caller_perm = self._perm_x
+        self.u_free._hfem_caller_perm = self._perm_u
+
+    def attach_optimizer(self, optimizer):
+        """``optimizer.state_dict()`` / ``load_state_dict()`` then speak the reference's row order (Adam moments, L-BFGS
+        history): REQUIRED for any ``torch.optim`` optimiser whose checkpoints cross row orders -- written by the reference,
+        by a ``reorder="off"`` model, or by a build with other tile defaults -- since a state dict in the wrong order loads
+        without an error (same shapes).  ``FusedAdam`` / ``FusedLBFGS`` do it themselves.  Returns the optimiser."""
+        from .optim import caller_order_hooks
+        return caller_order_hooks(optimizer)
+
+    def grad_in_caller_order(self):
+        """``{"node_coords_free": grad, "u_free": grad}`` with rows as the reference indexes them
+        (``node_coords[free_mask]`` order, models.py:260); ``None`` where no gradient exists.  The raw ``param.grad`` tensors
+        are in STORAGE order (tile-major for meshes of >= 4096 nodes)."""
+        out = {}
+        for name, which in (("node_coords_free", "x"), ("u_free", "u")):
+            g = getattr(self, name).grad
+            out[name] = None if g is None else self.to_caller_order(g, which)
+        return out
 
     # -- storage order of the parameter rows <-> the caller's numbering ----------------------
     def to_caller_order(self, t: torch.Tensor, which: str = "x") -> torch.Tensor:

@@ -13,6 +13,82 @@ from . import _lib
 from ._lib import check, ptr, require_gpu_tensor, stream_ptr, dev_index
 
 
+# ---- row order of optimiser state --------------------------------------------------------------------------------
+# Triangular models of >= 4096 nodes store node_coords_free / u_free TILE-MAJOR (models.py, reorder="auto"): row j of the
+# parameter is row perm[j] of the reference's layout (node_coords[free_mask], src/models.py:260).  model.state_dict() speaks
+# the reference's order through hooks; an optimiser's state (Adam moments, L-BFGS history vectors) has the parameters' shapes,
+# so a checkpoint written in one order loads into the other WITHOUT an error and with every moment on the wrong row.  The
+# two hooks below make optimizer.state_dict() / load_state_dict() speak the caller's order as well; FusedAdam and
+# FusedLBFGS install them on themselves, `model.attach_optimizer(opt)` / `caller_order_hooks(opt)` installs them on any
+# torch.optim optimiser.
+
+def _row_perm(p):
+    """Storage row j of parameter ``p`` <-> caller row perm[j] (None: stored as the caller numbers it)."""
+    return getattr(p, "_hfem_caller_perm", None)
+
+
+def _convert_state(optimizer, sd, to_caller):
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    ids = [i for g in sd["param_groups"] for i in g["params"]]
+    if len(ids) != len(params) or all(_row_perm(p) is None for p in params):
+        return sd
+    sizes = [p.numel() for p in params]
+    total = sum(sizes)
+
+    def rows(t, p):                                     # a tensor shaped like the parameter
+        perm = _row_perm(p).to(t.device)
+        if to_caller:
+            out = torch.empty_like(t)
+            out[perm] = t
+            return out
+        return t[perm]
+
+    def flat(t):                                        # a flat vector over ALL parameters (torch.optim.LBFGS: d, old_dirs, ...)
+        out, off = [], 0
+        for p, n in zip(params, sizes):
+            seg = t[off:off + n]
+            out.append(seg if _row_perm(p) is None else rows(seg.view(p.shape), p).reshape(-1))
+            off += n
+        return torch.cat(out)
+
+    def conv(v, p):
+        if torch.is_tensor(v):
+            if v.shape == p.shape and _row_perm(p) is not None:
+                return rows(v, p)
+            if v.dim() == 1 and v.numel() == total and total != p.shape[0]:
+                return flat(v)
+            return v
+        if isinstance(v, (list, tuple)):
+            return type(v)(conv(x, p) for x in v)
+        return v
+
+    by_id = dict(zip(ids, params))
+    out = dict(sd)
+    out["state"] = {k: ({name: conv(v, by_id[k]) for name, v in st.items()} if k in by_id else st)
+                    for k, st in sd["state"].items()}
+    return out
+
+
+def _state_dict_to_caller_order(optimizer, sd):
+    return _convert_state(optimizer, sd, True)
+
+
+def _state_dict_from_caller_order(optimizer, sd):
+    return _convert_state(optimizer, sd, False)
+
+
+def caller_order_hooks(optimizer):
+    """Make ``optimizer.state_dict()`` / ``optimizer.load_state_dict()`` speak the reference's row order for parameters a
+    model stores tile-major: a checkpoint of ``torch.optim.Adam`` / ``LBFGS`` state written by the reference, by a
+    ``reorder="off"`` model or by a build with other tile defaults then continues the same trajectory.  Idempotent; returns
+    the optimiser.  (``FusedAdam`` / ``FusedLBFGS`` call it on themselves.)"""
+    if not getattr(optimizer, "_hfem_caller_order_hooks", False):
+        optimizer.register_state_dict_post_hook(_state_dict_to_caller_order)
+        optimizer.register_load_state_dict_pre_hook(_state_dict_from_caller_order)
+        optimizer._hfem_caller_order_hooks = True
+    return optimizer
+
+
 class FusedAdam(torch.optim.Optimizer):
     """``capturable=True``: the step count lives on the device, so ``step()`` can be captured in a hipGraph
     (``hidenn_fem_amd.graphed.GraphedTraining``); the arithmetic is the same.  State layout: ``exp_avg``,
@@ -32,6 +108,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = capturable
         self._step_dev = None
+        caller_order_hooks(self)             # state_dict() / load_state_dict() in the reference's row order (tile-major models)
 
     def init_state(self):
         """Allocate moments, the step counter of every parameter and the pointer-table buffers now (idempotent)."""
@@ -233,6 +310,7 @@ class FusedLBFGS(torch.optim.Optimizer):
         self._h = None
         import ctypes as C
         self._status = (C.c_double * 8)()
+        caller_order_hooks(self)
 
     def __del__(self):
         try:

@@ -8,6 +8,9 @@ replace the bool-mask assembly of ``models.py:292-305``.
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import os
+import tempfile
 from typing import Optional
 
 import numpy as np
@@ -18,6 +21,11 @@ from . import _lib
 EXPORT_IDS = {"tile_desc": 0, "elem_pack": 1, "node_src": 2, "edge_pack": 3, "edge_gid": 4, "elem_gid": 5,
               "stamps": 6, "elem_pack_hi": 7, "tile_chunks": 8, "elem_gid_b": 9, "shard_desc": 10,
               "owned_node_ids": 11}
+
+
+# every hfem_set_option name that changes what hfem_plan_create builds (part of the cache key)
+_PLAN_OPTIONS = (b"plan_elem_order", b"plan_node_cap", b"plan_shards", b"plan_pair_block", b"plan_chunk_cap", b"plan_curve",
+                 b"plan_snap", b"plan_read_pack", b"tiled_block", b"store_policy", b"tiled_fast", b"fast_const_caps")
 
 
 def _np(a, dtype):
@@ -44,10 +52,13 @@ class TilePlan:
     def __init__(self, connectivity, n_nodes: int, coords_hint=None, x_src=None, u_src=None,
                  edges=None, tile_elems: int = 0, device: Optional[torch.device] = None,
                  elem_order: Optional[int] = None, nodes_per_elem: int = 3, shards: int = 1,
-                 pair_block: Optional[int] = None):
+                 pair_block: Optional[int] = None, cache_dir: Optional[str] = None):
         """``shards``: number of ranks the tiles will be split over (``shard_range`` / ``shard_parts``): the library sizes
         the tiles for the elements PER RANK and puts every rank's boundary tiles first in its range (``plan_shards``).
-        ``pair_block``: threads per tile of a paired plan, 256 or 512 (``None``: the library's shard-aware policy)."""
+        ``pair_block``: threads per tile of a paired plan, 256 or 512 (``None``: the library's shard-aware policy).
+        ``cache_dir`` (default: ``$HFEM_PLAN_CACHE``, else none): directory of plan blobs keyed by a hash of every planner
+        input and option -- the first process to need a plan builds it and writes the blob (atomically), every other rank
+        / later run deserialises it (``hfem_plan_deserialize``: seconds of host work per 10^6 elements saved)."""
         if nodes_per_elem not in (3, 4):
             raise ValueError("nodes_per_elem must be 3 (TRI3) or 4 (QUAD4)")
         self.nodes_per_elem = nodes_per_elem
@@ -74,26 +85,93 @@ class TilePlan:
         # creation-time defaults of the library: set, create, restore
         wanted = {b"plan_elem_order": elem_order, b"plan_shards": int(shards) if int(shards) != 1 else None,
                   b"plan_pair_block": pair_block}
-        prev = {}
-        try:
-            for name, val in wanted.items():
-                if val is not None:
-                    prev[name] = L.hfem_get_option(name)
-                    _lib.check(L.hfem_set_option(name, int(val)), "hfem_set_option")
-            rc = L.hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
-                                       p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
-        finally:
-            for name, val in prev.items():
-                L.hfem_set_option(name, val)
-        _lib.check(rc, "hfem_plan_create")
+        cache_dir = cache_dir if cache_dir is not None else os.environ.get("HFEM_PLAN_CACHE") or None
+        self.cache = None                      # "hit" / "miss" when a cache directory is in use
+        blob_path = None
+        if cache_dir:
+            # every planner input and every option that shapes a plan goes into the key (a stale hit is impossible by
+            # construction; the blob also carries the library version and a checksum of its own)
+            hsh = hashlib.blake2b(digest_size=20)
+            opts = {n: L.hfem_get_option(n) for n in _PLAN_OPTIONS}
+            opts.update({k: int(v) for k, v in wanted.items() if v is not None})
+            hsh.update(repr((L.hfem_version(), self.n_nodes, self.n_elems, nodes_per_elem, int(tile_elems),
+                             sorted(opts.items()))).encode())
+            for a_ in (conn, hint, xs, us, ed):
+                hsh.update(b"-" if a_ is None else memoryview(a_).cast("B"))
+            blob_path = os.path.join(cache_dir, f"plan_{hsh.hexdigest()}.bin")
+            if os.path.exists(blob_path):
+                try:
+                    self._load_blob(np.fromfile(blob_path, dtype=np.uint8), dev)
+                    self.cache = "hit"
+                except RuntimeError:
+                    self._h = C.c_void_p()     # unreadable entry (another version, a torn write): rebuild below
+        if not self._h:
+            prev = {}
+            try:
+                for name, val in wanted.items():
+                    if val is not None:
+                        prev[name] = L.hfem_get_option(name)
+                        _lib.check(L.hfem_set_option(name, int(val)), "hfem_set_option")
+                rc = L.hfem_plan_create_ex(dev, p(conn), self.n_elems, self.n_nodes, nodes_per_elem, p(hint), p(xs),
+                                           p(us), p(ed), self.n_edges, int(tile_elems), C.byref(self._h))
+            finally:
+                for name, val in prev.items():
+                    L.hfem_set_option(name, val)
+            _lib.check(rc, "hfem_plan_create")
+            if blob_path is not None:
+                self.cache = "miss"
+                os.makedirs(cache_dir, exist_ok=True)
+                fd, tmp = tempfile.mkstemp(dir=cache_dir, suffix=".tmp")
+                try:
+                    with os.fdopen(fd, "wb") as f:
+                        self.to_bytes().tofile(f)
+                    os.replace(tmp, blob_path)             # atomic: a reader sees the whole blob or none
+                except OSError:
+                    try:
+                        os.unlink(tmp)
+                    except OSError:
+                        pass
+        self._finish_init()
+
+    def _finish_init(self):
         st = _lib.PlanStats()
         _lib.check(_lib.lib().hfem_plan_get_stats(self._h, C.byref(st)), "hfem_plan_get_stats")
         self.stats = st.as_dict()
         self.n_tiles = self.stats["n_tiles"]
+        self.n_nodes, self.n_elems, self.n_edges = self.stats["n_nodes"], self.stats["n_elems"], self.stats["n_edges"]
+        self.nodes_per_elem = self.stats["nodes_per_elem"]
 
     @property
     def handle(self):
         return self._h
+
+    # ---- plan blobs: build once, load everywhere (hfem_plan_serialize / hfem_plan_deserialize) ----
+    def to_bytes(self) -> np.ndarray:
+        """The plan as one ``uint8`` array: host plan + creation-time decisions + checksum."""
+        L = _lib.lib()
+        n = L.hfem_plan_serialize(self._h, None, 0)
+        if n < 0:
+            _lib.check(-1, "hfem_plan_serialize")
+        out = np.empty(int(n), dtype=np.uint8)
+        if L.hfem_plan_serialize(self._h, out.ctypes.data_as(C.c_void_p), n) != n:
+            _lib.check(-1, "hfem_plan_serialize")
+        return out
+
+    def _load_blob(self, blob: np.ndarray, dev: int):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().hfem_plan_deserialize(dev, blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(self._h)),
+                   "hfem_plan_deserialize")
+
+    @classmethod
+    def from_bytes(cls, blob, device: Optional[torch.device] = None) -> "TilePlan":
+        """A plan from ``to_bytes()`` output (any process, any device; ``device=None`` -> host-only)."""
+        self = cls.__new__(cls)
+        self.device, self.cache = device, None
+        self._load_blob(np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob,
+                        -1 if device is None else _lib.dev_index(device))
+        self._finish_init()
+        return self
 
     def export(self, name: str) -> np.ndarray:
         which = EXPORT_IDS[name]

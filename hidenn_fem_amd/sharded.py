@@ -370,19 +370,44 @@ class ShardedTri3Energy:
                 self.inkernel_get = False              # default: fall back to the get as a launch of its own
         return self
 
-    def close_peer_exchange(self):
-        """Back to the collective path: detach the in-launch get from the plan (it holds a pointer into the windows' device
-        memory), then free / unmap the windows.  Collective in effect: every rank must have finished its last get."""
+    def close_peer_exchange(self, barrier: bool = True, check: bool = True):
+        """Back to the collective path: join the exchange in flight, read the windows' status (a get that timed out raises HERE
+        at the latest -- after the clean-up, on every rank that saw it), detach the in-launch get from the plan (it holds a
+        pointer into the windows' device memory), then free / unmap the windows.  COLLECTIVE (``barrier=True``): a peer's last
+        put may still be storing into this rank's window, so every rank synchronises its device and meets in a group barrier
+        before any window is unmapped; ``barrier=False`` only for a rank that is going away alone (``__del__``)."""
         if self.peer is None:
             return
+        err = None
+        try:
+            if getattr(self, "_pending", None) is not None and not torch.cuda.is_current_stream_capturing():
+                self._join_exchange()
+            if self.send.device.type == "cuda":
+                torch.cuda.synchronize(self.send.device)
+            if check:
+                self.peer.check()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if barrier and self.world > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)              # every rank's puts have landed: nobody stores into a window any more
         if self.inkernel_get:
             _lib.check(_lib.lib().hfem_plan_set_peer_get(self.plan.handle, None, 0, 0), "hfem_plan_set_peer_get")
         self.peer.close()
         self.peer, self.inkernel_get, self._wait_range, self._step_cache = None, False, None, None
+        if err is not None:
+            raise err
+
+    def reset_peer_exchange(self, timeout_s: float = 5.0):
+        """Once a status bit is set the exchange is UNUSABLE (later gets no longer wait: the two-slot protocol is out of step and
+        rows may be stale).  Recovery = new windows: collective; the caller restores the parameters first (a checkpoint, or
+        ``exchange_halo()`` over the collective path after this returns)."""
+        ik = self.inkernel_get
+        self.close_peer_exchange(check=False)
+        return self.enable_peer_exchange(timeout_s=timeout_s, inkernel_get=ik or None)
 
     def __del__(self):
         try:                       # the plan outlives this object (the model caches it): do not leave it a dangling pointer
-            self.close_peer_exchange()
+            self.close_peer_exchange(barrier=False, check=False)
         except Exception:
             pass
 
@@ -738,9 +763,20 @@ class ShardedTri3Energy:
 
     def finish_overlapped(self):
         """Join the exchange ``owner_train_step_overlapped`` left in flight: parameters and ``loss_global`` (the energy
-        of the last step) are then complete on this rank."""
+        of the last step) are then complete on this rank.  Over peer windows this is also where a timed-out get surfaces:
+        outside a stream capture the windows' status is read (one device synchronisation -- the caller is about to read
+        parameters or the loss anyway) and a set bit raises; inside a capture call ``check_exchange()`` after the replay."""
         self._join_exchange()
+        if self.peer is not None and not torch.cuda.is_current_stream_capturing():
+            self.peer.check()
         return self.loss_global
+
+    def check_exchange(self):
+        """Raise if a peer-window get ever timed out (sticky status; synchronises with the device).  Call it after replaying a
+        captured graph of ``owner_*`` steps -- a training loop that never does runs on stale interface rows silently.  No-op on
+        the collective path (a lost rank hangs or raises inside the collective there)."""
+        if self.peer is not None:
+            self.peer.check()
 
     def owned_rows(self):
         """(x rows, u rows) of node_coords_free / u_free that this rank's tiles own (int64 tensors)."""

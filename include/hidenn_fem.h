@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HFEM_VERSION 113   /* 0.1.1: round 3 -- hfem_plan_stats grew (append-only), new entry points, options */
+#define HFEM_VERSION 114   /* 0.1.1: round 4 -- plan blobs, sharded L-BFGS, fp32 arithmetic; append-only since 113 */
 
 int hfem_version(void);
 const char *hfem_last_error(void);
@@ -100,7 +100,7 @@ typedef struct hfem_plan_stats {
     int32_t slot_rows;                    /* paired plans: slots per thread in the widest tile */
     int32_t store_policy;                 /* gradient stores of this plan: 16 sc1 write-through, 2 nt (meshes of >= 750 k nodes
                                              whose rows have locality), 0 plain -- "store_policy" -1 = this choice */
-    int32_t reserved0;
+    int32_t nodes_per_elem;               /* 3 (TRI3) or 4 (QUAD4) -- was reserved0 before version 114 */
     double row_line_factor;               /* distinct 128-byte lines among a tile's coordinate rows / the minimum, mean over the
                                              tiles: ~1.3 = rows stored with locality, up to 8 = random numbering */
 } hfem_plan_stats;
@@ -130,6 +130,15 @@ int hfem_plan_get_stats(const hfem_plan *plan, hfem_plan_stats *out);
  * with uniform strides (tile t's node records start at t * node_stride, its slot records at t * elem_stride, padded;
  * extra records follow the last tile): walk them through tile_desc's offsets and counts, not as dense arrays.    */
 int64_t hfem_plan_export(const hfem_plan *plan, int which, void *buf, int64_t cap_elems);
+
+/* A plan as one relocatable byte string: the planner costs ~1 s per 10^6 elements and every rank of a multi-GPU job (and
+ * every later run on the same mesh) needs the same plan -- one process builds and serialises, the others deserialise
+ * (hidenn_fem_amd/plan.py: TilePlan.to_bytes / from_bytes / the cache_dir of TilePlan and bench.py --gpus N).  The blob
+ * holds the host plan, the creation-time decisions (element order, tile shape, store policy, shard layout) and a checksum;
+ * it is valid for the library version that wrote it (HFEM_VERSION) on any device.  serialize: buf NULL queries the size;
+ * returns bytes or <0.  deserialize: device < 0 = host-only plan.  No reference counterpart (the reference has no plan).  */
+int64_t hfem_plan_serialize(const hfem_plan *plan, void *buf, int64_t cap_bytes);
+int hfem_plan_deserialize(int device, const void *blob, int64_t n_bytes, hfem_plan **out);
 
 #define HFEM_FLAG_NO_GX 1   /* do not write gx_free (nodes fixed / no r-adaptivity) */
 #define HFEM_FLAG_NO_GU 2   /* do not write gu_free */

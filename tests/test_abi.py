@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(h, n), f"{n} declared in include/hidenn_fem.h but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == names
-    assert _lib.lib().hfem_version() == 113
+    assert _lib.lib().hfem_version() == 114
 
 
 def test_argument_errors_are_reported_not_raised_across_the_abi():

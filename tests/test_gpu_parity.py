@@ -47,7 +47,7 @@ def tri_model_from_golden(g, case, device):
 def test_library_loaded_and_native():
     from hidenn_fem_amd import _lib
     L = _lib.lib()
-    assert L.hfem_version() == 113
+    assert L.hfem_version() == 114
     assert L.hfem_device_count() >= 1
 
 

@@ -235,13 +235,13 @@ def test_fp32_model_owner_sharded_steps_one_rank():
     comm.close()
 
 
-def _worker_two_ranks(rank, world, port, q):
+def _worker_two_ranks(rank, world, port, q, per_gpu=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        d = torch.device("cuda:0")                         # both ranks on the box's one GPU
+        d = torch.device("cuda", rank if per_gpu else 0)   # all ranks on the box's one GPU, or one GPU per rank (xGMI leg)
         torch.cuda.set_device(d)
         n = 6
         report = {}
@@ -304,7 +304,14 @@ def _worker_two_ranks(rank, world, port, q):
                 raised = True
             report["timeout"] = (st, raised)
         dist.barrier()
-        lone.close_peer_exchange()
+        if rank == 0:                                      # a set status bit surfaces at close (and at finish_overlapped) too
+            try:
+                lone.close_peer_exchange()
+                report["timeout_at_close"] = False
+            except RuntimeError:
+                report["timeout_at_close"] = lone.peer is None      # ... after the windows were released
+        else:
+            lone.close_peer_exchange()
         q.put((rank, report))
     finally:
         dist.destroy_process_group()
@@ -312,15 +319,29 @@ def _worker_two_ranks(rank, world, port, q):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
+def test_peer_windows_two_gpus():
+    """The xGMI leg proper: two ranks, one GPU each -- every put is a store into a window on the OTHER GPU, every flag crosses
+    the link.  Same checks as the one-GPU processes test.  Skips on boxes with fewer than two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (stores into a window on another GPU)")
+    _peer_processes(2, per_gpu=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 3])
 def test_peer_windows_processes_sharing_one_gpu(world):
+    _peer_processes(world, per_gpu=False)
+
+
+def _peer_processes(world, per_gpu):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_two_ranks, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_two_ranks, args=(r, world, port, q, per_gpu)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=500) for _ in range(world))
@@ -335,4 +356,4 @@ def test_peer_windows_processes_sharing_one_gpu(world):
             assert st == (0, 6) and st_g == (0, 10), (r, name, st, st_g)
         assert all(res[r][name][4] == res[0][name][4] for r in range(world)), "ranks disagree on the global energies (summed in rank order everywhere)"
     assert all(res[r]["f32"] for r in range(world)), "fp32 model: peer-window fused steps differ from the all_gather ones"
-    assert res[0]["timeout"] == ((1, 1), True)
+    assert res[0]["timeout"] == ((1, 1), True) and res[0]["timeout_at_close"] is True

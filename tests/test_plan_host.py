@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from hidenn_fem_amd.mesh import structured_tri_mesh, generate_mesh
+from hidenn_fem_amd.mesh import structured_tri_mesh, structured_quad_mesh, generate_mesh
 from hidenn_fem_amd.plan import TilePlan, row_maps
 from oracle import closed_form as CF
 
@@ -555,3 +555,98 @@ def test_tile_local_nodes_follow_the_row_order_when_rows_are_stored_along_the_cu
         # the partition invariants do not depend on the local order
         own = np.concatenate([ns[no:no + nown] for (_, _, no, nno, nown, _, _, _) in td])
         assert len(np.unique(own[own[:, 0] >= 0, 0])) == int((~g).sum())
+
+
+@pytest.mark.parametrize("elem_order", [3, 4, 5])
+def test_sharded_and_unsharded_plans_agree_per_tile_on_every_per_tile_array(elem_order):
+    """A sharded plan only REORDERS tiles inside every rank's range (boundary tiles first): every array indexed by tile --
+    descriptor counts, row maps, slot records, global ids and, for the chunked order (plan_elem_order 4), the strip records
+    ``tile_chunks`` -- must move with its tile (tile_chunks stayed behind)."""
+    from hidenn_fem_amd import _lib
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(161, 121, jitter=0.2, seed=0, dtype=torch.float64)
+    nn = coords.shape[0]
+    L = _lib.lib()
+    prev = L.hfem_get_option(b"plan_node_cap")
+    L.hfem_set_option(b"plan_node_cap", 300)             # the same cut for both plans, whatever the shard-aware policy says
+    try:
+        base = TilePlan(conn, nn, coords_hint=coords, edges=edges, elem_order=elem_order, tile_elems=512)
+        plan = TilePlan(conn, nn, coords_hint=coords, edges=edges, elem_order=elem_order, tile_elems=512, shards=2)
+    finally:
+        L.hfem_set_option(b"plan_node_cap", prev)
+    assert base.n_tiles == plan.n_tiles and plan.stats["shards"] == 2
+
+    def per_tile(p):
+        td, ns = p.export("tile_desc"), p.export("node_src")
+        ep, eg = p.export("elem_pack"), p.export("elem_gid")
+        hi = p.export("elem_pack_hi") if p._export_len("elem_pack_hi") else None
+        egb = p.export("elem_gid_b") if p._export_len("elem_gid_b") else None
+        ch = p.export("tile_chunks") if p._export_len("tile_chunks") else None
+        edp, edg = p.export("edge_pack"), p.export("edge_gid")
+        out = {}
+        for t in range(p.n_tiles):
+            eo, nel, no, nno, nown, edo, ned, pad = (int(v) for v in td[t])
+            rec = [(nel, nno, nown, ned, pad), ns[no:no + nno].tobytes(), ep[eo:eo + nel].tobytes(), eg[eo:eo + nel].tobytes(),
+                   edp[edo:edo + ned].tobytes(), edg[edo:edo + ned].tobytes()]
+            if hi is not None:
+                rec.append(hi[eo:eo + nel].tobytes())
+            if egb is not None:
+                rec.append(egb[eo:eo + nel].tobytes())
+            if ch is not None:
+                rec.append(ch[t].tobytes())
+            key = eg[eo:eo + nel]
+            out[(int(key[key >= 0].min()) if (key >= 0).any() else -1 - t, nown)] = rec      # a tile is known by its first element
+        return out
+
+    a, b = per_tile(base), per_tile(plan)
+    assert a.keys() == b.keys()
+    moved = sum(1 for t in range(base.n_tiles) if not np.array_equal(base.export("tile_desc")[t, 1:5], plan.export("tile_desc")[t, 1:5]))
+    assert moved > 0, "the sharded plan reordered nothing: the test would be vacuous"
+    for k in a:
+        assert a[k] == b[k], f"tile starting at element {k[0]}: a per-tile array did not move with the tile (order {elem_order})"
+    if elem_order == 4:
+        assert plan._export_len("tile_chunks") == 4 * plan.n_tiles
+
+
+def test_plan_blob_round_trip_cache_and_rejection(tmp_path):
+    """hfem_plan_serialize / hfem_plan_deserialize: every exported array and the statistics survive; a flipped byte, a
+    truncated blob and a foreign byte string are rejected with an error; the cache directory builds once and hits after,
+    and any change of input or option is another key."""
+    from hidenn_fem_amd.plan import EXPORT_IDS, row_maps
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(161, 121, jitter=0.2, seed=0, dtype=torch.float64)
+    nn = coords.shape[0]
+    xs, us = row_maps(~geom.numpy()), row_maps(~bc.numpy())
+    for kw in (dict(shards=2), dict(elem_order=3), dict(elem_order=4, shards=3)):
+        p = TilePlan(conn, nn, coords_hint=coords, x_src=xs, u_src=us, edges=edges, **kw)
+        blob = p.to_bytes()
+        q = TilePlan.from_bytes(blob)
+        assert q.stats == p.stats and q.n_elems == p.n_elems and q.nodes_per_elem == 3
+        for name in EXPORT_IDS:
+            if name != "stamps":
+                assert np.array_equal(p.export(name), q.export(name)), name
+        assert q.shard_parts(0, kw.get("shards", 1)) == p.shard_parts(0, kw.get("shards", 1))
+        assert np.array_equal(q.to_bytes(), blob)
+    qc, qconn, *_ = structured_quad_mesh(41, 31, jitter=0.1, seed=1, dtype=torch.float64)
+    pq = TilePlan(qconn, qc.shape[0], coords_hint=qc, nodes_per_elem=4)
+    assert TilePlan.from_bytes(pq.to_bytes().tobytes()).nodes_per_elem == 4
+    bad = blob.copy()
+    bad[len(bad) // 2] ^= 1
+    for wrong in (bad, blob[:-16], np.frombuffer(b"not a plan" * 20, dtype=np.uint8)):
+        with pytest.raises(RuntimeError):
+            TilePlan.from_bytes(wrong)
+    d = str(tmp_path / "plans")
+    a = TilePlan(conn, nn, coords_hint=coords, x_src=xs, u_src=us, edges=edges, shards=2, cache_dir=d)
+    b = TilePlan(conn, nn, coords_hint=coords, x_src=xs, u_src=us, edges=edges, shards=2, cache_dir=d)
+    c = TilePlan(conn, nn, coords_hint=coords, x_src=xs, u_src=us, edges=edges, shards=3, cache_dir=d)
+    e = TilePlan(conn, nn, coords_hint=coords, x_src=us, u_src=xs, edges=edges, shards=2, cache_dir=d)
+    assert (a.cache, b.cache, c.cache, e.cache) == ("miss", "hit", "miss", "miss")
+    assert np.array_equal(a.to_bytes(), b.to_bytes())
+    import os
+    assert len(os.listdir(d)) == 3
+    # a torn / foreign cache entry is rebuilt, not trusted
+    fn = [f for f in os.listdir(d)][0]
+    with open(os.path.join(d, fn), "r+b") as f:
+        f.truncate(1000)
+    for kw in (dict(shards=2), dict(shards=3)):
+        TilePlan(conn, nn, coords_hint=coords, x_src=xs, u_src=us, edges=edges, cache_dir=d, **kw)
+    TilePlan(conn, nn, coords_hint=coords, x_src=us, u_src=xs, edges=edges, shards=2, cache_dir=d)
+    assert all(os.path.getsize(os.path.join(d, f)) > 1000 for f in os.listdir(d))

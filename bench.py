@@ -1059,17 +1059,43 @@ def main():
             _, Tc32 = lf32._traction(m32, None)
             mat32, Tcv32, Bk32 = dv(lf32._mat), dv(Tc32), dv([0.0] * 6)
 
-            def launch32(i):
+            def launch32(flags32):
+                def go(i):
+                    _lib.check(L.hfem_tri3_energy_plan_f32(pl32.handle, x32.data_ptr(), xfx32.data_ptr(), u32.data_ptr(), ufx32.data_ptr(),
+                                                           mat32, lf32._W, Bk32, None, Tcv32, 0, -1, ls32.data_ptr(), gx32.data_ptr(),
+                                                           gu32.data_ptr(), flags32, stream_box[0].cuda_stream), "hfem_tri3_energy_plan_f32")
+                return go
+            ab32 = 12 * ne + 32 * nn + 8
+
+            def fig(us_):
+                return dict(kernel_us=us_, element_evals_per_s=ne / (us_ * 1e-6), achieved=ab32 / (us_ * 1e-6) / 1e9,
+                            frac=ab32 / (us_ * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            us32, _ = time_launches(launch32(8 | 1024), kreps)           # HFEM_FLAG_FP32_MATH: what EnergyLoss2D(arithmetic="auto") runs
+            us32_64, _ = time_launches(launch32(8), kreps)
+            # accuracy of both against the fp64 kernel on the same float values (max-abs over max|g|)
+            m64 = PiecewiseLinearShapeNN2D(coords.float().double(), conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0,
+                                           neumann_edges=edges, reorder=a.reorder).to(dev)
+            with torch.no_grad():
+                m64.u_free.copy_(u32.double())
+            lf64 = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64)
+            lf64._mat, lf64._W, lf64._ci, lf64._cj = lf32._mat, lf32._W, lf32._ci, lf32._cj
+            l64 = lf64.value_and_grad_(m64).item()
+            acc = {}
+            for tag, fl_ in (("fp32_arithmetic", 1024), ("fp64_arithmetic", 0)):
                 _lib.check(L.hfem_tri3_energy_plan_f32(pl32.handle, x32.data_ptr(), xfx32.data_ptr(), u32.data_ptr(), ufx32.data_ptr(),
                                                        mat32, lf32._W, Bk32, None, Tcv32, 0, -1, ls32.data_ptr(), gx32.data_ptr(),
-                                                       gu32.data_ptr(), 8, stream_box[0].cuda_stream), "hfem_tri3_energy_plan_f32")
-            us32, _ = time_launches(launch32, kreps)
-            ab32 = 12 * ne + 32 * nn + 8
-            fp32_leg = dict(workload="T1M with fp32 parameter / gradient rows (the reference's default dtype), fp64 arithmetic",
-                            kernel_us=us32, element_evals_per_s=ne / (us32 * 1e-6), alg_bytes_per_launch=ab32,
-                            achieved=ab32 / (us32 * 1e-6) / 1e9, frac=ab32 / (us32 * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                            regime="replayed (same buffers every launch)")
-            del m32, pl32
+                                                       gu32.data_ptr(), fl_, torch.cuda.current_stream().cuda_stream), "hfem_tri3_energy_plan_f32")
+                acc[tag] = dict(loss_rel_err=abs(ls32.item() - l64) / abs(l64),
+                                gx_err_over_max=((gx32.double() - m64.node_coords_free.grad).abs().max() / m64.node_coords_free.grad.abs().max()).item(),
+                                gu_err_over_max=((gu32.double() - m64.u_free.grad).abs().max() / m64.u_free.grad.abs().max()).item())
+            fp32_leg = dict(workload="T1M as the reference runs it by default: an fp32 model (float parameter / gradient rows)",
+                            alg_bytes_per_launch=ab32, regime="replayed (same buffers every launch)",
+                            kernel="tri3_energy_pair_f32_kernel (csrc/tri3_pair_f32.hip): fp32 arithmetic, the two elements of a slot in "
+                                   "the two halves of packed-fp32 registers; EnergyLoss2D(arithmetic='auto')",
+                            **fig(us32), fp64_arithmetic=dict(kernel="tri3_energy_pair_kernel<float2>: rows widened on load, one rounding "
+                                                                    "on store; EnergyLoss2D(arithmetic='fp64')", **fig(us32_64)),
+                            error_vs_fp64_kernel_on_the_same_floats=acc)
+            del m32, pl32, m64
         except Exception as e:  # noqa: BLE001
             note(f"fp32_rows leg failed: {type(e).__name__}: {str(e)[:160]}")
 

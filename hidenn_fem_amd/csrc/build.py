@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["plan.cpp", "mg.cpp", "tri3_energy.hip", "tri3_stream.hip", "tri3_pair.hip", "tri3_pair_lab.hip", "tri3_pair_pipe.hip", "tri3_det.hip", "tri3_eval.hip", "line_rect.hip", "quad4.hip", "optim.hip", "exchange.hip", "peer.hip", "post.hip", "lbfgs.hip"]
+SOURCES = ["plan.cpp", "mg.cpp", "tri3_energy.hip", "tri3_stream.hip", "tri3_pair.hip", "tri3_pair_f32.hip", "tri3_pair_lab.hip", "tri3_pair_pipe.hip", "tri3_det.hip", "tri3_eval.hip", "line_rect.hip", "quad4.hip", "optim.hip", "exchange.hip", "peer.hip", "post.hip", "lbfgs.hip"]
 HEADERS = ["hfem_common.h", "hfem_device.h", "hfem_plan_dev.h", "tri3_energy_lab.inc", os.path.join(ROOT, "include", "hidenn_fem.h")]
 OUT = os.path.join(HERE, "libhidenn_hip.so")
 OUT_LAB = os.path.join(HERE, "libhidenn_hip_lab.so")

@@ -1021,8 +1021,9 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(plan->device >= 0, "host-only plan (created with device < 0) cannot launch");
     HFEM_ARG_CHECK(plan->host.npe == 3, "this plan was built for QUAD4");
     HFEM_ARG_CHECK(x_free && u_free, "x_free / u_free must be given");
-    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC | HFEM_FLAG_SUM_PREVIOUS)),
-                   "fp32-storage path: reference convention, atomic accumulation, no lagged loss sum");
+    const bool f32math = (flags & HFEM_FLAG_FP32_MATH) != 0;
+    HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC)), "fp32-storage path: reference convention, atomic accumulation");
+    HFEM_ARG_CHECK(f32math || !(flags & HFEM_FLAG_SUM_PREVIOUS), "fp32 rows with fp64 arithmetic: no lagged loss sum (HFEM_FLAG_FP32_MATH has it)");
     const HostPlan &h = plan->host;
     const int32_t nt = (int32_t)h.tiles.size();
     if (tile_end < 0) tile_end = nt;
@@ -1030,6 +1031,52 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
     bool hasb = false;
     for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
+    if (f32math) {
+        // fp32 ARITHMETIC (tri3_pair_f32.hip): paired-slot plans without chained records; body force, tile ranges, the lagged
+        // loss sum and the partials banks as hfem_tri3_energy_plan; no in-launch get
+        HFEM_ARG_CHECK(h.paired && h.n_chained == 0, "HFEM_FLAG_FP32_MATH: paired-slot plans only (this mesh's plan keeps one element per slot: drop the flag)");
+        HFEM_ARG_CHECK(!(flags & HFEM_FLAG_PEER_GET), "HFEM_FLAG_FP32_MATH: no in-launch get (the sharded steps run the fp64-arithmetic float-row instances)");
+        if (int rc = use_device(plan->device)) return rc;
+        PlanLock lock(plan);
+        const int n = tile_end - tile_begin;
+        const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0, same_bank = (flags & HFEM_FLAG_SAME_BANK) != 0;
+        HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
+        HFEM_ARG_CHECK(!lag_consume || (plan->prev_n > 0 && n > 0), "HFEM_FLAG_SUM_PREVIOUS: no previous unsummed launch on this plan");
+        HFEM_ARG_CHECK(!lag_consume || plan->prev_stream == stream, "HFEM_FLAG_SUM_PREVIOUS: the previous unsummed launch went to another stream (one plan = one stream)");
+        HFEM_ARG_CHECK(!same_bank || ((flags & HFEM_FLAG_NO_LOSS_SUM) && !lag_consume), "HFEM_FLAG_SAME_BANK needs HFEM_FLAG_NO_LOSS_SUM and excludes HFEM_FLAG_SUM_PREVIOUS");
+        const int wbank = (flags & HFEM_FLAG_NO_LOSS_SUM) ? (same_bank ? plan->bank : (plan->bank ^ 1)) : plan->bank;
+        double *pb = plan->d_partials + (size_t)wbank * nt;
+        LagSum lag;
+        if (lag_consume) {
+            lag.prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
+            lag.prev_n = plan->prev_n;
+            lag.out = loss_out;
+        }
+        if (n > 0) {
+            PairLaunch P;
+            P.grid = n + (lag.prev ? 1 : 0); P.tile_begin = (int)tile_begin;
+            P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
+            P.k = make_consts(mat, W, Bk); P.T_edge = (const double4 *)T_edge;
+            P.tc = Tconst ? make_double4(Tconst[0], Tconst[1], Tconst[2], Tconst[3]) : make_double4(0, 0, 0, 0);
+            P.partials = pb + tile_begin;
+            P.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; P.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
+            P.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0; P.s = (hipStream_t)stream;
+            HFEM_ARG_CHECK(launch_tri3_pair_f32(plan, P, hasb, lag) == 1, "HFEM_FLAG_FP32_MATH: tile shape outside the fp32 pair kernel's instances");
+            if (int rc = launch_status("hfem_tri3_energy_plan_f32(fp32 arithmetic)")) return rc;
+        }
+        if (flags & HFEM_FLAG_NO_LOSS_SUM) {              // the partials-bank bookkeeping of hfem_tri3_energy_plan
+            if (same_bank && plan->prev_n > 0 && n > 0 && (tile_end == plan->prev_begin || tile_begin == plan->prev_begin + plan->prev_n)) {
+                plan->prev_begin = std::min(plan->prev_begin, (int)tile_begin);
+                plan->prev_n += n;
+            } else if (!same_bank || n > 0) {
+                plan->prev_begin = tile_begin; plan->prev_n = n;
+            }
+            plan->bank = wbank; plan->prev_stream = stream;
+            return 0;
+        }
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pb + tile_begin, n, loss_out);
+        return launch_status("hfem_tri3_energy_plan_f32(sum)");
+    }
     HFEM_ARG_CHECK(!hasb && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
                    "fp32-storage path: needs a zero body force and tiles of <= 1024 nodes / 2048 slots");
     if (int rc = use_device(plan->device)) return rc;

@@ -19,14 +19,21 @@ from .utils import interval_gauss_points, triangle_gauss_points
 HFEM_FLAG_NO_EDGES = 4
 HFEM_FLAG_PHYSICAL_GRAD = 64
 HFEM_FLAG_DETERMINISTIC = 128
+HFEM_FLAG_FP32_MATH = 1024
 
 
 class EnergyLoss2D:
     def __init__(self, E: float = 10e9, nu: float = 0.3, length: float = 1.0, height: float = 1.0,
                  gauss_order: int = 4, gauss_order_1d: int = 2, device: Optional[torch.device] = None,
                  dtype: torch.dtype = torch.float32, tile_elems: int = 0, grad_convention: Optional[str] = None,
-                 deterministic: bool = False):
-        """Reference signature (loss.py:7-17) plus three opt-in switches:
+                 deterministic: bool = False, arithmetic: str = "auto"):
+        """Reference signature (loss.py:7-17) plus opt-in switches:
+        ``arithmetic`` -- what fp32 MODELS (the reference's default dtype, loss.py:16) compute in: ``"fp32"`` = the
+        reference's own arithmetic (packed-fp32 element math, float accumulators; results inside the band the reference's
+        fp32 run occupies around exact arithmetic, tests/test_gpu_tri3_f32.py; TRI3 meshes whose plan has paired slots),
+        ``"fp64"`` = float rows widened on load, fp64 arithmetic, ONE rounding on store (the accurate option, ~1.4x slower),
+        ``"auto"`` (default) = fp32 where that kernel exists, fp64 elsewhere (unpaired plans, QUAD4, physical convention,
+        deterministic).  fp64 models always compute in fp64.
         ``grad_convention``: ``"reference"`` (``dN_dx = Jinv * dN_dxi`` exactly as models.py:351, the parity contract),
         ``"physical"`` (``Jinv^T``: exact for linear fields, invariant to an element's local node order) or
         ``None`` = whatever the model says (``model.grad_convention``, ``"reference"`` unless set);
@@ -34,6 +41,9 @@ class EnergyLoss2D:
         cross-check kernel, ~3-4x slower); ``tile_elems``: home elements per tile (0 = library default)."""
         if grad_convention not in (None, "reference", "physical"):
             raise ValueError("grad_convention must be 'reference', 'physical' or None")
+        if arithmetic not in ("auto", "fp32", "fp64"):
+            raise ValueError("arithmetic must be 'auto', 'fp32' or 'fp64'")
+        self.arithmetic = arithmetic
         self.grad_convention, self.deterministic = grad_convention, bool(deterministic)
         self.E, self.nu = E, nu
         self.length, self.height = length, height          # stored, never read (as upstream, F9)
@@ -102,9 +112,21 @@ class EnergyLoss2D:
             raise ValueError(f"unknown grad_convention {conv!r}")
         return (HFEM_FLAG_PHYSICAL_GRAD if conv == "physical" else 0) | (HFEM_FLAG_DETERMINISTIC if self.deterministic else 0)
 
+    def _f32_math(self, model, plan, flags) -> bool:
+        """fp32 arithmetic for this launch?  Only fp32 TRI3 models on paired-slot plans in the reference convention."""
+        if self.arithmetic == "fp64" or model.node_coords_free.dtype != torch.float32:
+            return False
+        ok = bool(plan.stats["paired"]) and not (flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC))
+        if self.arithmetic == "fp32" and not ok:
+            raise RuntimeError("arithmetic='fp32': the fp32-arithmetic kernel needs a TRI3 plan with paired slots, the reference "
+                               "gradient convention and atomic accumulation; use arithmetic='auto' or 'fp64'")
+        return ok
+
     def _fused(self, model, b_force, T_edge, Tconst, flags, tile_range=(0, -1)):
         flags |= self._mode_flags(model)
         plan = model.tile_plan(self.tile_elems)
+        if self._f32_math(model, plan, flags):
+            flags |= HFEM_FLAG_FP32_MATH
         return ops.Tri3EnergyFn.apply(model.node_coords_free, model.u_free,
                                       model.node_coords_fixed.to(model.dtype), model.u_fixed_rows(), plan,
                                       self._mat, self._W, self._body_table(b_force), T_edge, Tconst,
@@ -199,6 +221,8 @@ class EnergyLoss2D:
         xfix = model.node_coords_fixed.to(device=xf.device, dtype=xf.dtype).contiguous()
         ufix = model.u_fixed_rows().to(device=xf.device, dtype=xf.dtype).contiguous()
         flags = (0 if model.N_edges else HFEM_FLAG_NO_EDGES) | self._mode_flags(model)
+        if f32 and not quad and self._f32_math(model, plan, flags):
+            flags |= HFEM_FLAG_FP32_MATH
         if flags & HFEM_FLAG_DETERMINISTIC and f32:
             raise NotImplementedError("deterministic: fp64 models (model.double())")
         if flags & HFEM_FLAG_PHYSICAL_GRAD and f32 and not quad:

@@ -89,9 +89,15 @@ class Tri3EnergyFn(torch.autograd.Function):
         tcv = None if Tconst is None else _dvec(Tconst)
         ctx.dtypes = (x_free.dtype, u_free.dtype)
         F32 = torch.float32
-        if (x_free.dtype == F32 and u_free.dtype == F32 and not any(float(b) != 0.0 for b in Bk) and not (flags & (64 | 128))
-                and plan.stats["max_tile_nodes"] <= 1024 and plan.stats["max_tile_elems"] <= 2048):
-            # fp32 model (the reference's default dtype): float rows in and out, fp64 arithmetic inside -- no widening copies
+        # HFEM_FLAG_FP32_MATH (1024): fp32 arithmetic for fp32 models (csrc/tri3_pair_f32.hip: paired-slot plans; body force
+        # allowed); without it -- or where that kernel has no instance -- float rows with fp64 arithmetic, else widening copies
+        f32math = bool(fl & 1024) and x_free.dtype == F32 and u_free.dtype == F32 and not (flags & (64 | 128)) and bool(plan.stats["paired"])
+        fl &= ~1024
+        hasb = any(float(b) != 0.0 for b in Bk)
+        if f32math or (x_free.dtype == F32 and u_free.dtype == F32 and not hasb and not (flags & (64 | 128))
+                       and plan.stats["max_tile_nodes"] <= 1024 and plan.stats["max_tile_elems"] <= 2048):
+            # fp32 model (the reference's default dtype): float rows in and out -- no widening copies
+            fl |= 1024 if f32math else 0
             xf, uf = require_gpu_tensor(x_free.detach(), "node_coords_free", F32), require_gpu_tensor(u_free.detach(), "u_free", F32)
             xfix = None if x_fixed is None else x_fixed.to(F32).contiguous()
             ufix = None if u_fixed is None else u_fixed.to(F32).contiguous()

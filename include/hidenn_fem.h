@@ -161,6 +161,10 @@ int hfem_plan_deserialize(int device, const void *blob, int64_t n_bytes, hfem_pl
 #define HFEM_FLAG_PEER_GET 512  /* paired-slot plans (no chained records) and 512-thread one-element-per-slot plans, after hfem_plan_set_peer_get: the launch starts with 8 service workgroups that
                                  * ARE the peer-window get (hfem_peer_iface_get's wait + unpack into this launch's x_free / u_free)
                                  * and the tiles named there (the rank's boundary tiles) wait for them inside the kernel        */
+#define HFEM_FLAG_FP32_MATH 1024 /* hfem_tri3_energy_plan_f32 only: fp32 ARITHMETIC as well as fp32 rows -- what the reference itself
+                                 * computes in for its default dtype (src/loss.py:16): packed-fp32 element math (the two elements of
+                                 * a slot side by side), float LDS accumulators; the tile energies and the loss stay fp64.  Paired-slot
+                                 * plans; body force, tile ranges, NO_LOSS_SUM / SUM_PREVIOUS / SAME_BANK as the fp64 entry point. */
 #define HFEM_FLAG_SAME_BANK 256 /* with NO_LOSS_SUM: another tile range of the SAME evaluation as the previous NO_LOSS_SUM
                                  * launch on this plan (a rank's boundary tiles after its interior tiles): the tile energies
                                  * go to the bank that launch wrote, so one hfem_plan_loss_sum / hfem_plan_iface_pack over
@@ -182,7 +186,9 @@ int hfem_tri3_energy_plan(hfem_plan *plan, const double *x_free, const double *x
 /* Same pass for an fp32 model (the reference's default dtype): x / u rows and the gradient rows are float
  * [rows][2]; they are widened on load and rounded once on store, arithmetic and loss_out stay fp64.
  * Needs a zero body force (Bk NULL or all zero) and the default tile shape; any other plan returns an
- * argument error (the caller then widens to the fp64 entry point).                                   */
+ * argument error (the caller then widens to the fp64 entry point).  With HFEM_FLAG_FP32_MATH the arithmetic is fp32 too
+ * (csrc/tri3_pair_f32.hip): results within the band the reference's own fp32 run occupies around exact arithmetic
+ * (tests/test_gpu_tri3_f32.py), ~1.4x faster; body force allowed.                                     */
 int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, const float *x_fixed,
                               const float *u_free, const float *u_fixed,
                               const double mat[4], double W, const double Bk[6],

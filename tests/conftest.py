@@ -42,6 +42,12 @@ def g_tri():
 
 
 @pytest.fixture(scope="session")
+def g_tri_f32():
+    """The reference run AS SHIPPED (fp32 model, EnergyLoss2D(dtype=float32)) + its fp64 run on the same float inputs."""
+    return Golden("g7_tri3_f32")
+
+
+@pytest.fixture(scope="session")
 def g_quad():
     return Golden("g5_quadrature")
 
@@ -100,6 +106,11 @@ def tri_case_forces(case):
     b = b_force_fn if (case.endswith("_body") or case in ("flipped", "permuted_random_diag")) else None
     t = t_force_fn if case == "traction_fn" else None
     return b, t
+
+
+def tri_case_forces_f32(case):
+    """Forces of the g7_tri3_f32 cases (make_golden.py: g7_tri3_f32)."""
+    return (b_force_fn if case == "order4_body" else None), (t_force_fn if case == "traction_fn" else None)
 
 
 def has_gpu():

@@ -143,6 +143,51 @@ def g1_tri3(out):
     tri_case(out, "mini_example4", big)
 
 
+# ---------------------------------------------------------------- G7 TRI3 + EDGE2 AS SHIPPED: fp32 (loss.py:16, models.py:274)
+def tri_case_f32(out, name, mesh6, gauss_order=4, gauss_order_1d=2, b_force=None, t_force=None, u_scale=1.0, seed=0):
+    """The reference in its DEFAULT dtype: fp32 model (no .double()), EnergyLoss2D(dtype=torch.float32).  Stored beside it:
+    the reference in fp64 on the SAME fp32-representable inputs (`*64`), i.e. what exact arithmetic would give -- so a test
+    can separate "the kernel differs from the reference's fp32 rounding noise" from "the kernel is wrong"."""
+    node_coords, conn, geom, bc, mn, edges = mesh6
+    node_coords = node_coords.to(torch.float32)
+    res = {}
+    for dt, tag in ((torch.float32, ""), (F64, "64")):
+        torch.manual_seed(seed)
+        model = RefTri(node_coords, conn, boundary_mask=geom, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges)   # fp32 parameters
+        with torch.no_grad():
+            model.u_free.mul_(u_scale)
+        u32 = np_(model.u_free).copy()
+        if dt == F64:
+            model = model.double()                                 # the same float values, exact arithmetic
+        loss_fn = RefLoss(E=10e9, nu=0.3, gauss_order=gauss_order, gauss_order_1d=gauss_order_1d, device=CPU, dtype=dt)
+        loss = loss_fn(model, b_force=b_force, t_force=t_force)
+        loss.backward()
+        assert loss.dtype == dt and model.u_free.grad.dtype == dt
+        res[tag] = (np_(loss), np_(model.u_free.grad), np_(model.node_coords_free.grad), u32)
+    p = name + "/"
+    out[p + "node_coords"] = np_(node_coords)
+    out[p + "conn"], out[p + "edges"] = np_(conn), np_(edges)
+    out[p + "boundary_mask"], out[p + "dirichlet_mask"] = np_(geom), np_(bc)
+    out[p + "u_free"] = res[""][3]
+    assert np.array_equal(res[""][3], res["64"][3])
+    out[p + "gauss_order"] = np.array([gauss_order, gauss_order_1d])
+    for tag in ("", "64"):
+        out[p + "loss" + tag], out[p + "g_u_free" + tag], out[p + "g_coords_free" + tag] = res[tag][:3]
+
+
+def g7_tri3_f32(out):
+    base = structured_tri_mesh(9, 7, jitter=0.2, seed=1, dtype=F64)
+    for o in (1, 4, 7):
+        tri_case_f32(out, f"order{o}", base, gauss_order=o)
+    tri_case_f32(out, "order4_body", base, b_force=b_force_fn, u_scale=3.0)
+    tri_case_f32(out, "flipped", structured_tri_mesh(9, 7, jitter=0.2, seed=1, flip_fraction=0.5, dtype=F64), u_scale=2.0)
+    tri_case_f32(out, "traction_fn", base, t_force=t_force_fn, gauss_order_1d=3)
+    tri_case_f32(out, "permuted_random_diag", structured_tri_mesh(12, 9, jitter=0.3, seed=3, diagonal="random", permute=True, dtype=F64),
+                 u_scale=2.0)
+    tri_case_f32(out, "mini_example4", structured_tri_mesh(41, 21, jitter=0.2, seed=0, dtype=F64))
+    tri_case_f32(out, "example4_mesh", structured_tri_mesh(101, 51, jitter=0.2, seed=5, dtype=F64))    # 10^4 elements: longer fp32 sums
+
+
 # ---------------------------------------------------------------- G6 mini example-4 LBFGS
 def g6_lbfgs(out):
     node_coords, conn, geom, bc, mn, edges = structured_tri_mesh(41, 21, jitter=0.0, seed=0, dtype=F64)
@@ -316,8 +361,11 @@ def g4_rect(out):
 
 def main():
     groups = {"g5_quadrature": g5_quadrature, "g1_tri3": g1_tri3, "g6_lbfgs": g6_lbfgs,
-              "g3_line": g3_line, "g4_rect": g4_rect}
+              "g3_line": g3_line, "g4_rect": g4_rect, "g7_tri3_f32": g7_tri3_f32}
+    only = sys.argv[1:]                      # `make_golden.py g7_tri3_f32` regenerates one group
     for name, fn in groups.items():
+        if only and name not in only:
+            continue
         out = {}
         fn(out)
         path = os.path.join(HERE, name + ".npz")

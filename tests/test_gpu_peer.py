@@ -218,7 +218,7 @@ def test_fp32_model_owner_sharded_steps_one_rank():
     # the unfused steps (energy -> Adam on the owned float rows -> exchange) against value_and_grad_ + FusedAdam
     from hidenn_fem_amd.optim import FusedAdam
     m1 = _model(d).float()
-    lf = EnergyLoss2D(device=d, dtype=torch.float32)
+    lf = EnergyLoss2D(device=d, dtype=torch.float32, arithmetic="fp64")      # the sharded steps compute in fp64 on float rows
     opt = FusedAdam([dict(params=[m1.node_coords_free], lr=LR_X), dict(params=[m1.u_free], lr=LR_U)])
     l1 = []
     for _ in range(n):

@@ -162,7 +162,7 @@ def test_fp32_model_takes_the_float_storage_kernel_and_matches_fp64_arithmetic()
         m32.u_free.mul_(50.0)
     assert m32.node_coords_free.dtype == torch.float32
     m64 = copy.deepcopy(m32).double()
-    lf32, lf64 = EnergyLoss2D(device=d, dtype=torch.float32), EnergyLoss2D(device=d, dtype=torch.float64)
+    lf32, lf64 = EnergyLoss2D(device=d, dtype=torch.float32, arithmetic="fp64"), EnergyLoss2D(device=d, dtype=torch.float64)
     # an fp32 loss object carries the reference's fp32-rounded constants (C, quadrature sums); same numbers for both
     lf64._mat, lf64._W, lf64._ci, lf64._cj = lf32._mat, lf32._W, lf32._ci, lf32._cj
     l32 = lf32(m32)

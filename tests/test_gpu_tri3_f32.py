@@ -1,0 +1,100 @@
+"""The reference's DEFAULT dtype on the GPU: fp32 models (``/root/reference/src/loss.py:16``, ``src/models.py:274``; examples 1-4
+as shipped) against vectors the reference itself produced IN fp32 (tests/golden/g7_tri3_f32.npz, ex1_f32_* in g3_line.npz --
+make_golden.py runs the reference unmodified, no ``.double()``).
+
+Tolerances.  The reference's own fp32 arithmetic differs from exact arithmetic on the same float inputs by up to 6e-7 x
+max|g| (gradients) and 2e-7 relative (loss) on these meshes (fixture keys ``*64`` = the reference run in fp64 on the same float
+values; tests/test_oracle_golden.py asserts the band).  So:
+* vs the reference's fp32 output: loss rel <= 2e-6, gradients max-abs <= 4e-6 x max|g| -- both sides carry fp32 rounding;
+* fp64-arithmetic instances (float rows widened on load, one rounding on store) vs the ``*64`` values: loss rel <= 1e-7 (the
+  fp32 loss tensor's own rounding), gradients <= 1.3e-7 x max|g| (ONE fp32 rounding);
+* fp32-arithmetic instances vs the ``*64`` values: gradients <= 4e-6 x max|g| -- no worse than the band the reference itself
+  occupies."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import tri_case_forces_f32
+
+pytestmark = pytest.mark.gpu
+F32, F64 = torch.float32, torch.float64
+EPS32 = float(torch.finfo(F32).eps)
+
+
+def _model(g, case, d):
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    p = case + "/"
+    nc = g.t(p + "node_coords")
+    assert nc.dtype == F32
+    m = PiecewiseLinearShapeNN2D(nc, g.t(p + "conn"), boundary_mask=g.t(p + "boundary_mask"), dirichlet_mask=g.t(p + "dirichlet_mask"),
+                                 u_fixed=0.0, neumann_edges=g.t(p + "edges")).to(d)
+    with torch.no_grad():
+        m.u_free.copy_(m.from_caller_order(g.t(p + "u_free").to(d), "u"))
+    assert m.node_coords_free.dtype == F32 and m.u_free.dtype == F32
+    return m
+
+
+def _err(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    return float(np.abs(got.detach().double().cpu().numpy() - want).max() / np.abs(want).max())
+
+
+@pytest.mark.parametrize("arithmetic", ["fp64", "fp32"])
+def test_fp32_models_against_the_reference_run_in_fp32(g_tri_f32, arithmetic):
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    d = torch.device("cuda:0")
+    worst = dict(loss=0.0, g=0.0, loss64=0.0, g64=0.0)
+    for case in g_tri_f32.cases():
+        m = _model(g_tri_f32, case, d)
+        go, go1 = (int(v) for v in g_tri_f32[case + "/gauss_order"])
+        b, t = tri_case_forces_f32(case)
+        lf = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=go, gauss_order_1d=go1, device=d, dtype=F32, arithmetic=arithmetic)
+        loss = lf(m, b_force=b, t_force=t)
+        loss.backward()
+        assert loss.dtype == F32 and m.u_free.grad.dtype == F32
+        gx = m.to_caller_order(m.node_coords_free.grad, "x")
+        gu = m.to_caller_order(m.u_free.grad, "u")
+        p = case + "/"
+        e_l = abs(loss.item() - g_tri_f32[p + "loss"].item()) / abs(g_tri_f32[p + "loss"].item())
+        e_g = max(_err(gx, g_tri_f32[p + "g_coords_free"]), _err(gu, g_tri_f32[p + "g_u_free"]))
+        e_l64 = abs(loss.item() - g_tri_f32[p + "loss64"].item()) / abs(g_tri_f32[p + "loss64"].item())
+        e_g64 = max(_err(gx, g_tri_f32[p + "g_coords_free64"]), _err(gu, g_tri_f32[p + "g_u_free64"]))
+        assert e_l <= 2e-6 and e_g <= 4e-6, (case, arithmetic, e_l, e_g)
+        if arithmetic == "fp64":
+            assert e_l64 <= 1e-7 and e_g64 <= 1.3e-7, (case, e_l64, e_g64)
+        else:
+            assert e_l64 <= 2e-6 and e_g64 <= 4e-6, (case, e_l64, e_g64)
+        for k, v in (("loss", e_l), ("g", e_g), ("loss64", e_l64), ("g64", e_g64)):
+            worst[k] = max(worst[k], v)
+        if b is None and t is None:              # the autograd-free form (default forces) leaves the same rows in .grad
+            m.zero_grad()
+            l2 = lf.value_and_grad_(m)
+            assert abs(l2.item() - loss.item()) <= 4 * EPS32 * abs(loss.item())
+            assert _err(m.to_caller_order(m.u_free.grad, "u"), gu.double().cpu().numpy()) <= (4 * EPS32 if arithmetic == "fp64" else 4e-6)
+    print(f"[fp32 goldens, arithmetic={arithmetic}] worst vs reference-fp32: loss {worst['loss']:.2e} grad {worst['g']:.2e}; "
+          f"vs reference-fp64-on-the-same-floats: loss {worst['loss64']:.2e} grad {worst['g64']:.2e}")
+
+
+def test_example1_as_shipped_fp32_adam_trajectory(g_line):
+    """examples/example1.py:25-42 exactly as the reference ships it -- fp32 model, fp32 data, torch.optim.Adam -- first 20
+    losses against the reference's own fp32 run (ex1_f32_r*: generated since round 1, consumed from round 4 on).  Adam's
+    early steps are lr * sign(g)-like, which amplifies fp32 rounding of near-zero gradient entries: 2e-4 relative."""
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN
+    from hidenn_fem_amd.loss import l2_projection_loss
+    d = torch.device("cuda:0")
+    for r_adapt in (True, False):
+        xg = torch.linspace(0, 1, 100, dtype=F32)
+        xt = torch.linspace(0, 1, 1000, dtype=F32).to(d)
+        ut = torch.sin(2 * torch.pi * xt)
+        m = PiecewiseLinearShapeNN(xg, r_adapt=r_adapt).to(d)
+        assert m.u.dtype == F32
+        opt = torch.optim.Adam(m.parameters(), lr=0.005)
+        got = []
+        for _ in range(20):
+            opt.zero_grad()
+            loss = l2_projection_loss(m, xt, ut)
+            assert loss.dtype == F32
+            loss.backward()
+            opt.step()
+            got.append(loss.item())
+        np.testing.assert_allclose(got, g_line[f"ex1_f32_r{int(r_adapt)}/adam_losses"], rtol=2e-4)

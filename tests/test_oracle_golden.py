@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ref_chain as R
-from conftest import tri_mesh_dict, tri_case_forces
+from conftest import tri_mesh_dict, tri_case_forces, tri_case_forces_f32
 
 F64 = torch.float64
 
@@ -45,6 +45,33 @@ def test_tri3_energy_and_grads_match_reference(g_tri):
         assert loss.item() == g_tri[case + "/loss"].item(), case
         np.testing.assert_allclose(gu.numpy(), g_tri[case + "/g_u_free"], rtol=0, atol=0, err_msg=case)
         np.testing.assert_allclose(gx.numpy(), g_tri[case + "/g_coords_free"], rtol=0, atol=0, err_msg=case)
+
+
+def test_tri3_fp32_as_shipped_matches_reference(g_tri_f32):
+    """The reference's DEFAULT dtype (src/loss.py:16, src/models.py:274): the oracle's op chain in fp32 against the reference
+    run in fp32, and in fp64 on the same float inputs against the reference's fp64 run -- same ATen ops in the same order."""
+    cases = g_tri_f32.cases()
+    assert len(cases) >= 9
+    worst = 0.0
+    for case in cases:
+        mesh, xf, uf = tri_mesh_dict(g_tri_f32, case)
+        assert xf.dtype == torch.float32 and uf.dtype == torch.float32
+        go, go1 = (int(v) for v in g_tri_f32[case + "/gauss_order"])
+        b, t = tri_case_forces_f32(case)
+        mesh32 = dict(mesh, u_fixed=torch.tensor(0.0, dtype=torch.float32))
+        loss, gx, gu = R.energy_and_grads(xf, uf, mesh32, gauss_order=go, gauss_order_1d=go1, b_force=b, t_force=t)
+        assert loss.dtype == torch.float32
+        assert loss.item() == g_tri_f32[case + "/loss"].item(), case
+        np.testing.assert_allclose(gu.numpy(), g_tri_f32[case + "/g_u_free"], rtol=0, atol=0, err_msg=case)
+        np.testing.assert_allclose(gx.numpy(), g_tri_f32[case + "/g_coords_free"], rtol=0, atol=0, err_msg=case)
+        mesh64 = dict(mesh, coords_fixed=mesh["coords_fixed"].double())
+        l64, gx64, gu64 = R.energy_and_grads(xf.double(), uf.double(), mesh64, gauss_order=go, gauss_order_1d=go1, b_force=b, t_force=t)
+        assert l64.item() == g_tri_f32[case + "/loss64"].item(), case
+        np.testing.assert_allclose(gu64.numpy(), g_tri_f32[case + "/g_u_free64"], rtol=0, atol=0, err_msg=case)
+        np.testing.assert_allclose(gx64.numpy(), g_tri_f32[case + "/g_coords_free64"], rtol=0, atol=0, err_msg=case)
+        worst = max(worst, float(np.abs(gx.numpy() - gx64.numpy()).max() / np.abs(gx64.numpy()).max()))
+    # what fp32 arithmetic costs the reference itself on these meshes: the tolerance the fp32 GPU tests are held to
+    assert 1e-8 < worst < 2e-6, worst
 
 
 def test_tri3_domain_edge_split(g_tri):

@@ -36,7 +36,7 @@ struct LbfgsState {                // one record in device memory
     int count, head;               // ring: logical i (0 = oldest) lives in slot (head + i) % M1, i < count
     int new_slot;                  // slot of the pair accepted in this iteration, -1 if none
     int stop_gtd;                  // g.d > -tolerance_change: no update this iteration
-    int pad;
+    int skip;                      // sharded flow: the break tests fired (or the host wants no direction): recursion / direction passes return at once
     double H_diag, t, gtd, cg;     // cg = -H_diag: coefficient of g in d
     double loss, prev_loss;
     double g_absmax, g_abssum, gg, d_absmax, ys, yy;
@@ -209,11 +209,13 @@ __device__ __forceinline__ void lb_load(const T *__restrict__ p, int64_t i, int6
 
 template <typename T, int PER, int VEC = 1>
 __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
-                                                       const T *__restrict__ Yring, int64_t n, int M1) {
+                                                       const T *__restrict__ Yring, int64_t n, int M1, int spec = 0) {
     constexpr int E = PER * VEC;                            // elements per thread
     __shared__ double red[2][5][kLb / 64];
     const LbfgsState &S = *A.st;
-    const int count = S.count, head = S.head, ns = S.new_slot;
+    // spec (sharded flow): the pair sits in the ring's SPARE slot, not yet accepted: dots with it, and its own row of dots
+    const int head = S.head, ns = spec ? (spec > 1 ? -1 : (S.head + S.count) % M1) : S.new_slot;
+    const int count = S.count + (spec == 1 ? 1 : 0);
     const int64_t base = (int64_t)blockIdx.x * (kLb * E) + (int64_t)threadIdx.x * VEC;
     T gv[E], sv[E], yv[E];                                  // in the vectors' own type (fp32 histories: half the registers)
 #pragma unroll
@@ -272,16 +274,17 @@ __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *_
 }
 
 // sum the per-chunk partials: grid = count blocks (logical slot l each)
-__global__ __launch_bounds__(kLb) void multidot_reduce_kernel(LbfgsArrays A, int nb, int M1) {
+__global__ __launch_bounds__(kLb) void multidot_reduce_kernel(LbfgsArrays A, int nb, int M1, double *__restrict__ out = nullptr) {
     __shared__ double red[kLb / 64];
     const LbfgsState &S = *A.st;
-    if ((int)blockIdx.x >= S.count) return;
+    if ((int)blockIdx.x >= S.count + (out ? 1 : 0)) return;       // out != NULL: the sharded flow's payload (spare slot included)
     const int slot = (S.head + blockIdx.x) % M1;
+    double *dst = out ? out : A.dots;
     for (int q = 0; q < 5; ++q) {
         double v = 0.0;
         for (int b = threadIdx.x; b < nb; b += kLb) v += A.part[((int64_t)b * M1 + slot) * 5 + q];
         const double r = block_sum(v, red);
-        if (threadIdx.x == 0) A.dots[slot * 5 + q] = r;
+        if (threadIdx.x == 0) dst[slot * 5 + q] = r;
         __syncthreads();
     }
 }
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(kLb) void multidot_reduce_kernel(LbfgsArrays A, int
 __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, double lr, double tol_change) {
     __shared__ double red[kLb / 64];
     LbfgsState &S = *A.st;
+    if (S.skip) return;
     const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x;
     const int nthr = blockDim.x;         // launched with ONE wave: the 2 x count sequential steps then sync at wave cost
     // Gram row / column of the new pair
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, i
     __shared__ int slot_[kRecMax];
     __shared__ double red[kRecT / 64];
     LbfgsState &S = *A.st;
+    if (S.skip) return;
     const int count = S.count, head = S.head, ns = S.new_slot, k = threadIdx.x;
     if (ns >= 0 && k < count) {                           // Gram row / column of the new pair
         const int j = (head + k) % M1;
@@ -461,10 +466,14 @@ __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, i
 // ---- d = cg g + sum_j cy_j Y_j + cs_j S_j (one pass over the history), max|d| partials [nb]
 // PER elements per thread: 8 for long vectors (fewer, fatter workgroups), 1 for short ones (more workgroups); the slot
 // loop is unrolled so that several slots' loads are in flight (it is latency-bound otherwise).  Same sums either way.
+// g_prev != NULL (sharded flow): prev_flat_grad = g is taken HERE -- i.e. only when a direction is really computed, as torch
+// does (a break after the closure leaves prev_flat_grad alone) -- instead of in the pair pass.
 template <typename T, int PER>
 __global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ Sring,
-                                                        const T *__restrict__ Yring, T *__restrict__ d, int64_t n, int M1) {
+                                                        const T *__restrict__ Yring, T *__restrict__ d, int64_t n, int M1,
+                                                        T *__restrict__ g_prev = nullptr) {
     const LbfgsState &S = *A.st;
+    if (S.skip) return;
     const int count = S.count, head = S.head;
     const int64_t base = (int64_t)blockIdx.x * (kLb * PER) + threadIdx.x;
     const double cg = S.cg;
@@ -472,7 +481,9 @@ __global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int64_t i = base + (int64_t)k * kLb;
-        acc[k] = i < n ? cg * (double)g[i] : 0.0;
+        const T gi = i < n ? g[i] : (T)0;
+        acc[k] = cg * (double)gi;
+        if (g_prev && i < n) g_prev[i] = gi;
     }
 #pragma unroll 4
     for (int l = 0; l < count; ++l) {
@@ -510,7 +521,17 @@ __global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *
     }
 }
 
-__global__ __launch_bounds__(kLb) void dmax_reduce_kernel(LbfgsArrays A, int nb) {
+// status != NULL (sharded flow): the status record is written HERE, after the recursion -- g.d, t and the g.d break flag
+// (bit 3) are those of the direction just computed; bit 4: no direction was computed (break tests / the host's wish)
+__global__ __launch_bounds__(kLb) void dmax_reduce_kernel(LbfgsArrays A, int nb, double *__restrict__ status = nullptr) {
+    if (A.st->skip) {
+        if (status && threadIdx.x == 0) {
+            const LbfgsState &S = *A.st;
+            status[0] = S.loss; status[1] = S.flags + 16.0; status[2] = S.g_absmax; status[3] = S.gtd; status[4] = S.t;
+            status[5] = (double)S.count; status[6] = (double)S.n_iter; status[7] = S.H_diag;
+        }
+        return;
+    }
     double mx = 0.0;
     for (int b = threadIdx.x; b < nb; b += kLb) {
         const double m = A.part[b];
@@ -527,6 +548,178 @@ __global__ __launch_bounds__(kLb) void dmax_reduce_kernel(LbfgsArrays A, int nb)
         double m = mred[0];
         for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
         A.st->d_absmax = m;
+        if (status) {
+            const LbfgsState &S = *A.st;
+            status[0] = S.loss; status[1] = S.flags + (S.stop_gtd ? 8.0 : 0.0); status[2] = S.g_absmax; status[3] = S.gtd;
+            status[4] = S.t; status[5] = (double)S.count; status[6] = (double)S.n_iter; status[7] = S.H_diag;
+        }
+    }
+}
+
+// =====================================================================================================================
+// NODE-SHARDED L-BFGS (hfem_lbfgs_shard_*; hidenn_fem_amd/optim.py ShardedLBFGS): every rank keeps the history, the
+// gradient and the direction of the parameter rows ITS tiles own (n = local length); what crosses ranks per inner
+// iteration is ONE small payload per rank -- the per-slot dots, y.s, y.y, the gradient statistics, max|d| and the rank's
+// partial energy -- gathered to every rank and summed there in RANK ORDER, so that all ranks take bit-identical decisions
+// (accept / reject the pair, every break test) without another message.  To get there in one exchange the pair and its dots
+// are computed SPECULATIVELY: y = g - g_prev, s = t d go into the ring's spare slot and the one pass over the history also
+// takes the dots with that slot; the one-block finish kernel then applies torch's break tests, and only if none fires (and the
+// host wants a direction) accepts the pair, advances the ring and lets the recursion and the direction pass run (S.skip).
+// Payload (doubles): [5 x M1 dots by slot | y.s, y.y, max|g|, sum|g|, g.g, max|d| of the previous direction, the rank's
+// energy, 0].
+constexpr int kShardTail = 8;
+
+// y, s into the spare slot (speculative) + five partial sums per block: y.s, y.y, max|g|, sum|g|, g.g
+template <typename T>
+__global__ __launch_bounds__(kLb) void shard_pair_kernel(LbfgsArrays A, const T *__restrict__ g, const T *__restrict__ g_prev,
+                                                         const T *__restrict__ d, T *__restrict__ Sring, T *__restrict__ Yring,
+                                                         int64_t n, int M1, int first) {
+    __shared__ double red[kLb / 64];
+    const LbfgsState &S = *A.st;
+    const int spare = (S.head + S.count) % M1;
+    const double t = S.t;
+    T *ys_ = Yring + (int64_t)spare * n, *ss_ = Sring + (int64_t)spare * n;
+    double a = 0.0, b = 0.0, mx = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kLb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLb) {
+        const T gi = g[i];
+        const double v = (double)gi, av = fabs(v);
+        mx = av > mx || av != av ? av : mx;
+        s1 += av;
+        s2 += v * v;
+        if (!first) {
+            const T y = gi - g_prev[i];
+            const T sv = (T)((double)d[i] * t);
+            ys_[i] = y; ss_[i] = sv;
+            a += (double)y * (double)sv;
+            b += (double)y * (double)y;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    __shared__ double mred[kLb / 64];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    const double ta = block_sum(a, red);
+    __syncthreads();
+    const double tb = block_sum(b, red);
+    __syncthreads();
+    const double t1 = block_sum(s1, red);
+    __syncthreads();
+    const double t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        double m = mred[0];
+        for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        double *o = A.part + 5 * (int64_t)blockIdx.x;
+        o[0] = ta; o[1] = tb; o[2] = m; o[3] = t1; o[4] = t2;
+    }
+}
+
+// the block partials of shard_pair_kernel -> the payload's tail (+ the rank's energy and the max|d| of its last direction)
+__global__ __launch_bounds__(kLb) void shard_tail_kernel(LbfgsArrays A, int nb, int M1, const double *__restrict__ loss_local,
+                                                         double *__restrict__ payload) {
+    __shared__ double red[kLb / 64];
+    double mx = 0.0, v[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nb; b += kLb) {
+        const double *p = A.part + 5 * (int64_t)b;
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[3]; v[3] += p[4];
+        mx = (p[2] > mx || p[2] != p[2]) ? p[2] : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    __shared__ double mred[kLb / 64];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    double r[4];
+    for (int q = 0; q < 4; ++q) {
+        r[q] = block_sum(v[q], red);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double m = mred[0];
+        for (int w = 1; w < kLb / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        double *t = payload + 5 * M1;
+        t[0] = r[0]; t[1] = r[1]; t[2] = m; t[3] = r[2]; t[4] = r[3];
+        t[5] = A.st->d_absmax;                                   // of this rank's rows, from its last direction pass
+        t[6] = loss_local ? loss_local[0] : 0.0;
+        t[7] = 0.0;
+    }
+    for (int i = threadIdx.x; i < 5 * M1; i += kLb) payload[i] = 0.0;      // slots the multidot reduce does not visit stay 0
+}
+
+// One block: sum the ranks' payloads in rank order, torch's break tests, accept / reject the speculative pair.
+__global__ __launch_bounds__(kLb) void shard_finish_kernel(LbfgsArrays A, const double *__restrict__ gathered, int world, int P,
+                                                           int M1, int first, int after_update, int want_direction,
+                                                           double tol_grad, double tol_change) {
+    for (int i = threadIdx.x; i < 5 * M1; i += kLb) {
+        double v = 0.0;
+        for (int r = 0; r < world; ++r) v += gathered[(int64_t)r * P + i];
+        A.dots[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LbfgsState &S = *A.st;
+        double ys = 0.0, yy = 0.0, gsum = 0.0, gg = 0.0, loss = 0.0, gmax = 0.0, dmax = 0.0;
+        for (int r = 0; r < world; ++r) {
+            const double *t = gathered + (int64_t)r * P + 5 * M1;
+            ys += t[0]; yy += t[1]; gsum += t[3]; gg += t[4]; loss += t[6];
+            gmax = (t[2] > gmax || t[2] != t[2]) ? t[2] : gmax;
+            dmax = (t[5] > dmax || t[5] != t[5]) ? t[5] : dmax;
+        }
+        S.g_absmax = gmax; S.g_abssum = gsum; S.gg = gg; S.loss = loss; S.d_absmax = dmax;
+        int f = 0;
+        if (gmax <= tol_grad) f |= 1;
+        if (after_update) {
+            if (dmax * fabs(S.t) <= tol_change) f |= 2;
+            if (fabs(S.loss - S.prev_loss) < tol_change) f |= 4;
+        }
+        S.flags = (double)f;
+        S.skip = (f != 0 || !want_direction) ? 1 : 0;
+        if (!S.skip) {                                           // pair_reduce_kernel's bookkeeping on the GLOBAL y.s, y.y
+            S.n_iter += 1;
+            S.new_slot = -1;
+            if (first) { S.count = 0; S.head = 0; S.H_diag = 1.0; }
+            else {
+                S.ys = ys; S.yy = yy;
+                if (ys > 1e-10) {
+                    const int m = M1 - 1, slot = (S.head + S.count) % M1;
+                    if (S.count == m) S.head = (S.head + 1) % M1;
+                    else S.count += 1;
+                    A.ro[slot] = 1.0 / ys;
+                    S.H_diag = ys / yy;
+                    S.new_slot = slot;
+                }
+            }
+            S.prev_loss = S.loss;
+        }
+    }
+}
+
+// gather the rows this rank owns into its flat local vector: [x rows | u rows], two values per row
+template <typename T>
+__global__ __launch_bounds__(kLb) void shard_gather_kernel(const T *__restrict__ gx, const int32_t *__restrict__ rx, int64_t nx,
+                                                           const T *__restrict__ gu, const int32_t *__restrict__ ru, int64_t nu,
+                                                           T *__restrict__ out) {
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    for (int64_t i = (int64_t)blockIdx.x * kLb + threadIdx.x; i < nx + nu; i += (int64_t)gridDim.x * kLb) {
+        const pair_t v = i < nx ? reinterpret_cast<const pair_t *>(gx)[rx[i]] : reinterpret_cast<const pair_t *>(gu)[ru[i - nx]];
+        reinterpret_cast<pair_t *>(out)[i] = v;
+    }
+}
+
+// p[row] += t d on the rows this rank owns (nothing if no direction was computed or it stopped on g.d)
+template <typename T>
+__global__ __launch_bounds__(kLb) void shard_apply_kernel(LbfgsArrays A, T *__restrict__ x, const int32_t *__restrict__ rx, int64_t nx,
+                                                          T *__restrict__ u, const int32_t *__restrict__ ru, int64_t nu,
+                                                          const T *__restrict__ d) {
+    const LbfgsState &S = *A.st;
+    if (S.stop_gtd || S.skip) return;
+    const double t = S.t;
+    for (int64_t i = (int64_t)blockIdx.x * kLb + threadIdx.x; i < nx + nu; i += (int64_t)gridDim.x * kLb) {
+        T *p = i < nx ? x + 2 * (int64_t)rx[i] : u + 2 * (int64_t)ru[i - nx];
+        p[0] = (T)((double)p[0] + t * (double)d[2 * i]);
+        p[1] = (T)((double)p[1] + t * (double)d[2 * i + 1]);
     }
 }
 
@@ -597,7 +790,7 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     const size_t nscal = 4 * M1 + 5 * M1 + 2 * M1 * M1;
     if (!rc) rc = lb_malloc(&o->scal, nscal);
     if (!rc) rc = lb_malloc(&o->status, 8);
-    const size_t npart = std::max<size_t>({(size_t)o->nb_md * M1 * 5, (size_t)o->nb_stream * 3, (size_t)o->nb_chunk,
+    const size_t npart = std::max<size_t>({(size_t)o->nb_md * M1 * 5, (size_t)o->nb_stream * 5, (size_t)o->nb_chunk,
                                            (size_t)((n + kLb - 1) / kLb) < 8192 ? (size_t)((n + kLb - 1) / kLb) : 0});
     if (!rc) rc = lb_malloc(&o->A.part, npart);
     if (!rc) rc = lb_malloc(&o->A.st, 1);
@@ -681,6 +874,99 @@ extern "C" int hfem_lbfgs_apply(hfem_lbfgs *o, void *p, int64_t offset, int64_t 
     if (o->dtype == 0) hipLaunchKernelGGL(apply_kernel<double>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, o->A, (double *)p, (const double *)o->d + offset, numel);
     else hipLaunchKernelGGL(apply_kernel<float>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, o->A, (float *)p, (const float *)o->d + offset, numel);
     return launch_status("hfem_lbfgs_apply");
+}
+
+// ---- node-sharded flow (see the block comment above shard_pair_kernel) ------------------------------------------------
+extern "C" int64_t hfem_lbfgs_shard_payload_doubles(const hfem_lbfgs *o) {
+    if (!o) { set_error("hfem_lbfgs_shard_payload_doubles: null optimiser"); return -1; }
+    return 5 * (int64_t)o->M1 + kShardTail;
+}
+
+// Phase 1 (local): g = this rank's flat gradient (n values); speculative pair into the spare slot, ONE pass over the local
+// history, everything another rank needs into payload_dev (hfem_lbfgs_shard_payload_doubles doubles).  loss_local_dev: the
+// rank's partial energy (device scalar) or NULL.  Enqueues only.
+extern "C" int hfem_lbfgs_shard_local(hfem_lbfgs *o, const void *g, const double *loss_local_dev, double *payload_dev, void *stream) {
+    HFEM_ARG_CHECK(o && g && payload_dev, "null pointer");
+    if (int rc = use_device(o->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int first = o->first ? 1 : 0, M1 = o->M1;
+    if (o->dtype == 0) hipLaunchKernelGGL(shard_pair_kernel<double>, dim3(o->nb_stream), dim3(kLb), 0, s, o->A, (const double *)g, (const double *)o->g_prev, (const double *)o->d, (double *)o->Sring, (double *)o->Yring, o->n, M1, first);
+    else hipLaunchKernelGGL(shard_pair_kernel<float>, dim3(o->nb_stream), dim3(kLb), 0, s, o->A, (const float *)g, (const float *)o->g_prev, (const float *)o->d, (float *)o->Sring, (float *)o->Yring, o->n, M1, first);
+    hipLaunchKernelGGL(shard_tail_kernel, dim3(1), dim3(kLb), 0, s, o->A, o->nb_stream, M1, loss_local_dev, payload_dev);
+    if (!first) {
+        int gy = 2048 / o->nb_chunk;
+        gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
+#define HFEM_MD(T, P, V) hipLaunchKernelGGL((multidot_kernel<T, P, V>), dim3(o->nb_md, gy), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, o->n, M1, 1)
+        if (o->dtype == 0) HFEM_MD(double, kLbPer, 1);
+        else if (o->per == 16) HFEM_MD(float, 8, 2);
+        else HFEM_MD(float, kLbPer, 1);
+#undef HFEM_MD
+        hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1), dim3(kLb), 0, s, o->A, o->nb_md, M1, payload_dev);
+    }
+    return launch_status("hfem_lbfgs_shard_local");
+}
+
+// Phase 2 (after the payloads of all `world` ranks were gathered to gathered_dev [world][payload doubles], rank order): the
+// global sums, torch's break tests (after_update: also the lack-of-progress tests), and -- unless one fired or
+// want_direction == 0 -- the memory update, the recursion and this rank's part of the direction (prev_flat_grad = g is taken
+// then, as in torch).  status_host[8] as hfem_lbfgs_check, g.d / t / bit 3 of the direction JUST computed, bit 4 (16): no
+// direction was computed.  Identical on every rank by construction.  Synchronises the stream.
+extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const double *gathered_dev, int32_t world, int32_t after_update,
+                                       int32_t want_direction, double lr, double tol_grad, double tol_change, double *status_host,
+                                       void *stream) {
+    HFEM_ARG_CHECK(o && g && gathered_dev && status_host, "null pointer");
+    HFEM_ARG_CHECK(world >= 1, "world must be >= 1");
+    if (int rc = use_device(o->device)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int first = o->first ? 1 : 0, M1 = o->M1;
+    hipLaunchKernelGGL(shard_finish_kernel, dim3(1), dim3(kLb), 0, s, o->A, gathered_dev, (int)world, 5 * M1 + kShardTail, M1, first,
+                       (int)after_update, (int)want_direction, tol_grad, tol_change);
+    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
+    else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
+    const int per_dir = o->nb_chunk >= 1024 ? kLbPer : (o->n >= (1 << 20) ? (o->dtype == 0 ? 2 : 4) : 1);
+    const int nb_dir = (int)((o->n + (int64_t)per_dir * kLb - 1) / ((int64_t)per_dir * kLb));
+#define HFEM_DIR(T, P) hipLaunchKernelGGL((direction_kernel<T, P>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, (T *)o->d, o->n, M1, (T *)o->g_prev)
+    if (o->dtype == 0) {
+        if (per_dir == kLbPer) HFEM_DIR(double, kLbPer);
+        else if (per_dir == 2) HFEM_DIR(double, 2);
+        else HFEM_DIR(double, 1);
+    } else {
+        if (per_dir == kLbPer) HFEM_DIR(float, kLbPer);
+        else if (per_dir == 4) HFEM_DIR(float, 4);
+        else HFEM_DIR(float, 1);
+    }
+#undef HFEM_DIR
+    hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, nb_dir, o->status);
+    if (int rc = launch_status("hfem_lbfgs_shard_finish")) return rc;
+    HFEM_HIP_CHECK(hipMemcpyAsync(status_host, o->status, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HFEM_HIP_CHECK(hipStreamSynchronize(s));
+    if (!((int)status_host[1] & 16)) o->first = false;          // a direction exists from now on
+    return 0;
+}
+
+// this rank's flat gradient from the gradient ROW arrays: out = [gx rows rows_x | gu rows rows_u] (two values per row; the
+// optimiser's dtype); out NULL = into the optimiser's own buffer (returned by hfem_lbfgs_shard_grad_ptr)
+extern "C" int hfem_lbfgs_shard_gather(hfem_lbfgs *o, const void *gx, const int32_t *rows_x, int64_t nx, const void *gu,
+                                       const int32_t *rows_u, int64_t nu, void *out, void *stream) {
+    HFEM_ARG_CHECK(o && out && (gx || nx == 0) && (gu || nu == 0), "null pointer");
+    HFEM_ARG_CHECK(2 * (nx + nu) == o->n, "row counts do not match the optimiser's length (two values per row)");
+    if (int rc = use_device(o->device)) return rc;
+    const int grid = (int)std::min<int64_t>((nx + nu + kLb - 1) / kLb, 4096);
+    if (o->dtype == 0) hipLaunchKernelGGL(shard_gather_kernel<double>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, (const double *)gx, rows_x, nx, (const double *)gu, rows_u, nu, (double *)out);
+    else hipLaunchKernelGGL(shard_gather_kernel<float>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, (const float *)gx, rows_x, nx, (const float *)gu, rows_u, nu, (float *)out);
+    return launch_status("hfem_lbfgs_shard_gather");
+}
+
+// x[rows_x], u[rows_u] += t d on the rows this rank owns (nothing if no direction was computed or it stopped on g.d)
+extern "C" int hfem_lbfgs_shard_apply(hfem_lbfgs *o, void *x, const int32_t *rows_x, int64_t nx, void *u, const int32_t *rows_u,
+                                      int64_t nu, void *stream) {
+    HFEM_ARG_CHECK(o && (x || nx == 0) && (u || nu == 0), "null pointer");
+    HFEM_ARG_CHECK(2 * (nx + nu) == o->n, "row counts do not match the optimiser's length (two values per row)");
+    if (int rc = use_device(o->device)) return rc;
+    const int grid = (int)std::min<int64_t>((nx + nu + kLb - 1) / kLb, 4096);
+    if (o->dtype == 0) hipLaunchKernelGGL(shard_apply_kernel<double>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, o->A, (double *)x, rows_x, nx, (double *)u, rows_u, nu, (const double *)o->d);
+    else hipLaunchKernelGGL(shard_apply_kernel<float>, dim3(grid), dim3(kLb), 0, (hipStream_t)stream, o->A, (float *)x, rows_x, nx, (float *)u, rows_u, nu, (const float *)o->d);
+    return launch_status("hfem_lbfgs_shard_apply");
 }
 
 // device pointer of the direction d (flat, n elements of the optimiser's dtype): for tests / callers that

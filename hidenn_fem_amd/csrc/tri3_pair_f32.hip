@@ -7,9 +7,12 @@
 //     two), the node image is half the bytes;
 //   * the two elements of a slot, A = (n, b, c) and B = (n, c, d), are evaluated SIDE BY SIDE in the two halves of packed fp32
 //     registers (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): a pair costs the vector instructions of one element;
-//   * gradient accumulators are four float arrays in LDS (ds_add_f32), rows leave as float2.
-// The tile energy is accumulated in fp64 (one v_cvt + one v_add_f64 per slot): the loss is better than the reference's fp32
-// sum, never worse.  Accuracy contract (tests/test_gpu_tri3_f32.py): within the band the reference's own fp32 run occupies
+//   * gradient accumulators stay four DOUBLE arrays in LDS (ds_add_f64): gfx950 services ds_add_f32 lane by lane -- the
+//     first version of this kernel, with float accumulators, took 46.9 us on T1M against 9.1 us for the fp64-arithmetic
+//     float-row instance (profiles/r04: fp32_first_try.json) --, while ds_add_f64 goes 16 lanes per LDS cycle; each
+//     contribution is widened (v_cvt_f64_f32) on the way in, rows are rounded ONCE on the way out, as float2.
+// The tile energy is accumulated in fp64 too (one v_cvt + one v_add_f64 per slot): loss and gradient SUMS are better than the
+// reference's fp32 sums, never worse.  Accuracy contract (tests/test_gpu_tri3_f32.py): within the band the reference's own fp32 run occupies
 // around exact arithmetic on the same float inputs (gradients <= 4e-6 x max|g|); the fp64-arithmetic float-row instances of
 // tri3_pair.hip stay available as the accurate option (hfem_tri3_energy_plan_f32 without HFEM_FLAG_FP32_MATH).
 // HBM-bound by construction, no MFMA (2x2 / 2x3 contractions).  Algorithmic bytes per launch: 12 Ne + 32 Nn + 8.
@@ -95,9 +98,9 @@ __device__ __forceinline__ f2 tri3_pair_f32(const f2 X0x, const f2 X0y, const f2
 
 // BLOCK threads per tile; NPT >= ceil(max nodes / BLOCK), EPT >= ceil(max slots / BLOCK); CAPO / CAPN > 0: compile-time LDS
 // strides of the default tile shape.  SP: cache policy of the gradient stores (16 sc1 write-through, 2 nt).  LDS:
-// float4 nd[cap_n] | float acc[4][cap_owned] | double red[BLOCK / 64].
+// float4 nd[cap_n] | double acc[4][cap_owned] | double red[BLOCK / 64].
 template <int BLOCK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 6) void tri3_energy_pair_f32_kernel(
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_f32_kernel(
     PlanDev pd, int tile_begin, const float2 *__restrict__ x_free, const float2 *__restrict__ x_fixed,
     const float2 *__restrict__ u_free, const float2 *__restrict__ u_fixed, Tri3ConstsF k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
@@ -107,9 +110,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 6) void tri3_energy_pair_
     const int cap_n = CAPN > 0 ? CAPN : cap_nodes;
     extern __shared__ float4 lds4[];
     float4 *nd = lds4;
-    float *acc0 = reinterpret_cast<float *>(lds4 + cap_n);
-    float *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
-    double *red = reinterpret_cast<double *>(acc3 + cap_owned);       // cap_owned is a multiple of 2: 8-byte aligned
+    double *acc0 = reinterpret_cast<double *>(lds4 + cap_n);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
 
     const int tid = threadIdx.x;
     const int bid = (int)blockIdx.x;
@@ -162,13 +165,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 6) void tri3_energy_pair_
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
         if (l < d.n_node) nd[l] = make_float4(vx[j].x, vx[j].y, vu[j].x, vu[j].y);
-        if (l < n_owned) { acc0[l] = 0.0f; acc1[l] = 0.0f; acc2[l] = 0.0f; acc3[l] = 0.0f; }
+        if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     __syncthreads();
 
     auto add_row = [&](int l, float gx, float gy, float gu, float gv) {
-        unsafeAtomicAdd(&acc0[l], gx); unsafeAtomicAdd(&acc1[l], gy);
-        unsafeAtomicAdd(&acc2[l], gu); unsafeAtomicAdd(&acc3[l], gv);
+        unsafeAtomicAdd(&acc0[l], (double)gx); unsafeAtomicAdd(&acc1[l], (double)gy);
+        unsafeAtomicAdd(&acc2[l], (double)gu); unsafeAtomicAdd(&acc3[l], (double)gv);
     };
     double e_loc = 0.0;
 #pragma unroll
@@ -226,11 +229,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 6) void tri3_energy_pair_
         const int l = tid + j * BLOCK;
         if (l < n_owned) {
             if (gx_free && s[j].x >= 0) {
-                const float2 v = make_float2(acc0[l], acc1[l]);
+                const float2 v = make_float2((float)acc0[l], (float)acc1[l]);       // rounded once
                 __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, SP);
             }
             if (gu_free && s[j].y >= 0) {
-                const float2 v = make_float2(acc2[l], acc3[l]);
+                const float2 v = make_float2((float)acc2[l], (float)acc3[l]);
                 __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, SP);
             }
         }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 6) void tri3_energy_pair_
 template <int BLK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
 static void launch_pair_f32_inst(const PairLaunch &A, const Tri3ConstsF &kf, const LagSum &lag) {
     const int cap_n = CAPN > 0 ? CAPN : ((A.max_nodes + 1) & ~1), cap_o = CAPO > 0 ? CAPO : ((A.max_owned + 1) & ~1);
-    const size_t lds = (size_t)cap_n * 16 + (size_t)cap_o * 16 + 8 * (BLK / 64);
+    const size_t lds = (size_t)cap_n * 16 + (size_t)cap_o * 32 + 8 * (BLK / 64);
     hipLaunchKernelGGL((tri3_energy_pair_f32_kernel<BLK, NPT, EPT, CAPO, CAPN, SP, HASB>), dim3(A.grid), dim3(BLK), lds, A.s, A.pd,
                        A.tile_begin, (const float2 *)A.x_free, (const float2 *)A.x_fixed, (const float2 *)A.u_free,
                        (const float2 *)A.u_fixed, kf, A.T_edge, A.tc, A.partials, (float2 *)A.gx, (float2 *)A.gu, cap_n, cap_o,

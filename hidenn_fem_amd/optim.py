@@ -408,6 +408,129 @@ class FusedLBFGS(torch.optim.Optimizer):
         return list(self._status)
 
 
+class ShardedLBFGS:
+    """``torch.optim.LBFGS(model.parameters())`` as ``/root/reference/examples/example4.py:68-78`` drives it (lr 1, max_iter 20,
+    max_eval 25, tolerance_grad 1e-7, tolerance_change 1e-9, history 100, no line search) with the optimiser NODE-SHARDED over
+    the ranks of a ``ShardedTri3Energy``: every rank keeps the (s, y) history, the gradient and the direction of the parameter
+    rows ITS tiles own -- at BASELINE size the two passes over the 2 x 100 history vectors (6.4 GB, 1.24 ms on one MI355X)
+    ARE example 4's iteration, and they shrink by the number of ranks.  Per inner iteration two small exchanges cross ranks:
+    the interface parameter rows before the energy launch (the owner-sharded evaluation's own exchange) and ONE payload per
+    rank with everything the recursion needs (per-slot dots, y.s, y.y, gradient statistics, max|d|, the partial energy),
+    summed in rank order on every rank -- all ranks take bit-identical decisions (csrc/lbfgs.hip, hfem_lbfgs_shard_*).
+    Same algorithm and break tests as ``torch/optim/lbfgs.py`` / ``FusedLBFGS``; the closure is the sharded energy itself.
+    HIP evaluator only; fp64 and fp32 models; one ``step()`` = one ``optimizer.step(closure)`` of the reference's loop."""
+
+    def __init__(self, sharded, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
+        import ctypes as C
+        sh = self.sh = sharded
+        if not sh._hip:
+            raise RuntimeError("ShardedLBFGS needs the HIP evaluator")
+        if not hasattr(sh, "iface_rows"):
+            sh.setup_interfaces()
+        self.lr, self.max_iter = float(lr), int(max_iter)
+        self.max_eval = int(max_eval) if max_eval is not None else self.max_iter * 5 // 4
+        self.tolerance_grad, self.tolerance_change = float(tolerance_grad), float(tolerance_change)
+        m = sh.model
+        dev = m.node_coords_free.device
+        rx, ru = sh.owned_rows()
+        self._rx, self._ru = rx.to(torch.int32).contiguous(), ru.to(torch.int32).contiguous()
+        self._n = 2 * (self._rx.numel() + self._ru.numel())
+        self._dtype = m.node_coords_free.dtype
+        self._g = torch.zeros(self._n, dtype=self._dtype, device=dev)
+        self._h = C.c_void_p()
+        L = _lib.lib()
+        check(L.hfem_lbfgs_create(dev_index(dev), max(self._n, 1), int(history_size), 0 if self._dtype == torch.float64 else 1,
+                                  C.byref(self._h)), "hfem_lbfgs_create")
+        P = int(L.hfem_lbfgs_shard_payload_doubles(self._h))
+        self._payload = torch.zeros(P, dtype=torch.float64, device=dev)
+        self._gathered = torch.zeros(sh.world * P, dtype=torch.float64, device=dev) if sh.world > 1 else self._payload
+        self._loss_local = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._status = (C.c_double * 8)()
+        self.state = dict(func_evals=0, n_iter=0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().hfem_lbfgs_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _evaluate(self):
+        """Interface rows of the parameters in, then the energy over this rank's tiles: the gradient of the owned rows into the
+        flat local vector, the rank's partial energy into a device scalar."""
+        sh, L = self.sh, _lib.lib()
+        m = sh.model
+        dev = m.node_coords_free.device
+        if sh.world > 1:
+            sh.exchange_halo()                      # foreign interface rows (its energy slot is not used here)
+        sh._eval_range(sh.lo, sh.hi, 0, False)      # HFEM_FLAG_NO_LOSS_SUM: the tile energies stay in the plan
+        check(L.hfem_plan_loss_sum(sh.plan.handle, int(sh.lo), int(sh.hi), ptr(self._loss_local), stream_ptr(dev)), "hfem_plan_loss_sum")
+        _, gx, gu = sh._views(sh.send)
+        check(L.hfem_lbfgs_shard_gather(self._h, ptr(gx), ptr(self._rx), self._rx.numel(), ptr(gu), ptr(self._ru), self._ru.numel(),
+                                        ptr(self._g), stream_ptr(dev)), "hfem_lbfgs_shard_gather")
+
+    def _reduce(self, after_update: int, want_direction: bool) -> int:
+        """local sums -> ONE exchange -> finish (break tests, memory update, recursion, this rank's part of d); the flags."""
+        sh, L = self.sh, _lib.lib()
+        dev = self._g.device
+        check(L.hfem_lbfgs_shard_local(self._h, ptr(self._g), ptr(self._loss_local), ptr(self._payload), stream_ptr(dev)),
+              "hfem_lbfgs_shard_local")
+        if sh.world > 1:
+            if sh.comm is not None:
+                sh.comm.all_gather(self._payload, self._gathered)
+            else:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(self._gathered, self._payload, group=sh.group)
+        check(L.hfem_lbfgs_shard_finish(self._h, ptr(self._g), ptr(self._gathered), int(sh.world), int(after_update),
+                                        1 if want_direction else 0, self.lr, self.tolerance_grad, self.tolerance_change,
+                                        self._status, stream_ptr(dev)), "hfem_lbfgs_shard_finish")
+        return int(self._status[1])
+
+    @torch.no_grad()
+    def step(self) -> torch.Tensor:
+        """One ``optimizer.step(closure)`` of the reference's loop; returns the (global) energy of its FIRST evaluation."""
+        sh, L = self.sh, _lib.lib()
+        m = sh.model
+        dev = self._g.device
+        self._evaluate()
+        flags = self._reduce(0, True)
+        orig_loss = float(self._status[0])
+        current_evals = 1
+        self.state["func_evals"] += 1
+        out = torch.tensor(orig_loss, dtype=torch.float64, device=dev)
+        if flags & 1:                                            # optimal condition
+            return out
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            self.state["n_iter"] += 1
+            if flags & 8:                                        # g.d > -tolerance_change: nothing is applied
+                break
+            check(L.hfem_lbfgs_shard_apply(self._h, ptr(m.node_coords_free.data), ptr(self._rx), self._rx.numel(),
+                                           ptr(m.u_free.data), ptr(self._ru), self._ru.numel(), stream_ptr(dev)), "hfem_lbfgs_shard_apply")
+            if n_iter == self.max_iter:
+                break
+            self._evaluate()
+            current_evals += 1
+            self.state["func_evals"] += 1
+            want = current_evals < self.max_eval
+            flags = self._reduce(1, want)
+            if not want or flags & 7:
+                break
+        return out
+
+    def finish(self):
+        """Make every rank's copy of the parameters complete (the rows other ranks own that this rank's tiles read): call before
+        reading ``model.coords`` / ``u_full`` on a rank, or before switching to another optimiser."""
+        if self.sh.world > 1:
+            self.sh.exchange_halo()
+
+    def status(self):
+        """Last status record: loss, flags, max|g|, g.d, t, history count, n_iter, H_diag (identical on every rank)."""
+        return list(self._status)
+
+
 class EnergyAdamStep:
     """One launch per training iteration of a triangular elasticity model: energy, gradients AND torch.optim.Adam's
     update (``hfem_tri3_energy_adam_step``).  Every free row is owned by exactly one tile, which has the row's complete

@@ -387,6 +387,27 @@ int hfem_lbfgs_check(hfem_lbfgs *opt, const void *g, const double *loss, int32_t
 int hfem_lbfgs_direction(hfem_lbfgs *opt, const void *g, double lr, double tol_change, void *stream);
 int hfem_lbfgs_apply(hfem_lbfgs *opt, void *p, int64_t offset, int64_t numel, void *stream);
 void *hfem_lbfgs_direction_ptr(hfem_lbfgs *opt);
+/* NODE-SHARDED L-BFGS (hidenn_fem_amd/optim.py ShardedLBFGS; no reference counterpart -- the reference runs example 4 on one
+ * device).  The optimiser object holds the history, gradient copy and direction of the parameter rows ONE RANK owns (n = 2 x
+ * its owned rows); per inner iteration every rank
+ *     hfem_lbfgs_shard_gather (its gradient rows -> flat local vector)
+ *     hfem_lbfgs_shard_local  (speculative pair + ONE pass over its history -> a payload of
+ *                              hfem_lbfgs_shard_payload_doubles() doubles: per-slot dots, y.s, y.y, gradient statistics,
+ *                              max|d|, its partial energy)
+ *     [the caller gathers the payloads of all ranks to every rank, rank order: one small all_gather / peer-window put]
+ *     hfem_lbfgs_shard_finish (sums in rank order -> torch's break tests -> memory update, recursion, its part of d; status)
+ *     hfem_lbfgs_shard_apply  (x[rows], u[rows] += t d)
+ * so the two passes over the history shrink by the number of ranks and every rank takes bit-identical decisions.  With
+ * world = 1 (gathered = the payload itself) the flow is torch.optim.LBFGS / hfem_lbfgs_direction on one device.           */
+int64_t hfem_lbfgs_shard_payload_doubles(const hfem_lbfgs *opt);
+int hfem_lbfgs_shard_gather(hfem_lbfgs *opt, const void *gx, const int32_t *rows_x, int64_t nx, const void *gu,
+                            const int32_t *rows_u, int64_t nu, void *out, void *stream);
+int hfem_lbfgs_shard_local(hfem_lbfgs *opt, const void *g, const double *loss_local_dev, double *payload_dev, void *stream);
+int hfem_lbfgs_shard_finish(hfem_lbfgs *opt, const void *g, const double *gathered_dev, int32_t world, int32_t after_update,
+                            int32_t want_direction, double lr, double tol_grad, double tol_change, double *status_host,
+                            void *stream);
+int hfem_lbfgs_shard_apply(hfem_lbfgs *opt, void *x, const int32_t *rows_x, int64_t nx, void *u, const int32_t *rows_u,
+                           int64_t nu, void *stream);
 
 /* ------------------------------------------------------------------ post-processing
  * hfem_tri3_von_mises: per element, grad_u at the centroid (constant on a P1 triangle; reference

@@ -6,8 +6,9 @@ Tolerances.  The reference's own fp32 arithmetic differs from exact arithmetic o
 max|g| (gradients) and 2e-7 relative (loss) on these meshes (fixture keys ``*64`` = the reference run in fp64 on the same float
 values; tests/test_oracle_golden.py asserts the band).  So:
 * vs the reference's fp32 output: loss rel <= 2e-6, gradients max-abs <= 4e-6 x max|g| -- both sides carry fp32 rounding;
-* fp64-arithmetic instances (float rows widened on load, one rounding on store) vs the ``*64`` values: loss rel <= 1e-7 (the
-  fp32 loss tensor's own rounding), gradients <= 1.3e-7 x max|g| (ONE fp32 rounding);
+* fp64-arithmetic instances (float rows widened on load, one rounding on store) vs the ``*64`` values: loss rel and gradients
+  <= 2.5e-7 (ONE fp32 rounding of the result, plus the fp32 loss object's fp32-rounded constants C, W -- the ``*64`` run used
+  fp64 constants);
 * fp32-arithmetic instances vs the ``*64`` values: gradients <= 4e-6 x max|g| -- no worse than the band the reference itself
   occupies."""
 import numpy as np
@@ -61,7 +62,7 @@ def test_fp32_models_against_the_reference_run_in_fp32(g_tri_f32, arithmetic):
         e_g64 = max(_err(gx, g_tri_f32[p + "g_coords_free64"]), _err(gu, g_tri_f32[p + "g_u_free64"]))
         assert e_l <= 2e-6 and e_g <= 4e-6, (case, arithmetic, e_l, e_g)
         if arithmetic == "fp64":
-            assert e_l64 <= 1e-7 and e_g64 <= 1.3e-7, (case, e_l64, e_g64)
+            assert e_l64 <= 2.5e-7 and e_g64 <= 2.5e-7, (case, e_l64, e_g64)
         else:
             assert e_l64 <= 2e-6 and e_g64 <= 4e-6, (case, e_l64, e_g64)
         for k, v in (("loss", e_l), ("g", e_g), ("loss64", e_l64), ("g64", e_g64)):

@@ -48,17 +48,19 @@ def build(force: bool = False, keep_temps: bool = False, lab: bool = False) -> s
 
     def compile_one(pair):
         src, obj = pair
-        if not force and not _stale(obj, [src] + hdrs + [__file__]):
+        res = obj + ".resource.txt"
+        if not force and not _stale(obj, [src] + hdrs + [__file__]) and os.path.exists(res):
             return
-        cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj]
+        # the compiler's per-kernel resource report (VGPRs, scratch, occupancy) is always kept beside the object:
+        # tests/test_build_resources.py holds the product to "no scratch, <= 100 pair-kernel instances"
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
         if keep_temps:
-            cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            cmd += ["-save-temps=obj"]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=bdir)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        if keep_temps and r.stderr:
-            with open(obj + ".resource.txt", "w") as f:
-                f.write(r.stderr)
+        with open(res, "w") as f:
+            f.write(r.stderr)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
@@ -67,6 +69,24 @@ def build(force: bool = False, keep_temps: bool = False, lab: bool = False) -> s
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
+def resource_usage(lab: bool = False):
+    """``{kernel mangled name: dict(vgprs, scratch, occupancy, source)}`` of the last build (``-Rpass-analysis=kernel-resource-usage``)."""
+    import re
+    bdir = os.path.join(HERE, "build", "lab") if lab else os.path.join(HERE, "build")
+    out = {}
+    for s in SOURCES:
+        path = os.path.join(bdir, os.path.splitext(s)[0] + ".o.resource.txt")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run build() first")
+        text = open(path).read()
+        for blk in text.split("Function Name: ")[1:]:
+            name = blk.split()[0]
+            get = lambda key: int(re.search(key + r": (\d+)", blk).group(1))
+            out[name] = dict(vgprs=get(r" VGPRs"), scratch=get(r"ScratchSize \[bytes/lane\]"), occupancy=get(r"Occupancy \[waves/SIMD\]"),
+                             source=s)
     return out
 
 

@@ -432,8 +432,8 @@ __global__ __launch_bounds__(kBlockL) void rectq4_eval_bwd_kernel(
     for (int64_t q = (int64_t)blockIdx.x * kBlockL + threadIdx.x; q < m; q += stride) {
         const typename Row2<T>::type pt = x_eval[q];
         const Q4 c = q4_eval(gx, nx, gy, ny, u, (double)pt.x, (double)pt.y);
-        double2 gpt;
-        q4_backward(c, (double)cot[q], ny, ggx, ggy, gu, gx_eval ? &gpt : nullptr);
+        double2 gpt;                                        // always taken (a conditional address of a local lands in scratch)
+        q4_backward(c, (double)cot[q], ny, ggx, ggy, gu, &gpt);
         if (gx_eval) {
             typename Row2<T>::type o;
             o.x = (T)gpt.x; o.y = (T)gpt.y;

@@ -737,10 +737,11 @@ __global__ __launch_bounds__(256) void quad4_det_grad_kernel(
             Un[j] = q4_row(u_free, u_fixed, u_src[nj]);
         }
         quad4_element<true, true, PHYS>(Xn, Un, k, gx, gu, body.b);
-        const double2 px = c == 0 ? gx[0] : (c == 1 ? gx[1] : (c == 2 ? gx[2] : gx[3]));
-        const double2 pu = c == 0 ? gu[0] : (c == 1 ? gu[1] : (c == 2 ? gu[2] : gu[3]));
-        sx.x += px.x; sx.y += px.y;
-        su.x += pu.x; su.y += pu.y;
+        // this node's corner by 0 / 1 weights, not by a select chain (which the compiler turns into an indexed load of a scratch
+        // copy of the arrays); exact for finite rows (tri3_det.hip)
+        const double m0 = c == 0 ? 1.0 : 0.0, m1 = c == 1 ? 1.0 : 0.0, m2 = c == 2 ? 1.0 : 0.0, m3 = c == 3 ? 1.0 : 0.0;
+        sx.x += (m0 * gx[0].x + m1 * gx[1].x) + (m2 * gx[2].x + m3 * gx[3].x); sx.y += (m0 * gx[0].y + m1 * gx[1].y) + (m2 * gx[2].y + m3 * gx[3].y);
+        su.x += (m0 * gu[0].x + m1 * gu[1].x) + (m2 * gu[2].x + m3 * gu[3].x); su.y += (m0 * gu[0].y + m1 * gu[1].y) + (m2 * gu[2].y + m3 * gu[3].y);
     }
     if (!skip_edges)
         for (int32_t i = eadj_ptr[n]; i < eadj_ptr[n + 1]; ++i) {
@@ -750,8 +751,9 @@ __global__ __launch_bounds__(256) void quad4_det_grad_kernel(
             double2 gx[2], gu[2];
             edge2_element<true>(q4_row(x_free, x_fixed, x_src[ni]), q4_row(x_free, x_fixed, x_src[nj]),
                                 q4_row(u_free, u_fixed, u_src[ni]), q4_row(u_free, u_fixed, u_src[nj]), tt, gx, gu);
-            sx.x += gx[end].x; sx.y += gx[end].y;
-            su.x += gu[end].x; su.y += gu[end].y;
+            const double2 px = end ? gx[1] : gx[0], pu = end ? gu[1] : gu[0];      // selects, not a dynamic index (that puts the arrays in scratch)
+            sx.x += px.x; sx.y += px.y;
+            su.x += pu.x; su.y += pu.y;
         }
     const int32_t rx = x_src[n], ru = u_src[n];
     if (gx_free && rx >= 0) gx_free[rx] = sx;

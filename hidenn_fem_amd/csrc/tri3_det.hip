@@ -45,10 +45,12 @@ __global__ __launch_bounds__(kDetBlock) void tri3_det_grad_kernel(
         tri3_element<true, true, PHYS>(row_of(x_free, x_fixed, x_src[n0]), row_of(x_free, x_fixed, x_src[n1]),
                                        row_of(x_free, x_fixed, x_src[n2]), row_of(u_free, u_fixed, u_src[n0]),
                                        row_of(u_free, u_fixed, u_src[n1]), row_of(u_free, u_fixed, u_src[n2]), k, gx, gu);
-        const double2 px = c == 0 ? gx[0] : (c == 1 ? gx[1] : gx[2]);
-        const double2 pu = c == 0 ? gu[0] : (c == 1 ? gu[1] : gu[2]);
-        sx.x += px.x; sx.y += px.y;
-        su.x += pu.x; su.y += pu.y;
+        // this node's corner by 0 / 1 weights, not by a select chain: the compiler turns `c == 0 ? g[0] : ...` into an indexed
+        // load of a SCRATCH copy of the arrays.  Exact (x * 1 + y * 0 + z * 0) for finite rows; an element whose rows are not
+        // finite (det = 0) has no finite corner anyway.
+        const double m0 = c == 0 ? 1.0 : 0.0, m1 = c == 1 ? 1.0 : 0.0, m2 = c == 2 ? 1.0 : 0.0;
+        sx.x += m0 * gx[0].x + m1 * gx[1].x + m2 * gx[2].x; sx.y += m0 * gx[0].y + m1 * gx[1].y + m2 * gx[2].y;
+        su.x += m0 * gu[0].x + m1 * gu[1].x + m2 * gu[2].x; su.y += m0 * gu[0].y + m1 * gu[1].y + m2 * gu[2].y;
     }
     if (!skip_edges)
         for (int32_t i = eadj_ptr[n]; i < eadj_ptr[n + 1]; ++i) {
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(kDetBlock) void tri3_det_grad_kernel(
             double2 gx[2], gu[2];
             edge2_element<true>(row_of(x_free, x_fixed, x_src[ni]), row_of(x_free, x_fixed, x_src[nj]),
                                 row_of(u_free, u_fixed, u_src[ni]), row_of(u_free, u_fixed, u_src[nj]), tt, gx, gu);
-            sx.x += gx[end].x; sx.y += gx[end].y;
-            su.x += gu[end].x; su.y += gu[end].y;
+            const double2 px = end ? gx[1] : gx[0], pu = end ? gu[1] : gu[0];      // selects, not a dynamic index (that puts the arrays in scratch)
+            sx.x += px.x; sx.y += px.y;
+            su.x += pu.x; su.y += pu.y;
         }
     const int32_t rx = x_src[n], ru = u_src[n];
     if (gx_free && rx >= 0) gx_free[rx] = sx;

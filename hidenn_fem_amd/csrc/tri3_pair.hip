@@ -304,13 +304,21 @@ static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const Adam
 }
 template <int BLK, int NPT, int EPT, int CAPO, bool HASB, bool PHYS, typename V2, bool ADAM>
 static void launch_pair_inst(const PairLaunch &A, const LagSum &lag, const AdamFuse &af) {
-    if (A.chain) launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, true>(A, lag, af);
-    else launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, false>(A, lag, af);
+#ifdef HFEM_LAB
+    if (A.chain) { launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, true>(A, lag, af); return; }   // strip order: lab evidence only
+#endif
+    launch_pair_inst2<BLK, NPT, EPT, CAPO, HASB, PHYS, V2, ADAM, false>(A, lag, af);
 }
 
 // Launch on a paired plan: picks the instance that holds the plan's tile shape.  1 = launched, 0 = none does.
 // mode: 0 fp64 reference convention (zero body force), 1 general fp64 (body force and / or physical convention),
 //       2 fp32 rows, 3 fused Adam write-out on fp64 rows, 4 the same on fp32 rows (3, 4: hasb selects the body-force instance).
+// Instance matrix (round 4: 92 instances in the product, 209 before; tests/test_build_resources.py holds the count and
+// "no scratch"): the hot modes (0, 2, 3, 4 without a body force) get the exact shapes -- NPT 3 | 4 nodes per thread, 3 | 4 | 6
+// slot rows (a five-row plan takes the six-row instance: one masked row), the compile-time-stride instance of the default
+// tile, nt stores for the big-mesh policy, and the in-launch get (PG) of each; body force and the physical convention -- not
+// the reference's defaults (src/loss.py:43-45, src/models.py:351) -- share ONE generic shape per block size (<256, 4, 6> /
+// <512, 2, 2>).  Chained records (strip order, plan_elem_order 6) and the store-policy A/B instances exist in the lab build only.
 int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
                      const AdamFuse &af) {
     const HostPlan &h = plan->host;
@@ -320,6 +328,9 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned; A.lds = (size_t)plan->lds_bytes;
     A.col_stride = h.col_stride;
     if (A.chain < 0) A.chain = h.n_chained > 0 ? 1 : 0;   // chained records need the carrying slot loop
+#ifndef HFEM_LAB
+    if (A.chain) return 0;                                // product: no carrying slot loop (it measured slower)
+#endif
     if (h.pair_block == 512) {
         // 512 threads per tile (shard-aware tile policy, hfem_plan_create: launches of 100 k - 600 k elements): NPT = 2
         // (<= 1024 nodes), one or two slot rows; the plain slot loop only
@@ -355,7 +366,6 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     switch (ept) {                                                                               \
         case 1: case 2: case 3: launch_pair_inst<256, NPT, 3, CO, HB, PH, V, AD>(A, lag, af); return 1; \
         case 4: launch_pair_inst<256, NPT, 4, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
-        case 5: launch_pair_inst<256, NPT, 5, CO, HB, PH, V, AD>(A, lag, af); return 1;           \
         default: launch_pair_inst<256, NPT, 6, CO, HB, PH, V, AD>(A, lag, af); return 1;          \
     }
     // nt (non-temporal) gradient stores -- the plan's store policy for meshes whose gradient arrays cannot stay in the
@@ -379,6 +389,7 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
     }
 #undef HFEM_PAIR_NT
     if (mode == 0) {
+#ifdef HFEM_LAB
         const int sp = plan->tune.store_policy;
         if (cc && npt == 3 && ept <= 3 && sp != 16 && !A.chain && !lag.pg_blocks) {   // "store_policy" A/B instances of the default tile shape
             const size_t lds = (size_t)(kPairCapN * 32 + kPairCapO * 32 + 128);
@@ -396,23 +407,23 @@ int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, b
             }
 #undef HFEM_PAIR_SP
         }
+#endif
         if (cc && npt == 3) HFEM_PAIR_EPT(3, 560, false, false, double2, false)
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, false)
         HFEM_PAIR_EPT(4, 0, false, false, double2, false)
-    } else if (mode == 1) {
-        if (phys) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, true, double2, false) HFEM_PAIR_EPT(4, 0, true, true, double2, false) }
-        (void)hasb;
-        if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, double2, false)
-        HFEM_PAIR_EPT(4, 0, true, false, double2, false)
+    } else if (mode == 1) {                      // body force and / or physical convention: the generic shape
+        if (phys) launch_pair_inst<256, 4, 6, 0, true, true, double2, false>(A, lag, af);
+        else launch_pair_inst<256, 4, 6, 0, true, false, double2, false>(A, lag, af);
+        return 1;
     } else if (mode == 2) {
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, false)
         HFEM_PAIR_EPT(4, 0, false, false, float2, false)
     } else if (mode == 3) {                      // fused Adam write-out: fp64 rows
-        if (hasb) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, double2, true) HFEM_PAIR_EPT(4, 0, true, false, double2, true) }
+        if (hasb) { launch_pair_inst<256, 4, 6, 0, true, false, double2, true>(A, lag, af); return 1; }
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, double2, true)
         HFEM_PAIR_EPT(4, 0, false, false, double2, true)
     } else if (mode == 4) {                      // fused Adam write-out: fp32 rows (parameters, moments, new rows all float)
-        if (hasb) { if (npt == 3) HFEM_PAIR_EPT(3, 0, true, false, float2, true) HFEM_PAIR_EPT(4, 0, true, false, float2, true) }
+        if (hasb) { launch_pair_inst<256, 4, 6, 0, true, false, float2, true>(A, lag, af); return 1; }
         if (npt == 3) HFEM_PAIR_EPT(3, 0, false, false, float2, true)
         HFEM_PAIR_EPT(4, 0, false, false, float2, true)
     }

@@ -177,6 +177,58 @@ def test_atomic_and_tiled_kernels_vs_oracle(nx, ny, kw):
         plan.close()
 
 
+@pytest.mark.parametrize("world,nx,ny,kw", [(8, 401, 301, {}), (3, 301, 151, dict(diagonal="random", permute=True)), (8, 161, 121, dict(flip_fraction=0.3))])
+def test_sharded_plan_ranges_vs_oracle(world, nx, ny, kw):
+    """A plan prepared for `world` ranks (shard-aware tile policy: 512-thread / one-row tiles at these sizes; every rank's
+    BOUNDARY tiles first in its range) evaluated range by range through the C ABI -- boundary part and interior part as two
+    launches, the way the overlapped step runs them -- against the plain-C closed forms: energies add up, every gradient row is
+    written by exactly one rank and equals the oracle's (no test held a shards=N plan against the oracle)."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.plan import TilePlan
+    from oracle import closed_form as CF
+    d = dev()
+    X, U, conn, edges = _random_problem(nx, ny, seed=nx + world, **kw)
+    mat, W = CF.plane_stress(), 0.25
+    Tc = np.array([2e5, 0.0, 0.0, 1e4])
+    e_ref, gX_ref, gU_ref = CF.tri3_energy(X, U, conn, mat, W, np.zeros(6))
+    e_ref -= CF.edge2_energy(X, U, edges, Tconst=Tc, gX=gX_ref, gU=gU_ref)
+    L = _lib.lib()
+    s = _lib.stream_ptr(d)
+    Xd, Ud = torch.from_numpy(X).to(d), torch.from_numpy(U).to(d)
+    dv = lambda a: (C.c_double * len(a))(*a)
+    plan = TilePlan(conn, X.shape[0], coords_hint=X, edges=edges, device=d, shards=world)
+    st = plan.stats
+    assert st["shards"] == world
+    if (nx, ny) == (401, 301):
+        assert st["threads_per_tile"] == 512 and st["paired"] == 1, st          # 240 k elements / 8 ranks: the 512-thread shape
+    acc_l, accX, accU = 0.0, torch.zeros_like(Xd), torch.zeros_like(Ud)
+    written = torch.zeros(X.shape[0], dtype=torch.int32, device=d)
+    n_bnd = 0
+    for r in range(world):
+        lo, mid, hi = plan.shard_parts(r, world)
+        assert lo <= mid <= hi
+        n_bnd += mid - lo
+        for a, b in ((mid, hi), (lo, mid)):                  # interior first, boundary second: the overlapped step's order
+            if b <= a:
+                continue
+            l3 = torch.zeros((), dtype=F64, device=d)
+            gX3, gU3 = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+            _lib.check(L.hfem_tri3_energy_plan(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv([0.0] * 6), None,
+                                               dv(Tc), a, b, l3.data_ptr(), gX3.data_ptr(), gU3.data_ptr(), 0, s))
+            rows = ~torch.isnan(gX3[:, 0])
+            assert bool((rows == ~torch.isnan(gU3[:, 0])).all())
+            written += rows.int()
+            acc_l += l3.item()
+            accX += torch.nan_to_num(gX3)
+            accU += torch.nan_to_num(gU3)
+    assert 0 < n_bnd < plan.n_tiles
+    assert int(written.min()) == 1 and int(written.max()) == 1, "every node row is written by exactly one tile range"
+    assert abs(acc_l - e_ref) <= LOSS_RTOL * abs(e_ref)
+    assert_grad_close(accX, gX_ref, f"shards={world} gX")
+    assert_grad_close(accU, gU_ref, f"shards={world} gU")
+    plan.close()
+
+
 def test_full_size_1m_elements_vs_oracle():
     """BASELINE config 'Example 4 / T1M': 1001x501 nodes -> 1,000,000 TRI3, through the model API."""
     from hidenn_fem_amd.mesh import structured_tri_mesh

@@ -83,6 +83,7 @@ def parse():
                     "past half of it")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic in the run (two rocprofv3 --pmc child "
                     "passes of the replayed leg, ~15 s each); the committed figure is reported instead, labelled so")
+    ap.add_argument("--no-lbfgs", action="store_true", help="skip the L-BFGS legs (config.lbfgs_step, lbfgs_step_1gpu, lbfgs_sharded_emulated)")
     ap.add_argument("--no-peer", action="store_true", help="skip the peer-window exchange legs (config.peer_exchange / sharded_step_1gpu)")
     ap.add_argument("--only-regime", default="", help="profiler helper: run ONLY this roofline leg (replayed | "
                     "rewritten_inputs | rotating_sets) and exit")
@@ -654,7 +655,50 @@ def main():
         return dict(mode=mode, value=n_elems / (el / a.steps), ms_per_step=el / a.steps * 1e3, launch=ln,
                     ms_per_step_replays=[round(r / a.steps * 1e3, 5) for r in regs])
 
-    alt = train = train_ov = strong = eval_ov = train_fused = train_fused_ov = None
+    def lbfgs_leg(sh_, what, emulate=False, outer=8):
+        """Example 4's optimiser (examples/example4.py:68-78: torch.optim.LBFGS defaults, 20 inner iterations per step, history
+        100) NODE-SHARDED over the ranks of sh_ (optim.ShardedLBFGS): ms per inner iteration with the history full (outer steps
+        6-8), max over ranks.  The parameters are restored afterwards."""
+        from hidenn_fem_amd.optim import ShardedLBFGS
+        m_ = sh_.model
+        keep = (m_.node_coords_free.detach().clone(), m_.u_free.detach().clone())
+        opt = ShardedLBFGS(sh_, emulate=emulate)
+        ts, its = [], []
+        for _ in range(outer):
+            if not emulate:
+                sync_all()
+            else:
+                torch.cuda.synchronize()
+            n0, t0 = opt.state["n_iter"], time.perf_counter()
+            opt.step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1 and not emulate:
+                t = torch.tensor([el], dtype=f64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            ts.append(el)
+            its.append(opt.state["n_iter"] - n0)
+        opt.finish()
+        full = [(t_, i_) for t_, i_ in list(zip(ts, its))[5:] if i_ > 0] or [(t_, i_) for t_, i_ in zip(ts, its) if i_ > 0]
+        per = sorted(t_ / i_ for t_, i_ in full)[len(full) // 2]
+        n_loc, n_par = opt._n, m_.node_coords_free.numel() + m_.u_free.numel()
+        byts = 4.0 * 100 * n_loc * m_.node_coords_free.element_size()
+        out_ = dict(workload=what, parameters=n_par, parameters_this_rank=n_loc, ms_per_inner_iteration=per * 1e3,
+                    inner_iterations_per_step=its, history_pairs=int(opt.status()[5]),
+                    local_history_bytes_per_iteration=byts, achieved_this_rank=byts / per / 1e9, unit="GB/s",
+                    frac_this_rank=byts / per / 1e9 / HBM_PEAK_GBS,
+                    exchanges_per_iteration="2 small ones: the interface parameter rows before the energy launch, one L-BFGS payload "
+                                            f"({opt._payload.numel() * 8} B per rank: per-slot dots, y.s, y.y, gradient statistics, max|d|, "
+                                            "partial energy) gathered to every rank and summed there in rank order")
+        with torch.no_grad():
+            m_.node_coords_free.copy_(keep[0])
+            m_.u_free.copy_(keep[1])
+        del opt
+        torch.cuda.empty_cache()
+        return out_
+
+    alt = train = train_ov = strong = eval_ov = train_fused = train_fused_ov = lbfgs_n = None
     exchange_mode = "serial: evaluation -> pack -> all_gather -> unpack on one stream"
     if world > 1:
         how = comm_state
@@ -737,6 +781,16 @@ def main():
             sh.close_peer_exchange(check=False)
         peer_on[0] = False
 
+    # ---- N > 1: Example 4's own optimiser, node-sharded (weak: N x 10^6 elements, every rank keeps 2 x 10^6 parameters' history)
+    if world > 1 and not a.no_lbfgs:
+        try:
+            was_peer = sh.peer is not None
+            if was_peer:
+                sh.close_peer_exchange(check=False)      # the L-BFGS legs exchange over the collective path
+            lbfgs_n = lbfgs_leg(sh, f"T1M x {world} (weak), ShardedLBFGS as examples/example4.py drives torch.optim.LBFGS, history full")
+        except Exception as e:  # noqa: BLE001
+            note(f"lbfgs_step leg failed: {type(e).__name__}: {str(e)[:160]}")
+
     # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
     def strong_leg(name, mesh6_s):
         m_s = staged(lambda: build_model(mesh6_s))
@@ -791,6 +845,11 @@ def main():
                 note(f"peer-window exchange on {name[:12]}: {type(e).__name__}: {str(e)[:160]}")
             sh_s.close_peer_exchange(check=False)
             peer_on[0] = False
+        if not a.no_lbfgs:
+            try:
+                res["lbfgs_step"] = lbfgs_leg(sh_s, name[:12] + ": ShardedLBFGS, history full -- the optimiser's passes shrink by the number of ranks")
+            except Exception as e:  # noqa: BLE001
+                note(f"lbfgs_step on {name[:12]}: {type(e).__name__}: {str(e)[:160]}")
         del sh_s, m_s, ko
         return res
 
@@ -1158,7 +1217,7 @@ def main():
     #      history 100, no line search) on T1M.  With the history full an inner iteration streams the 2 x 100 history vectors twice
     #      (multidot + direction passes, csrc/lbfgs.hip): 4 h n 8 B = 6.4 GB -- the optimiser, not the 9 us energy launch, is the iteration.
     lbfgs1 = None
-    if world == 1 and not a.no_extra and not only and not a.only_extra:
+    if world == 1 and not a.no_extra and not a.no_lbfgs and not only and not a.only_extra:
         try:
             from hidenn_fem_amd.optim import FusedLBFGS
 
@@ -1188,6 +1247,26 @@ def main():
             lbfgs1["torch_optim_LBFGS_ms_per_inner_iteration"] = sorted(tt[5:])[len(tt[5:]) // 2] / 20.0 * 1e3
         except Exception as e:  # noqa: BLE001
             note(f"lbfgs_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
+
+    # ---- N = 1: the node-sharded L-BFGS of BASELINE configs[3] as stated (10^6 elements FIXED over 8 ranks) rehearsed on this GPU:
+    #      rank r of 8 -- its tile range's energy launch, its 1/8 of the history (emulate=True: no peers; the payload gather is a
+    #      local copy) -- ms per inner iteration against lbfgs_step_1gpu (the whole optimiser on one GPU)
+    lbfgs_emu = None
+    if world == 1 and not a.no_extra and not a.no_lbfgs and not only and not a.only_extra:
+        try:
+            lbfgs_emu = []
+            for r_ in (0, 4, 7):
+                m_ = build_model(mesh6)
+                lf_ = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64, tile_elems=a.tile_elems)
+                sh_ = ShardedTri3Energy(m_, lf_, rank=r_, world=8)
+                leg_ = lbfgs_leg(sh_, f"T1M fixed, rank {r_} of 8 emulated on one GPU", emulate=True)
+                leg_["rank"] = r_
+                if lbfgs1 is not None:
+                    leg_["speedup_vs_lbfgs_step_1gpu"] = lbfgs1["ms_per_inner_iteration"] / leg_["ms_per_inner_iteration"]
+                lbfgs_emu.append(leg_)
+                del sh_, m_
+        except Exception as e:  # noqa: BLE001
+            note(f"lbfgs_sharded_emulated leg failed: {type(e).__name__}: {str(e)[:160]}")
 
     # ---- N = 1: what the owner-sharded step machinery costs on ONE rank (no peer to talk to: every microsecond above the
     #      plain iteration is overhead of the exchange path) -- all_gather stand-in on one stream, the side-stream overlap,
@@ -1286,12 +1365,16 @@ def main():
             out["config"]["train_step_fused_overlap"] = train_fused_ov
         if strong is not None:
             out["config"]["strong_scaling"] = strong
+        if lbfgs_n is not None:
+            out["config"]["lbfgs_step"] = lbfgs_n
         if peer_state is not None:
             out["config"]["peer_exchange"] = dict(state=peer_state, **(peer_legs or {}))
         if shard1 is not None:
             out["config"]["sharded_step_1gpu"] = shard1
         if lbfgs1 is not None:
             out["config"]["lbfgs_step_1gpu"] = lbfgs1
+        if lbfgs_emu is not None:
+            out["config"]["lbfgs_sharded_emulated"] = lbfgs_emu
         if notes:
             out["config"]["notes"] = notes
         if cpu is not None:

@@ -170,17 +170,24 @@ class FusedAdam(torch.optim.Optimizer):
     #      during the capture: their addresses are not known before) -- the copy node simply replays with the graph.
     _TAB_SLOTS = 4
 
+    def _new_slot(self, dev, nbytes):
+        return dict(host=torch.zeros(nbytes, dtype=torch.uint8).pin_memory(), dev=torch.zeros(nbytes, dtype=torch.uint8, device=dev),
+                    key=None, event=None, captured=False, entry=None)
+
     def _alloc_tables(self, dev, n_params):
         if getattr(self, "_tabs", None) is not None and self._tabs["n"] >= n_params and self._tabs["dev"] == dev:
             return
         import ctypes as C
         nbytes = max(1, n_params) * C.sizeof(_lib.AdamTensor)
-        self._tabs = dict(n=n_params, dev=dev, used={},
-                          free=[(torch.zeros(nbytes, dtype=torch.uint8).pin_memory(), torch.zeros(nbytes, dtype=torch.uint8, device=dev))
-                                for _ in range(self._TAB_SLOTS)])
+        self._tabs = dict(n=n_params, dev=dev, nbytes=nbytes, next=0, slots=[self._new_slot(dev, nbytes) for _ in range(self._TAB_SLOTS)])
         self._ticket = torch.zeros(1056, dtype=torch.int32, device=dev)      # HFEM_ADAM_TICKET_INTS
 
     def _table(self, todo):
+        """Device table of this step's tensors.  A slot (pinned host buffer + device buffer) is reused only when nothing can
+        still read it: a slot whose upload was CAPTURED into a hipGraph is never written again (the graph's copy node reads the
+        pinned buffer at every replay -- ADVICE r3), an eager slot is rewritten only after the event recorded behind its last
+        upload has completed.  A changing hyper-parameter (an LR scheduler: a new key every step) therefore walks round the
+        ring without ever synchronising the stream."""
         import ctypes as C
         key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                      float(group["lr"]), tuple(group["betas"]), float(group["eps"]), p.dtype) for group, p, g, st in todo)
@@ -193,16 +200,22 @@ class FusedAdam(torch.optim.Optimizer):
                                    "allocated inside a hipGraph capture)")
             self._alloc_tables(dev, sum(len(g["params"]) for g in self.param_groups))
             tabs = self._tabs
-        if key in tabs["used"]:
-            return tabs["used"][key]
-        if not tabs["free"]:
+        for sl in tabs["slots"]:
+            if sl["key"] == key:
+                if capturing:
+                    sl["captured"] = True
+                return sl["entry"]
+        free = [sl for sl in tabs["slots"] if not sl["captured"]]
+        if not free:
             if capturing:
-                raise RuntimeError("FusedAdam: more than %d distinct (parameter, gradient) address sets inside one hipGraph "
-                                   "capture" % self._TAB_SLOTS)
-            torch.cuda.current_stream(dev).synchronize()       # no table upload is in flight: recycle every slot
-            tabs["free"] = [v[4] for v in tabs["used"].values()]
-            tabs["used"] = {}
-        host, tab_dev = tabs["free"].pop()
+                raise RuntimeError("FusedAdam: every pointer-table slot is held by a captured hipGraph and a new one cannot be "
+                                   "allocated inside a capture; run one eager step with these tensors first")
+            tabs["slots"].append(self._new_slot(dev, tabs["nbytes"]))
+            free = [tabs["slots"][-1]]
+        sl = free[tabs["next"] % len(free)]
+        tabs["next"] += 1
+        if sl["event"] is not None:
+            sl["event"].synchronize()                          # its previous upload has been consumed (normally long ago)
         total_vecs = sum((p.numel() + (1 if p.dtype == torch.float64 else 3)) // (2 if p.dtype == torch.float64 else 4)
                          for _, p, _, _ in todo)
         chunk = max(256, -(-total_vecs // 2048))                   # <= ~2048 blocks (8 per CU: 512 ... 8192 measured flat), contiguous runs of 16-byte vectors
@@ -216,10 +229,16 @@ class FusedAdam(torch.optim.Optimizer):
             e.dtype, e.block_begin = (0 if p.dtype == torch.float64 else 1), blk
             blk += max(1, -(-nvec // chunk))
         raw = bytes(tab)
-        host[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-        tab_dev.copy_(host, non_blocking=True)                     # stream-ordered before the launch that reads it
-        tabs["used"][key] = (tab_dev, len(todo), blk, chunk, (host, tab_dev))
-        return tabs["used"][key]
+        sl["host"][:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        sl["dev"].copy_(sl["host"], non_blocking=True)             # stream-ordered before the launch that reads it
+        sl["key"], sl["captured"] = key, capturing
+        sl["entry"] = (sl["dev"], len(todo), blk, chunk, sl)
+        if capturing:
+            sl["event"] = None
+        else:
+            sl["event"] = torch.cuda.Event()
+            sl["event"].record(torch.cuda.current_stream(dev))     # behind the COPY: once it has run the pinned buffer is free; the
+        return sl["entry"]                                         # device buffer is protected by stream order (the next copy follows the launch that reads it)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -420,9 +439,14 @@ class ShardedLBFGS:
     Same algorithm and break tests as ``torch/optim/lbfgs.py`` / ``FusedLBFGS``; the closure is the sharded energy itself.
     HIP evaluator only; fp64 and fp32 models; one ``step()`` = one ``optimizer.step(closure)`` of the reference's loop."""
 
-    def __init__(self, sharded, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
+    def __init__(self, sharded, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100,
+                 emulate: bool = False):
+        """``emulate=True`` (bench.py's one-GPU rehearsal of rank r of N; timing only): ``sharded`` plays one rank of a world
+        that does not exist -- no interface exchange, and the payload "gather" is this rank's payload copied into every rank's
+        slot, so the local passes, launches and the status read cost what they would on that rank."""
         import ctypes as C
         sh = self.sh = sharded
+        self._emulate = bool(emulate)
         if not sh._hip:
             raise RuntimeError("ShardedLBFGS needs the HIP evaluator")
         if not hasattr(sh, "iface_rows"):
@@ -462,7 +486,7 @@ class ShardedLBFGS:
         sh, L = self.sh, _lib.lib()
         m = sh.model
         dev = m.node_coords_free.device
-        if sh.world > 1:
+        if sh.world > 1 and not self._emulate:
             sh.exchange_halo()                      # foreign interface rows (its energy slot is not used here)
         sh._eval_range(sh.lo, sh.hi, 0, False)      # HFEM_FLAG_NO_LOSS_SUM: the tile energies stay in the plan
         check(L.hfem_plan_loss_sum(sh.plan.handle, int(sh.lo), int(sh.hi), ptr(self._loss_local), stream_ptr(dev)), "hfem_plan_loss_sum")
@@ -476,7 +500,9 @@ class ShardedLBFGS:
         dev = self._g.device
         check(L.hfem_lbfgs_shard_local(self._h, ptr(self._g), ptr(self._loss_local), ptr(self._payload), stream_ptr(dev)),
               "hfem_lbfgs_shard_local")
-        if sh.world > 1:
+        if sh.world > 1 and self._emulate:
+            self._gathered.view(sh.world, -1).copy_(self._payload.unsqueeze(0).expand(sh.world, -1))
+        elif sh.world > 1:
             if sh.comm is not None:
                 sh.comm.all_gather(self._payload, self._gathered)
             else:
@@ -523,7 +549,7 @@ class ShardedLBFGS:
     def finish(self):
         """Make every rank's copy of the parameters complete (the rows other ranks own that this rank's tiles read): call before
         reading ``model.coords`` / ``u_full`` on a rank, or before switching to another optimiser."""
-        if self.sh.world > 1:
+        if self.sh.world > 1 and not self._emulate:
             self.sh.exchange_halo()
 
     def status(self):

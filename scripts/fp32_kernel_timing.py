@@ -19,6 +19,8 @@ K = 200
 dev = torch.device("cuda:0")
 f64 = torch.float64
 nx, ny = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1001, 501)
+if len(sys.argv) > 3:                  # home nodes per tile (plan_node_cap) for this run
+    _lib.check(_lib.lib().hfem_set_option(b"plan_node_cap", int(sys.argv[3])), "hfem_set_option")
 coords, conn, geom, bc, mn, edges = structured_tri_mesh(nx, ny, length=2.0, height=1.0, jitter=0.2, seed=0, dtype=f64)
 ne, nn = conn.shape[0], coords.shape[0]
 L = _lib.lib()
@@ -69,7 +71,8 @@ with torch.no_grad():
 lf64 = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=4, device=dev, dtype=f64)
 lf64._mat, lf64._W, lf64._ci, lf64._cj = lf32._mat, lf32._W, lf32._ci, lf32._cj
 l64 = lf64.value_and_grad_(m64).item()
-res = dict(elements=ne, nodes=nn, tiles=pl.stats["n_tiles"], alg_bytes=12 * ne + 32 * nn + 8)
+res = dict(elements=ne, nodes=nn, tiles=pl.stats["n_tiles"], slot_rows=pl.stats["slot_rows"], max_owned=pl.stats["max_tile_owned"],
+           max_nodes=pl.stats["max_tile_nodes"], alg_bytes=12 * ne + 32 * nn + 8)
 for tag, fl in (("fp32_arithmetic", 1024), ("fp64_arithmetic", 0)):
     launch(fl, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

@@ -357,3 +357,72 @@ def test_fused_energy_adam_step_fp32_rows_and_body_force(mesh_kw):
             assert (pa - pb).abs().max().item() <= 4 * torch.finfo(torch.float32).eps * pa.abs().max().item()
             assert (pa == pb).float().mean().item() > 0.98
         assert (b32.u_free - base32.u_free).abs().max().item() > 0
+
+
+@pytest.mark.gpu
+def test_fused_adam_pointer_tables_with_an_lr_scheduler_and_a_captured_graph():
+    """(i) a captured hipGraph replays the host-to-device copy of ITS pointer-table slot, so that slot must never be
+    rewritten -- after more than four other (parameter, gradient, lr) sets have been seen the graph still steps the right
+    tensors; (ii) an LR scheduler changes the key every step: the steps stay equal to torch.optim.Adam's with the same
+    schedule (and no longer synchronise the stream every four steps)."""
+    from hidenn_fem_amd.optim import FusedAdam
+    d = torch.device("cuda:0")
+    torch.manual_seed(0)
+    w0 = [torch.randn(1000, 2, dtype=torch.float64, device=d), torch.randn(777, dtype=torch.float64, device=d)]
+    tgt = [torch.randn_like(w) for w in w0]
+
+    def make(cls, **kw):
+        ps = [torch.nn.Parameter(w.clone()) for w in w0]
+        return ps, cls(ps, lr=1e-2, **kw)
+
+    def grads(ps):
+        for p, t in zip(ps, tgt):
+            p.grad = (p.detach() - t) * 2.0 if p.grad is None else p.grad.copy_((p.detach() - t) * 2.0)
+
+    # (ii) scheduler
+    pa, oa = make(torch.optim.Adam)
+    pb, ob = make(FusedAdam)
+    sa = torch.optim.lr_scheduler.ExponentialLR(oa, gamma=0.9)
+    sb = torch.optim.lr_scheduler.ExponentialLR(ob, gamma=0.9)
+    for _ in range(12):
+        grads(pa); grads(pb)
+        oa.step(); ob.step()
+        sa.step(); sb.step()
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() <= 1e-13 * a.abs().max().item()
+    assert len(ob._tabs["slots"]) == FusedAdam._TAB_SLOTS          # the ring was walked, not grown
+    # (i) a graph captured on one set of tensors, then many other keys through the same optimiser, then the graph again
+    pc, oc = make(FusedAdam, capturable=True)
+    oc.init_state()
+    grads(pc)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        oc.step()
+    pr, orf = make(torch.optim.Adam)
+    for k in range(3):
+        grads(pr); orf.step()
+        grads(pc); g.replay()
+    held = [sl for sl in oc._tabs["slots"] if sl["captured"]]
+    assert len(held) == 1
+    for lr in (3e-3, 4e-3, 5e-3, 6e-3, 7e-3, 8e-3):              # six more keys: eager steps with changing lr (and undone below)
+        for grp in oc.param_groups:
+            grp["lr"] = lr
+        keep = [p.detach().clone() for p in pc]
+        st = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in oc.state[p].items() if k != "step"} for p in pc}
+        step_before = oc._step_dev.clone()
+        grads(pc); oc.step()
+        with torch.no_grad():                                     # undo: parameters, moments, the device step counter
+            for p, kp in zip(pc, keep):
+                p.copy_(kp)
+                for k, v in st[id(p)].items():
+                    oc.state[p][k].copy_(v)
+            oc._step_dev.copy_(step_before)
+    assert [sl for sl in oc._tabs["slots"] if sl["captured"]] == held and held[0]["key"] is not None
+    for grp in oc.param_groups:
+        grp["lr"] = 1e-2
+    for k in range(3):
+        grads(pr); orf.step()
+        grads(pc); g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(pr, pc):
+        assert (a - b).abs().max().item() <= 1e-13 * a.abs().max().item(), "the captured graph stepped with a recycled pointer table"

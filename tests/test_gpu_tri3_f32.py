@@ -40,11 +40,12 @@ def _err(got, want):
     return float(np.abs(got.detach().double().cpu().numpy() - want).max() / np.abs(want).max())
 
 
-@pytest.mark.parametrize("arithmetic", ["fp64", "fp32"])
+@pytest.mark.parametrize("arithmetic", ["fp64", "auto"])
 def test_fp32_models_against_the_reference_run_in_fp32(g_tri_f32, arithmetic):
     from hidenn_fem_amd.loss import EnergyLoss2D
     d = torch.device("cuda:0")
     worst = dict(loss=0.0, g=0.0, loss64=0.0, g64=0.0)
+    ran_fp32 = []
     for case in g_tri_f32.cases():
         m = _model(g_tri_f32, case, d)
         go, go1 = (int(v) for v in g_tri_f32[case + "/gauss_order"])
@@ -52,6 +53,8 @@ def test_fp32_models_against_the_reference_run_in_fp32(g_tri_f32, arithmetic):
         lf = EnergyLoss2D(E=10e9, nu=0.3, gauss_order=go, gauss_order_1d=go1, device=d, dtype=F32, arithmetic=arithmetic)
         loss = lf(m, b_force=b, t_force=t)
         loss.backward()
+        if arithmetic == "auto" and m.tile_plan(0).stats["paired"]:      # "auto": fp32 arithmetic wherever the plan has paired slots
+            ran_fp32.append(case)
         assert loss.dtype == F32 and m.u_free.grad.dtype == F32
         gx = m.to_caller_order(m.node_coords_free.grad, "x")
         gu = m.to_caller_order(m.u_free.grad, "u")
@@ -72,7 +75,14 @@ def test_fp32_models_against_the_reference_run_in_fp32(g_tri_f32, arithmetic):
             l2 = lf.value_and_grad_(m)
             assert abs(l2.item() - loss.item()) <= 4 * EPS32 * abs(loss.item())
             assert _err(m.to_caller_order(m.u_free.grad, "u"), gu.double().cpu().numpy()) <= (4 * EPS32 if arithmetic == "fp64" else 4e-6)
-    print(f"[fp32 goldens, arithmetic={arithmetic}] worst vs reference-fp32: loss {worst['loss']:.2e} grad {worst['g']:.2e}; "
+    if arithmetic == "auto":
+        assert len(ran_fp32) >= 6, ran_fp32                      # most golden meshes pair up: the fp32 kernel really ran
+        with pytest.raises(RuntimeError):                        # ... and where it cannot, asking for it by name fails loudly
+            m_flip = _model(g_tri_f32, "flipped", d)
+            if m_flip.tile_plan(0).stats["paired"]:
+                raise RuntimeError("paired after all")
+            EnergyLoss2D(device=d, dtype=F32, arithmetic="fp32")(m_flip)
+    print(f"[fp32 goldens, arithmetic={arithmetic}, fp32 kernel on {len(ran_fp32)} cases] worst vs reference-fp32: loss {worst['loss']:.2e} grad {worst['g']:.2e}; "
           f"vs reference-fp64-on-the-same-floats: loss {worst['loss64']:.2e} grad {worst['g64']:.2e}")
 
 

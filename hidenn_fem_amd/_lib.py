@@ -105,6 +105,8 @@ PROTOTYPES = {
     "hfem_peer_destroy": (C.c_int, [_vp]),
     "hfem_peer_attach_get": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64]),
     "hfem_plan_set_peer_get": (C.c_int, [_vp, _vp, _i32, _i32]),
+    "hfem_peer_attach_put": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _f64, _f64]),
+    "hfem_plan_set_peer_put": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hfem_peer_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "hfem_plan_iface_pack_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _f64, _f64, _vp, _vp]),
     "hfem_iface_unpack_f32": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _vp, _vp]),

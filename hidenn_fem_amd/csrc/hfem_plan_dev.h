@@ -39,6 +39,14 @@ struct PeerGetDev {                  // device-resident arguments of the in-laun
     double *loss_out;
 };
 
+struct PeerPutDev {                  // device-resident arguments of the in-launch put (hfem_peer_attach_put)
+    PeerView pv;
+    const int32_t *pos_x, *pos_u;    // per parameter ROW: its place in this rank's payload lane (double2 units), or -1
+    int64_t stride, loss_slot;
+    int64_t *counter;                // the optimiser's device step counter (bumped by the last boundary tile), or NULL
+    double beta1, beta2;
+};
+
 // parameter rows of either storage type in the exchange payload (always double2: float -> double -> float is lossless)
 template <typename V> __device__ __forceinline__ double2 row_widen(V v) { return make_double2((double)v.x, (double)v.y); }
 template <typename V> __device__ __forceinline__ V row_narrow(double2 v) {
@@ -56,6 +64,14 @@ struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgr
     // rank's boundary tiles, the only ones that read rows another rank owns -- wait for it before they gather
     const PeerGetDev *pg = nullptr;
     int pg_blocks = 0, wait_begin = 0, wait_end = 0;
+    // HFEM_FLAG_PEER_PUT (fused-Adam instances with the in-launch get): the boundary tiles [wait_begin, wait_end) ALSO publish --
+    // each stores the NEW rows of its interface nodes into every rank's window at write-out, and the last of them to finish
+    // writes the rank's energy of the PREVIOUS evaluation (put_prev: its tile energies, complete since the last kernel
+    // boundary), bumps the step counter, writes the next step's bias corrections (put_bc_next) and raises the flags
+    const PeerPutDev *put = nullptr;
+    const double *put_prev = nullptr;
+    int put_prev_n = 0;
+    double *put_bc_next = nullptr;
 };
 
 // One service workgroup of the in-launch get (256 threads of a tile kernel's block): iface_get_kernel's wait + unpack with
@@ -146,8 +162,8 @@ struct AdamFuse {                    // arguments of the fused optimiser write-o
 // dtype: the gradient is rounded to float once, as the float-row kernel would store it, then torch's fp32 arithmetic).
 // m, v are read and written in place, the NEW row goes to the other parameter buffer (ping-pong).
 template <typename V2>
-__device__ __forceinline__ void adam_fused_row(const AdamFuse &af, int c, int row, double gx, double gy, double2 p64,
-                                               double bc1, double sqrt_bc2) {
+__device__ __forceinline__ V2 adam_fused_row(const AdamFuse &af, int c, int row, double gx, double gy, double2 p64,
+                                             double bc1, double sqrt_bc2) {
     typedef decltype(V2().x) T;
     V2 *mp = reinterpret_cast<V2 *>(c ? af.mu : af.mx) + row, *vp = reinterpret_cast<V2 *>(c ? af.vu : af.vx) + row;
     const V2 m = *mp, v = *vp;
@@ -161,6 +177,53 @@ __device__ __forceinline__ void adam_fused_row(const AdamFuse &af, int c, int ro
     pn.y = p1 - ss * (mn.y / ((T)sqrt((double)vn.y) / sb + eps));
     *mp = mn; *vp = vn;
     reinterpret_cast<V2 *>(c ? af.u_out : af.x_out)[row] = pn;
+    return pn;
+}
+
+// The in-launch put, part 1 (a boundary tile at write-out): the NEW row of an interface node into every rank's window.
+template <typename V2>
+__device__ __forceinline__ void peer_put_row(const PeerPutDev &P, size_t slot_off, int pos, V2 pn) {
+    const double2 v = row_widen(pn);
+    for (int p = 0; p < P.pv.world; ++p) reinterpret_cast<double2 *>(P.pv.win[p] + slot_off)[pos] = v;
+}
+
+// The in-launch put, part 2 (every boundary tile after its write-out): its rows have reached the windows -> ticket; the LAST
+// of the n_boundary tiles publishes the rank's previous energy, bumps the step counter, writes the next bias corrections,
+// raises the flags in every window and completes the put (seq + 1).  `red`: >= 4 doubles of LDS.  All threads of the block.
+__device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSum &lag, uint64_t seq, size_t slot_off,
+                                                int n_boundary, double *red) {
+    __shared__ int put_last;
+    char *ctl = P.pv.ctl;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) put_last = atomicAdd((unsigned *)(ctl + 8), 1u) == (unsigned)(n_boundary - 1);
+    __syncthreads();
+    if (!put_last) return;
+    double v = 0.0;
+    if (lag.put_prev && threadIdx.x < 256)
+        for (int k = threadIdx.x; k < lag.put_prev_n; k += 256) v += lag.put_prev[k];
+    const double tot = block_sum(v, red);          // same order and bits as sum_partials_kernel for <= 256-thread strides
+    if (threadIdx.x == 0) {
+        for (int p = 0; p < P.pv.world; ++p) reinterpret_cast<double2 *>(P.pv.win[p] + slot_off)[P.loss_slot] = make_double2(tot, 0.0);
+        if (P.counter) {
+            const int64_t c = P.counter[0] + 1;
+            P.counter[0] = c;
+            if (lag.put_bc_next) {
+                lag.put_bc_next[0] = 1.0 - pow(P.beta1, (double)(c + 1));
+                lag.put_bc_next[1] = sqrt(1.0 - pow(P.beta2, (double)(c + 1)));
+            }
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    const int par = (int)(seq & 1);
+    if ((int)threadIdx.x < P.pv.world)
+        __hip_atomic_store((uint64_t *)(P.pv.win[threadIdx.x] + kPeerFlags) + par * kMaxPeers + P.pv.rank, seq + 1,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        *(unsigned *)(ctl + 8) = 0u;
+        __hip_atomic_store((uint64_t *)ctl, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
@@ -214,6 +277,8 @@ struct hfem_plan {
     int64_t device_bytes = 0;
     double row_line_factor = 1.0; // distinct 128-byte lines per tile's coordinate rows / the minimum (hfem_plan_create)
     const hfem::PeerGetDev *peer_get = nullptr;   // hfem_plan_set_peer_get: in-launch get of HFEM_FLAG_PEER_GET launches
+    const hfem::PeerPutDev *peer_put = nullptr;   // hfem_plan_set_peer_put: in-launch put of HFEM_FLAG_PEER_PUT launches
+    double *put_bc[2] = {nullptr, nullptr};       // ... and the two bias-correction buffers its steps alternate between
     int peer_wait_begin = 0, peer_wait_end = 0;   // the tiles that wait for it (the rank's boundary tiles)
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
@@ -285,6 +350,7 @@ struct hfem_peer {
     char *local = nullptr;           // this rank's window (hipExtMallocWithFlags, uncached)
     char *ctl = nullptr;             // puts / tickets / status / unpacked (hipMalloc)
     hfem::PeerGetDev *get_dev = nullptr;   // arguments of the in-launch get (hfem_peer_attach_get), or NULL
+    hfem::PeerPutDev *put_dev = nullptr;   // arguments of the in-launch put (hfem_peer_attach_put), or NULL
     std::vector<void *> opened;      // hipIpcOpenMemHandle results (the peers' windows)
     bool connected = false;
     hfem::PeerView view{};

@@ -232,6 +232,26 @@ extern "C" int hfem_peer_attach_get(hfem_peer *peer, const int32_t *src, const i
     return 0;
 }
 
+// Arguments of the in-launch put (HFEM_FLAG_PEER_PUT launches of a plan, hfem_plan_set_peer_put): where every parameter row
+// sits in this rank's payload lane (pos_x [rows of x_free], pos_u [rows of u_free]: double2 index, or -1 = not an interface
+// row), the loss slot, and the optimiser's step counter + betas (the last boundary tile does what hfem_plan_iface_put's
+// block 0 does).  Device arrays stay owned by the caller.
+extern "C" int hfem_peer_attach_put(hfem_peer *peer, const int32_t *pos_x, const int32_t *pos_u, int64_t loss_slot,
+                                    int64_t *counter, double beta1, double beta2) {
+    HFEM_ARG_CHECK(peer && pos_x && pos_u, "null pointer");
+    HFEM_ARG_CHECK(peer->connected, "hfem_peer_connect has not been called");
+    HFEM_ARG_CHECK(loss_slot >= 0 && loss_slot < peer->stride, "bad loss slot");
+    if (int rc = use_device(peer->device)) return rc;
+    PeerPutDev g;
+    g.pv = peer->view; g.pos_x = pos_x; g.pos_u = pos_u; g.stride = peer->stride; g.loss_slot = loss_slot;
+    g.counter = counter; g.beta1 = beta1; g.beta2 = beta2;
+    hipError_t e = hipSuccess;
+    if (!peer->put_dev) e = hipMalloc((void **)&peer->put_dev, sizeof(PeerPutDev));
+    if (e == hipSuccess) e = hipMemcpy(peer->put_dev, &g, sizeof(PeerPutDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "hfem_peer_attach_put");
+    return 0;
+}
+
 extern "C" int hfem_peer_destroy(hfem_peer *peer) {
     if (!peer) return 0;
     (void)use_device(peer->device);
@@ -240,6 +260,7 @@ extern "C" int hfem_peer_destroy(hfem_peer *peer) {
     if (peer->local) (void)hipFree(peer->local);
     if (peer->ctl) (void)hipFree(peer->ctl);
     if (peer->get_dev) (void)hipFree(peer->get_dev);
+    if (peer->put_dev) (void)hipFree(peer->put_dev);
     delete peer;
     return 0;
 }

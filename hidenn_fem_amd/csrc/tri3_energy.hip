@@ -1197,6 +1197,20 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
         lag.pg = plan->peer_get; lag.pg_blocks = kPeerGetBlocks;
         lag.wait_begin = plan->peer_wait_begin; lag.wait_end = plan->peer_wait_end;
     }
+    if (flags & HFEM_FLAG_PEER_PUT) {
+        HFEM_ARG_CHECK((flags & HFEM_FLAG_PEER_GET) && plan->peer_put, "HFEM_FLAG_PEER_PUT: with HFEM_FLAG_PEER_GET, after hfem_plan_set_peer_put");
+        HFEM_ARG_CHECK(h.paired && (flags & HFEM_FLAG_NO_LOSS_SUM) && !lag_consume && !same_bank,
+                       "HFEM_FLAG_PEER_PUT: paired-slot plans, with HFEM_FLAG_NO_LOSS_SUM, one launch per evaluation");
+        HFEM_ARG_CHECK(lag.wait_begin < lag.wait_end && tile_begin <= lag.wait_begin && lag.wait_end <= tile_end,
+                       "HFEM_FLAG_PEER_PUT: the launch must cover the rank's (non-empty) boundary range");
+        HFEM_ARG_CHECK(bc_dev == plan->put_bc[0] || bc_dev == plan->put_bc[1], "HFEM_FLAG_PEER_PUT: bc_dev must be one of the two buffers given to hfem_plan_set_peer_put");
+        lag.put = plan->peer_put;
+        lag.put_bc_next = bc_dev == plan->put_bc[0] ? plan->put_bc[1] : plan->put_bc[0];
+        if (plan->prev_n > 0 && plan->prev_stream == stream) {      // the previous evaluation's tile energies (the other bank)
+            lag.put_prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
+            lag.put_prev_n = plan->prev_n;
+        }
+    }
     if (n > 0) {
         AdamFuse af;
         af.x_out = x_out; af.u_out = u_out;
@@ -1341,6 +1355,23 @@ extern "C" int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t 
                    "the in-launch get needs the paired-slot kernel's plain slot loop (no chained records) or the 512-thread "
                    "one-element-per-slot kernel with write-through / nt stores");
     plan->peer_get = peer->get_dev; plan->peer_wait_begin = wait_begin; plan->peer_wait_end = wait_end;
+    return 0;
+}
+
+// The in-launch put: fused energy + Adam launches of this plan with HFEM_FLAG_PEER_PUT | HFEM_FLAG_PEER_GET also PUBLISH -- the
+// boundary tiles store the new rows of their interface nodes into every rank's window at write-out and the last of them
+// completes the put (csrc/peer.hip, hfem_peer_attach_put): an owner-sharded training step is ONE launch.  bc_a / bc_b: the
+// two bias-correction buffers the steps alternate between (a launch reads one as bc_dev, its put writes the next step's
+// into the other).  peer == NULL detaches.
+extern "C" int hfem_plan_set_peer_put(hfem_plan *plan, hfem_peer *peer, double *bc_a, double *bc_b) {
+    HFEM_ARG_CHECK(plan, "null pointer");
+    PlanLock lock(plan);
+    if (!peer) { plan->peer_put = nullptr; plan->put_bc[0] = plan->put_bc[1] = nullptr; return 0; }
+    HFEM_ARG_CHECK(peer->connected && peer->put_dev, "hfem_peer_connect / hfem_peer_attach_put first");
+    HFEM_ARG_CHECK(peer->device == plan->device, "plan and peer windows live on different devices");
+    HFEM_ARG_CHECK(plan->host.paired && plan->host.n_chained == 0, "the in-launch put needs a paired-slot plan (plain slot loop)");
+    HFEM_ARG_CHECK(bc_a && bc_b && bc_a != bc_b, "need two distinct bias-correction buffers");
+    plan->peer_put = peer->put_dev; plan->put_bc[0] = bc_a; plan->put_bc[1] = bc_b;
     return 0;
 }
 

@@ -236,12 +236,53 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         // the NEW row to the OTHER parameter buffer (tiles still gathering must see the old one: ping-pong); the gradient
         // never goes to memory.  Arithmetic = optim.hip's adam_step_dev_kernel, operation for operation.
         const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];
+        // HFEM_FLAG_PEER_PUT (PG instances): a boundary tile also PUBLISHES -- the new rows of its interface nodes go straight
+        // into every rank's receive window (the separate put launch of a sharded step disappears)
+        bool putting = false;
+        uint64_t put_seq = 0;
+        size_t put_off = 0;
+        if constexpr (PG) {
+            putting = lag.put && tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end;
+            if (putting) {
+                put_seq = __hip_atomic_load((uint64_t *)lag.put->pv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                put_off = kPeerData + ((size_t)(put_seq & 1) * lag.put->pv.world + lag.put->pv.rank) * (size_t)lag.put->stride * sizeof(double2);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NPT; ++j) {
             const int l = tid + j * BLOCK;
             if (l < n_owned) {
-                if (s[j].x >= 0) adam_fused_row<V2>(af, 0, s[j].x, acc0[l], acc1[l], nd_xy[l], bc1, sqrt_bc2);
-                if (s[j].y >= 0) adam_fused_row<V2>(af, 1, s[j].y, acc2[l], acc3[l], nd_uv[l], bc1, sqrt_bc2);
+                if (s[j].x >= 0) {
+                    const V2 pn = adam_fused_row<V2>(af, 0, s[j].x, acc0[l], acc1[l], nd_xy[l], bc1, sqrt_bc2);
+                    if constexpr (PG) {
+                        if (putting) {
+                            const int pos = lag.put->pos_x[s[j].x];
+                            if (pos >= 0) peer_put_row<V2>(*lag.put, put_off, pos, pn);
+                        }
+                    }
+                }
+                if (s[j].y >= 0) {
+                    const V2 pn = adam_fused_row<V2>(af, 1, s[j].y, acc2[l], acc3[l], nd_uv[l], bc1, sqrt_bc2);
+                    if constexpr (PG) {
+                        if (putting) {
+                            const int pos = lag.put->pos_u[s[j].y];
+                            if (pos >= 0) peer_put_row<V2>(*lag.put, put_off, pos, pn);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (PG) {
+            if (putting) {
+                if (tid == 0) {                                 // the tile energy first: this block may return inside the put
+                    double tile_e = 0.0;
+#pragma unroll
+                    for (int w = 0; w < BLOCK / 64; ++w) tile_e += red[w];
+                    partials[slot] = tile_e;
+                }
+                __syncthreads();                                // red[] is reused by the put's block sum
+                peer_put_finish(*lag.put, lag, put_seq, put_off, lag.wait_end - lag.wait_begin, red);
+                return;
             }
         }
     } else {

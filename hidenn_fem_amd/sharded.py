@@ -177,6 +177,7 @@ class ShardedTri3Energy:
         self.model, self.loss_fn, self.group, self.comm = model, loss_fn, group, comm
         self.peer: Optional[PeerWindows] = None          # enable_peer_exchange(): interface rows by stores into peer windows
         self.inkernel_get = False
+        self.inkernel_put = False                        # ... and the put inside the fused energy + Adam launch (one launch per step)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is not None and world is not None:      # planning / single-process tests: act as rank of world
@@ -368,7 +369,33 @@ class ShardedTri3Energy:
                 if inkernel_get:
                     raise
                 self.inkernel_get = False              # default: fall back to the get as a launch of its own
+        self.inkernel_put = False
+        if self.inkernel_get and getattr(self, "_fused", None) is not None and bool(self.plan.stats["paired"]):
+            self._bind_peer_put()
         return self
+
+    def _bind_peer_put(self):
+        """The put INSIDE the fused energy + Adam launch (``owner_train_step_fused_overlapped`` becomes ONE launch per step):
+        per parameter row its place in this rank's payload lane, the step counter and betas, the two bias-correction buffers."""
+        dev = self.send.device
+        n_x, n_u = self._pub_n
+        rows = self._pub_rows.long()
+        pos_x = torch.full((self._nx // 2,), -1, dtype=torch.int32, device=dev)
+        pos_u = torch.full((self._nu // 2,), -1, dtype=torch.int32, device=dev)
+        pos_x[rows[:n_x]] = torch.arange(n_x, dtype=torch.int32, device=dev)
+        pos_u[rows[n_x:]] = torch.arange(n_x, n_x + n_u, dtype=torch.int32, device=dev)
+        self._put_pos = (pos_x, pos_u)
+        ad, fz = self._adam, self._fused
+        L = _lib.lib()
+        _lib.check(L.hfem_peer_attach_put(self.peer.handle, pos_x.data_ptr(), pos_u.data_ptr(), self.iface_rows, ad["step"].data_ptr(),
+                                          ad["betas"][0], ad["betas"][1]), "hfem_peer_attach_put")
+        try:
+            _lib.check(L.hfem_plan_set_peer_put(self.plan.handle, self.peer.handle, fz["bcs"][0].data_ptr(), fz["bcs"][1].data_ptr()),
+                       "hfem_plan_set_peer_put")
+        except RuntimeError:
+            return                                     # a plan whose kernel has no in-launch put: the put stays a launch of its own
+        self.inkernel_put = True
+        self._put_lag = False
 
     def close_peer_exchange(self, barrier: bool = True, check: bool = True):
         """Back to the collective path: join the exchange in flight, read the windows' status (a get that timed out raises HERE
@@ -390,10 +417,12 @@ class ShardedTri3Energy:
             err = e
         if barrier and self.world > 1 and dist.is_initialized():
             dist.barrier(group=self.group)              # every rank's puts have landed: nobody stores into a window any more
+        if self.inkernel_put:
+            _lib.check(_lib.lib().hfem_plan_set_peer_put(self.plan.handle, None, None, None), "hfem_plan_set_peer_put")
         if self.inkernel_get:
             _lib.check(_lib.lib().hfem_plan_set_peer_get(self.plan.handle, None, 0, 0), "hfem_plan_set_peer_get")
         self.peer.close()
-        self.peer, self.inkernel_get, self._wait_range, self._step_cache = None, False, None, None
+        self.peer, self.inkernel_get, self.inkernel_put, self._wait_range, self._step_cache = None, False, False, None, None
         if err is not None:
             raise err
 
@@ -531,9 +560,11 @@ class ShardedTri3Energy:
         if fused:
             import math
             b1, b2 = self._adam["betas"]
+            bc0 = torch.tensor([1.0 - b1, math.sqrt(1.0 - b2)], dtype=F64, device=dev)
+            # bias corrections of the NEXT fused step: two buffers, step k reads bcs[k & 1]; whoever completes step k (the pack / put
+            # launch after the swap, or the in-launch put's last boundary tile) writes the other one
             self._fused = dict(x=[m.node_coords_free.data, m.node_coords_free.data.clone()],
-                               u=[m.u_free.data, m.u_free.data.clone()], k=0,
-                               bc=torch.tensor([1.0 - b1, math.sqrt(1.0 - b2)], dtype=F64, device=dev))
+                               u=[m.u_free.data, m.u_free.data.clone()], k=0, bcs=[bc0, bc0.clone()])
         self._e_parts = torch.zeros(2, dtype=F64, device=dev)      # seam evaluators: energies of the two tile sub-ranges
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = None
@@ -578,14 +609,14 @@ class ShardedTri3Energy:
                     self.plan.handle, self.peer.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(),
                     m.u_free.data_ptr(), self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.iface_rows,
                     ad["step"].data_ptr() if count_step else None, ad["betas"][0] if ad else 0.0, ad["betas"][1] if ad else 0.0,
-                    fz["bc"].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_put")
+                    fz["bcs"][fz["k"] & 1].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_put")
                 return
             pack = _lib.lib().hfem_plan_iface_pack_f32 if self._f32 else _lib.lib().hfem_plan_iface_pack
             _lib.check(pack(
                 self.plan.handle, int(self.lo), int(self.hi), m.node_coords_free.data_ptr(), m.u_free.data_ptr(),
                 self._pub_rows.data_ptr(), self._pub_n[0], self._pub_n[1], self.payload.data_ptr(), self.iface_rows,
                 ad["step"].data_ptr() if count_step else None, ad["betas"][0] if ad else 0.0, ad["betas"][1] if ad else 0.0,
-                fz["bc"].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
+                fz["bcs"][fz["k"] & 1].data_ptr() if (fz is not None and count_step) else None, _lib.stream_ptr(dev)), "hfem_plan_iface_pack")
         else:
             self._pack()
             with torch.no_grad():
@@ -632,7 +663,7 @@ class ShardedTri3Energy:
         return self.loss_global
 
     # ---- fused steps: the energy launch applies Adam's update to the rows its tiles own (no gradient traffic, no Adam launch)
-    def _fused_range(self, lo, hi, cont, peer_get=False):
+    def _fused_range(self, lo, hi, cont, peer_get=False, peer_put=False):
         """Energy over tiles [lo, hi) with the fused Adam write-out: reads the current parameter buffers, writes the new rows of
         the nodes those tiles own into the other buffers.  HIP only; fp64 models; default forces."""
         if hi <= lo:
@@ -648,8 +679,9 @@ class ShardedTri3Energy:
             self.plan.handle, 1 if self._f32 else 0, fz["x"][i].data_ptr(), xfix.data_ptr() if xfix.numel() else None, fz["u"][i].data_ptr(),
             ufix.data_ptr() if ufix.numel() else None, mat, W, None, None, Tc, fz["x"][o].data_ptr(), fz["u"][o].data_ptr(),
             a["mx"].data_ptr(), a["vx"].data_ptr(), a["mu"].data_ptr(), a["vu"].data_ptr(), a["lr"][0], a["lr"][1],
-            a["betas"][0], a["betas"][1], a["eps"], fz["bc"].data_ptr(), int(lo), int(hi), self.loss_global.data_ptr(),
-            8 | (256 if cont else 0) | (0 if m.N_edges else 4) | (512 if peer_get else 0), _lib.stream_ptr(dev)),
+            a["betas"][0], a["betas"][1], a["eps"], fz["bcs"][i].data_ptr(), int(lo), int(hi), self.loss_global.data_ptr(),
+            8 | (256 if cont else 0) | (0 if m.N_edges else 4) | (512 if peer_get else 0) | (2048 if peer_put else 0),
+            _lib.stream_ptr(dev)),
             "hfem_tri3_energy_adam_step_ex")
 
     def _fused_swap(self):
@@ -680,6 +712,15 @@ class ShardedTri3Energy:
         the other, so the boundary tiles still see the step's input values of the rows interior tiles own)."""
         if self._fused is None or not self._hip:
             raise RuntimeError("owner_train_step_fused_overlapped needs init_owner_adam(..., fused=True) and the HIP evaluator")
+        if self.inkernel_put and self.mid > self.lo:
+            # ONE launch: service workgroups = the get of the previous step's rows, boundary tiles wait for them, evaluate, apply
+            # Adam and PUBLISH their new interface rows at write-out; the last boundary tile completes the put.  The energy a
+            # get delivers lags one step more than in the two-launch form (finish_overlapped() flushes the last one).
+            self._inkernel_begin()
+            self._fused_range(self.lo, self.hi, False, peer_get=True, peer_put=True)
+            self._fused_swap()
+            self._pending, self._put_lag = ("peer", self._loss_slots[0]), True
+            return self.loss_global
         if self.inkernel_get:
             self._inkernel_begin()
             self._fused_range(self.lo, self.hi, False, peer_get=True)
@@ -748,6 +789,10 @@ class ShardedTri3Energy:
         work, slot = self._pending
         if work == "peer":
             self._unpack_hip(slot)
+            if getattr(self, "_put_lag", False):           # the in-launch put published the energy of the step BEFORE its own:
+                self._pack_loss(count_step=False)          # one put launch with the last evaluation's energy (same rows again)
+                self._unpack_hip(slot)
+                self._put_lag = False
             self.loss_global = slot
         elif self._side is not None:
             if work != "inline":

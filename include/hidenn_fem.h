@@ -161,6 +161,9 @@ int hfem_plan_deserialize(int device, const void *blob, int64_t n_bytes, hfem_pl
 #define HFEM_FLAG_PEER_GET 512  /* paired-slot plans (no chained records) and 512-thread one-element-per-slot plans, after hfem_plan_set_peer_get: the launch starts with 8 service workgroups that
                                  * ARE the peer-window get (hfem_peer_iface_get's wait + unpack into this launch's x_free / u_free)
                                  * and the tiles named there (the rank's boundary tiles) wait for them inside the kernel        */
+#define HFEM_FLAG_PEER_PUT 2048  /* hfem_tri3_energy_adam_step_ex with HFEM_FLAG_PEER_GET, after hfem_plan_set_peer_put: the launch also PUBLISHES --
+                                 * its boundary tiles store the new rows of their interface nodes into every rank's window at
+                                 * write-out and the last of them completes the put: one launch per owner-sharded training step */
 #define HFEM_FLAG_FP32_MATH 1024 /* hfem_tri3_energy_plan_f32 only: fp32 ARITHMETIC as well as fp32 rows -- what the reference itself
                                  * computes in for its default dtype (src/loss.py:16): packed-fp32 element math (the two elements of
                                  * a slot side by side), float LDS accumulators; the tile energies and the loss stay fp64.  Paired-slot
@@ -483,6 +486,19 @@ int hfem_peer_status(hfem_peer *peer, int32_t *status_out, int64_t *puts_out);
 int hfem_peer_attach_get(hfem_peer *peer, const int32_t *src, const int32_t *dst, int32_t n_x, int32_t n_u,
                          int64_t loss_slot, double *loss_out, int64_t timeout_ticks);
 int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t wait_begin, int32_t wait_end);
+/* The put INSIDE the fused energy + Adam launch (round 4: ONE launch per owner-sharded training step).  hfem_peer_attach_put
+ * stores in device memory where every parameter row sits in this rank's payload lane (pos_x / pos_u: per row of x_free /
+ * u_free the double2 index, -1 = not an interface row), the loss slot and the optimiser's step counter + betas;
+ * hfem_plan_set_peer_put binds them to a paired-slot plan with the TWO bias-correction buffers the steps alternate between.
+ * hfem_tri3_energy_adam_step_ex(..., HFEM_FLAG_PEER_GET | HFEM_FLAG_PEER_PUT | HFEM_FLAG_NO_LOSS_SUM) then: the boundary tiles
+ * [wait_begin, wait_end) of hfem_plan_set_peer_get store the NEW rows of their interface nodes into every rank's window at
+ * write-out; the last of them to finish writes the rank's energy of the PREVIOUS evaluation into the loss slot (this one's is
+ * not complete yet: the global energy a get delivers therefore lags one step more; hfem_plan_iface_put flushes the last),
+ * bumps the step counter, writes the next step's bias corrections into the other buffer and raises the flags.  Protocol,
+ * slots and bounded waits as hfem_plan_iface_put / the in-launch get.                                                */
+int hfem_peer_attach_put(hfem_peer *peer, const int32_t *pos_x, const int32_t *pos_u, int64_t loss_slot, int64_t *counter,
+                         double beta1, double beta2);
+int hfem_plan_set_peer_put(hfem_plan *plan, hfem_peer *peer, double *bc_a, double *bc_b);
 int hfem_plan_iface_put(hfem_plan *plan, hfem_peer *peer, int32_t tile_begin, int32_t tile_end, const double *x_free,
                         const double *u_free, const int32_t *rows, int32_t n_x, int32_t n_u, int64_t loss_slot,
                         int64_t *counter, double beta1, double beta2, double *bc_next, void *stream);

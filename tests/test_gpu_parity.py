@@ -177,7 +177,8 @@ def test_atomic_and_tiled_kernels_vs_oracle(nx, ny, kw):
         plan.close()
 
 
-@pytest.mark.parametrize("world,nx,ny,kw", [(8, 401, 301, {}), (3, 301, 151, dict(diagonal="random", permute=True)), (8, 161, 121, dict(flip_fraction=0.3))])
+@pytest.mark.parametrize("world,nx,ny,kw", [(8, 401, 301, {}), (2, 401, 301, {}), (3, 301, 151, dict(diagonal="random", permute=True)),
+                                            (8, 161, 121, dict(flip_fraction=0.3))])
 def test_sharded_plan_ranges_vs_oracle(world, nx, ny, kw):
     """A plan prepared for `world` ranks (shard-aware tile policy: 512-thread / one-row tiles at these sizes; every rank's
     BOUNDARY tiles first in its range) evaluated range by range through the C ABI -- boundary part and interior part as two
@@ -199,8 +200,8 @@ def test_sharded_plan_ranges_vs_oracle(world, nx, ny, kw):
     plan = TilePlan(conn, X.shape[0], coords_hint=X, edges=edges, device=d, shards=world)
     st = plan.stats
     assert st["shards"] == world
-    if (nx, ny) == (401, 301):
-        assert st["threads_per_tile"] == 512 and st["paired"] == 1, st          # 240 k elements / 8 ranks: the 512-thread shape
+    if (nx, ny) == (401, 301):               # 240 k elements: 120 k per rank -> 512-thread one-row tiles; 30 k per rank -> 256-thread ones
+        assert st["paired"] == 1 and st["threads_per_tile"] == (512 if world == 2 else 256) and st["slot_rows"] == 1, st
     acc_l, accX, accU = 0.0, torch.zeros_like(Xd), torch.zeros_like(Ud)
     written = torch.zeros(X.shape[0], dtype=torch.int32, device=d)
     n_bnd = 0

@@ -763,10 +763,15 @@ def main():
                 peer_legs["train_step_fused"] = leg(sh.owner_train_step_fused, "Adam inside the energy launch -> put -> get", ne)
                 peer_legs["train_step_fused_overlap"] = leg(sh.owner_train_step_fused_overlapped, "Adam inside the two energy launches, "
                                                             "the get after the next step's interior tiles", ne, end_=sh.finish_overlapped)
-            st = torch.tensor([float(sh.peer.status()[0])], dtype=f64, device=dev)
+            st = torch.tensor([float(sh.peer.status()[0]), sh.verify_interfaces()], dtype=f64, device=dev)
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
-            if st.item() != 0.0:
+            if st[0].item() != 0.0:
                 raise RuntimeError("a rank timed out waiting for a peer's flags during the timed legs")
+            if st[1].item() != 0.0:
+                raise RuntimeError(f"after the peer-window legs a rank's copy of an interface row differs from its owner's by {st[1].item():.3e}")
+            peer_legs["one_launch_step"] = bool(sh.inkernel_put)
+            peer_legs["interface_rows_verified"] = ("after the timed legs every rank compared the interface rows it reads with the owners' "
+                                                    "current rows over torch.distributed: identical")
             best = max(("eval_exchange", "eval_exchange_overlap"), key=lambda k: peer_legs[k]["value"])
             if peer_legs[best]["value"] > value:
                 value, ms_per_step, launch = peer_legs[best]["value"], peer_legs[best]["ms_per_step"], peer_legs[best]["launch"]

@@ -55,6 +55,13 @@ template <typename V> __device__ __forceinline__ V row_narrow(double2 v) {
     return o;
 }
 
+// Kernel-parameter type of the parameter ROW arrays (x_free, u_free): `const V2 *__restrict__` everywhere except in the PG
+// instances (HFEM_FLAG_PEER_GET), whose service workgroups WRITE the foreign interface rows into those very arrays while the
+// boundary tiles of the same launch read them afterwards (ordered by peer_wait_unpacked's acquire fence): there the rows are
+// plain pointers to non-const data -- no write through a const __restrict__ pointer.
+template <typename V2, bool PG> struct RowArg { typedef const V2 *__restrict__ type; };
+template <typename V2> struct RowArg<V2, true> { typedef V2 *type; };
+
 struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgroup reduces the previous launch's tile energies
     const double *prev = nullptr;    // partials bank the previous launch wrote (offset to its first tile)
     int prev_n = 0;
@@ -181,20 +188,30 @@ __device__ __forceinline__ V2 adam_fused_row(const AdamFuse &af, int c, int row,
 }
 
 // The in-launch put, part 1 (a boundary tile at write-out): the NEW row of an interface node into every rank's window.
+// System-scope relaxed atomic stores (global_store ... sc0 sc1: write-through, never parked in this XCD's L2): the window is
+// uncached memory, and ordering comes from the counted wait in part 2 -- NOT from a system-scope fence, which from a tile
+// workgroup writes back its XCD's whole L2 under the running tiles (first version: 62 us per step instead of 28).
 template <typename V2>
 __device__ __forceinline__ void peer_put_row(const PeerPutDev &P, size_t slot_off, int pos, V2 pn) {
     const double2 v = row_widen(pn);
-    for (int p = 0; p < P.pv.world; ++p) reinterpret_cast<double2 *>(P.pv.win[p] + slot_off)[pos] = v;
+    for (int p = 0; p < P.pv.world; ++p) {
+        double *q = reinterpret_cast<double *>(P.pv.win[p] + slot_off) + 2 * (size_t)pos;
+        __hip_atomic_store(q, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
-// The in-launch put, part 2 (every boundary tile after its write-out): its rows have reached the windows -> ticket; the LAST
-// of the n_boundary tiles publishes the rank's previous energy, bumps the step counter, writes the next bias corrections,
-// raises the flags in every window and completes the put (seq + 1).  `red`: >= 4 doubles of LDS.  All threads of the block.
+// The in-launch put, part 2 (every boundary tile after its write-out): wait until its own stores are acknowledged
+// (s_waitcnt vmcnt(0): write-through system-scope stores complete at their destination), then take a ticket; the LAST of the
+// n_boundary tiles publishes the rank's previous energy, bumps the step counter, writes the next bias corrections, and -- its
+// own stores acknowledged as well -- raises the flags in every window and completes the put (seq + 1).  A peer that sees a
+// flag therefore sees every row: all of them were acknowledged before the flag store was issued.  `red`: >= 4 doubles of
+// LDS.  All threads of the block.
 __device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSum &lag, uint64_t seq, size_t slot_off,
                                                 int n_boundary, double *red) {
     __shared__ int put_last;
     char *ctl = P.pv.ctl;
-    __threadfence_system();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's window stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) put_last = atomicAdd((unsigned *)(ctl + 8), 1u) == (unsigned)(n_boundary - 1);
     __syncthreads();
@@ -202,10 +219,14 @@ __device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSu
     double v = 0.0;
     if (lag.put_prev && threadIdx.x < 256)
         for (int k = threadIdx.x; k < lag.put_prev_n; k += 256) v += lag.put_prev[k];
-    const double tot = block_sum(v, red);          // same order and bits as sum_partials_kernel for <= 256-thread strides
+    const double tot = block_sum(v, red);
     if (threadIdx.x == 0) {
-        for (int p = 0; p < P.pv.world; ++p) reinterpret_cast<double2 *>(P.pv.win[p] + slot_off)[P.loss_slot] = make_double2(tot, 0.0);
-        if (P.counter) {
+        for (int p = 0; p < P.pv.world; ++p) {
+            double *q = reinterpret_cast<double *>(P.pv.win[p] + slot_off) + 2 * (size_t)P.loss_slot;
+            __hip_atomic_store(q, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(q + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (P.counter) {                                   // device-local: the next launch reads them behind the kernel boundary
             const int64_t c = P.counter[0] + 1;
             P.counter[0] = c;
             if (lag.put_bc_next) {
@@ -213,16 +234,16 @@ __device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSu
                 lag.put_bc_next[1] = sqrt(1.0 - pow(P.beta2, (double)(c + 1)));
             }
         }
-        __threadfence_system();
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     const int par = (int)(seq & 1);
     if ((int)threadIdx.x < P.pv.world)
         __hip_atomic_store((uint64_t *)(P.pv.win[threadIdx.x] + kPeerFlags) + par * kMaxPeers + P.pv.rank, seq + 1,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (threadIdx.x == 0) {
         *(unsigned *)(ctl + 8) = 0u;
-        __hip_atomic_store((uint64_t *)ctl, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((uint64_t *)ctl, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

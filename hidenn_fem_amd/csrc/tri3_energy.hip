@@ -238,8 +238,8 @@ __global__ __launch_bounds__(BLOCK) void tri3_energy_tiled_kernel(
 template <int BLOCK, int NPT, int EPT, bool HASB, bool STAMP = false, int SP = 0, typename V2 = double2, int CAPN = 0,
           int CAPO = 0, bool ADAM = false, bool PHYS = false, bool PG = false>
 __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_energy_fast_kernel(
-    PlanDev pd, int tile_begin, const V2 *__restrict__ x_free,
-    const V2 *__restrict__ x_fixed, const V2 *__restrict__ u_free,
+    PlanDev pd, int tile_begin, typename RowArg<V2, PG>::type x_free,
+    const V2 *__restrict__ x_fixed, typename RowArg<V2, PG>::type u_free,
     const V2 *__restrict__ u_fixed, Tri3Consts k, const double4 *__restrict__ T_edge,
     double4 Tconst, double *__restrict__ partials, V2 *__restrict__ gx_free,
     V2 *__restrict__ gu_free, int cap_nodes_rt, int cap_owned_rt, int skip_edges, int stagger_ticks, int stagger_cfg,
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(BLOCK, (!HASB && BLOCK >= 512) ? 8 : 1) void tri3_e
     int bid = (int)blockIdx.x;
     if constexpr (PG) {
         if (bid < lag.pg_blocks) {
-            peer_get_block<V2>(*lag.pg, bid, lag.pg_blocks, const_cast<V2 *>(x_free), const_cast<V2 *>(u_free));
+            peer_get_block<V2>(*lag.pg, bid, lag.pg_blocks, x_free, u_free);      // RowArg<V2, true>: writable, not restrict
             return;
         }
         bid -= lag.pg_blocks;
@@ -529,7 +529,7 @@ void launch_fast(const Tri3Launch &A, int grid, const AdamFuse &af, const LagSum
     if constexpr (!HB && !PHYS && !STAMP && BLK == 512 && (SP == 16 || SP == 2)) {
         if (lag.pg_blocks) {                               // HFEM_FLAG_PEER_GET: the instance with the in-launch get
             hipLaunchKernelGGL((tri3_energy_fast_kernel<BLK, NPT, EPT, HB, STAMP, SP, V2, 0, CO, ADAM, PHYS, true>), dim3(grid), dim3(BLK),
-                               lds, A.s, A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
+                               lds, A.s, A.pd, A.tile_begin, (V2 *)const_cast<void *>(A.x_free), (const V2 *)A.x_fixed, (V2 *)const_cast<void *>(A.u_free),
                                (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
                                CO > 0 ? CO : A.max_owned, A.skip_edges, A.stagger, A.stagger_cfg, A.stamps, af, lag);
             return;
@@ -745,6 +745,11 @@ extern "C" int hfem_plan_create_ex(int device, const int64_t *conn, int64_t ne, 
     if (pair_block < 0) pair_block = 256;
     if (tile_elems <= 0) tile_elems = node_cap > 0 ? 1200 : 1024;
     int order = g_def.plan_elem_order.load();
+#ifndef HFEM_LAB
+    // the strip order's carrying slot loop measured slower and ships in the lab build only; the PLANNER keeps
+    // the order (host-only plans: tests/test_plan_host.py, scripts/plan_bank_stats.py)
+    HFEM_ARG_CHECK(!(order == 6 && device >= 0), "plan_elem_order 6 (pairs chained into strips): device plans in the lab build only (libhidenn_hip_lab.so)");
+#endif
     const bool auto_order = order < 0;
     if (auto_order) order = nodes_per_elem == 3 ? 5 : 3;
     if (build_host_plan(conn, nodes_per_elem, ne, nn, coords_hint, x_src, u_src, edges, ned, tile_elems, node_cap, order,

@@ -31,8 +31,8 @@ namespace hfem {
 template <int BLOCK, int NPT, int EPT, int WPS, int CAPO, bool HASB = false, bool PHYS = false, typename V2 = double2,
           bool ADAM = false, bool CHAIN = false, int CAPN = 0, int SP = 16, bool PG = false>
 __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
-    PlanDev pd, int tile_begin, const V2 *__restrict__ x_free, const V2 *__restrict__ x_fixed,
-    const V2 *__restrict__ u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
+    PlanDev pd, int tile_begin, typename RowArg<V2, PG>::type x_free, const V2 *__restrict__ x_fixed,
+    typename RowArg<V2, PG>::type u_free, const V2 *__restrict__ u_fixed, Tri3Consts k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     V2 *__restrict__ gx_free, V2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
     LagSum lag, AdamFuse af, int col_stride) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     int bid = (int)blockIdx.x;
     if constexpr (PG) {
         if (bid < lag.pg_blocks) {
-            peer_get_block<V2>(*lag.pg, bid, lag.pg_blocks, const_cast<V2 *>(x_free), const_cast<V2 *>(u_free));
+            peer_get_block<V2>(*lag.pg, bid, lag.pg_blocks, x_free, u_free);      // RowArg<V2, true>: writable, not restrict
             return;
         }
         bid -= lag.pg_blocks;                           // a multiple of 8: the block -> XCD mapping of the tiles is unchanged
@@ -332,7 +332,7 @@ static void launch_pair_inst2(const PairLaunch &A, const LagSum &lag, const Adam
     if constexpr (!HASB && !PHYS && !CHAIN) {
         if (lag.pg_blocks) {                               // HFEM_FLAG_PEER_GET: the instance with the in-launch get
             hipLaunchKernelGGL((tri3_energy_pair_kernel<BLK, NPT, EPT, 4, CAPO, HASB, PHYS, V2, ADAM, CHAIN, CAPN, SP, true>), dim3(A.grid), dim3(BLK), lds, A.s,
-                               A.pd, A.tile_begin, (const V2 *)A.x_free, (const V2 *)A.x_fixed, (const V2 *)A.u_free,
+                               A.pd, A.tile_begin, (V2 *)const_cast<void *>(A.x_free), (const V2 *)A.x_fixed, (V2 *)const_cast<void *>(A.u_free),
                                (const V2 *)A.u_fixed, A.k, A.T_edge, A.tc, A.partials, (V2 *)A.gx, (V2 *)A.gu, A.max_nodes,
                                CAPO > 0 ? CAPO : A.max_owned, A.skip_edges, lag, af, A.col_stride);
             return;

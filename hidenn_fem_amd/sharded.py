@@ -823,6 +823,30 @@ class ShardedTri3Energy:
         if self.peer is not None:
             self.peer.check()
 
+    def verify_interfaces(self) -> float:
+        """Max |difference| between this rank's copy of every interface row it READS and the owner's current value, obtained
+        over ``torch.distributed`` (never over the peer windows): 0.0 when the exchange delivered what it should.  A check for
+        callers that want to confirm a peer-window run on their topology (bench.py does, after its one-launch legs); collective,
+        synchronises.  Call after ``finish_overlapped()``."""
+        m = self.model
+        if self.world == 1:
+            return 0.0
+        n_x, n_u = self._pub_n
+        rows = self._pub_rows.long()
+        pay = torch.zeros(self.iface_stride, 2, dtype=F64, device=self.send.device)
+        pay[:n_x] = m.node_coords_free.detach()[rows[:n_x]].to(F64)
+        pay[n_x:n_x + n_u] = m.u_free.detach()[rows[n_x:]].to(F64)
+        got = torch.zeros(self.world * self.iface_stride, 2, dtype=F64, device=self.send.device)
+        dist.all_gather_into_tensor(got, pay, group=self.group)
+        nx_, nu_ = self._need_n
+        src, dst = self._need_src.long(), self._need_dst.long()
+        err = 0.0
+        if nx_:
+            err = max(err, (got[src[:nx_]] - m.node_coords_free.detach()[dst[:nx_]].to(F64)).abs().max().item())
+        if nu_:
+            err = max(err, (got[src[nx_:]] - m.u_free.detach()[dst[nx_:]].to(F64)).abs().max().item())
+        return err
+
     def owned_rows(self):
         """(x rows, u rows) of node_coords_free / u_free that this rank's tiles own (int64 tensors)."""
         td, ns = self.plan.export("tile_desc").astype(np.int64), self.plan.export("node_src").astype(np.int64)

@@ -278,6 +278,7 @@ def _worker_two_ranks(rank, world, port, q, per_gpu=False):
             seen_u = torch.unique(torch.cat([own_u, ref._need_dst[ref._need_n[0]:].long()]))
             same = (_close(l_got, l_ref) and _close(got.model.node_coords_free[seen_x].detach(), ref.model.node_coords_free[seen_x].detach())
                     and _close(got.model.u_free[seen_u].detach(), ref.model.u_free[seen_u].detach()))
+            same = same and got.verify_interfaces() == 0.0      # every interface row this rank reads IS the owner's current row
             st = (got.peer.status(), _puts(got, name, n, 1))
             # captured: an even number of steps per graph (the fused steps alternate between two parameter buffers)
             dist.barrier()

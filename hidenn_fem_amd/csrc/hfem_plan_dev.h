@@ -75,7 +75,8 @@ struct LagSum {                      // HFEM_FLAG_SUM_PREVIOUS: one extra workgr
     // each stores the NEW rows of its interface nodes into every rank's window at write-out, and the last of them to finish
     // writes the rank's energy of the PREVIOUS evaluation (put_prev: its tile energies, complete since the last kernel
     // boundary), bumps the step counter, writes the next step's bias corrections (put_bc_next) and raises the flags
-    const PeerPutDev *put = nullptr;
+    const PeerPutDev *put = nullptr;     // non-NULL = the launch publishes; its fields the tiles need early travel BY VALUE below
+    const int32_t *put_pos_x = nullptr, *put_pos_u = nullptr;   // (no dependent load of the struct in front of the row lookups)
     const double *put_prev = nullptr;
     int put_prev_n = 0;
     double *put_bc_next = nullptr;
@@ -300,6 +301,7 @@ struct hfem_plan {
     const hfem::PeerGetDev *peer_get = nullptr;   // hfem_plan_set_peer_get: in-launch get of HFEM_FLAG_PEER_GET launches
     const hfem::PeerPutDev *peer_put = nullptr;   // hfem_plan_set_peer_put: in-launch put of HFEM_FLAG_PEER_PUT launches
     double *put_bc[2] = {nullptr, nullptr};       // ... and the two bias-correction buffers its steps alternate between
+    const int32_t *put_pos[2] = {nullptr, nullptr};   // ... and the row -> payload position tables (by value into the launch)
     int peer_wait_begin = 0, peer_wait_end = 0;   // the tiles that wait for it (the rank's boundary tiles)
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
@@ -372,6 +374,7 @@ struct hfem_peer {
     char *ctl = nullptr;             // puts / tickets / status / unpacked (hipMalloc)
     hfem::PeerGetDev *get_dev = nullptr;   // arguments of the in-launch get (hfem_peer_attach_get), or NULL
     hfem::PeerPutDev *put_dev = nullptr;   // arguments of the in-launch put (hfem_peer_attach_put), or NULL
+    const int32_t *put_pos[2] = {nullptr, nullptr};
     std::vector<void *> opened;      // hipIpcOpenMemHandle results (the peers' windows)
     bool connected = false;
     hfem::PeerView view{};

@@ -249,6 +249,7 @@ extern "C" int hfem_peer_attach_put(hfem_peer *peer, const int32_t *pos_x, const
     if (!peer->put_dev) e = hipMalloc((void **)&peer->put_dev, sizeof(PeerPutDev));
     if (e == hipSuccess) e = hipMemcpy(peer->put_dev, &g, sizeof(PeerPutDev), hipMemcpyHostToDevice);
     if (e != hipSuccess) return hip_fail(e, "hfem_peer_attach_put");
+    peer->put_pos[0] = pos_x; peer->put_pos[1] = pos_u;
     return 0;
 }
 

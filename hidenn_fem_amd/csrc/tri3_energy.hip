@@ -1210,6 +1210,7 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
                        "HFEM_FLAG_PEER_PUT: the launch must cover the rank's (non-empty) boundary range");
         HFEM_ARG_CHECK(bc_dev == plan->put_bc[0] || bc_dev == plan->put_bc[1], "HFEM_FLAG_PEER_PUT: bc_dev must be one of the two buffers given to hfem_plan_set_peer_put");
         lag.put = plan->peer_put;
+        lag.put_pos_x = plan->put_pos[0]; lag.put_pos_u = plan->put_pos[1];
         lag.put_bc_next = bc_dev == plan->put_bc[0] ? plan->put_bc[1] : plan->put_bc[0];
         if (plan->prev_n > 0 && plan->prev_stream == stream) {      // the previous evaluation's tile energies (the other bank)
             lag.put_prev = plan->d_partials + (size_t)plan->bank * nt + plan->prev_begin;
@@ -1371,12 +1372,13 @@ extern "C" int hfem_plan_set_peer_get(hfem_plan *plan, hfem_peer *peer, int32_t 
 extern "C" int hfem_plan_set_peer_put(hfem_plan *plan, hfem_peer *peer, double *bc_a, double *bc_b) {
     HFEM_ARG_CHECK(plan, "null pointer");
     PlanLock lock(plan);
-    if (!peer) { plan->peer_put = nullptr; plan->put_bc[0] = plan->put_bc[1] = nullptr; return 0; }
+    if (!peer) { plan->peer_put = nullptr; plan->put_bc[0] = plan->put_bc[1] = nullptr; plan->put_pos[0] = plan->put_pos[1] = nullptr; return 0; }
     HFEM_ARG_CHECK(peer->connected && peer->put_dev, "hfem_peer_connect / hfem_peer_attach_put first");
     HFEM_ARG_CHECK(peer->device == plan->device, "plan and peer windows live on different devices");
     HFEM_ARG_CHECK(plan->host.paired && plan->host.n_chained == 0, "the in-launch put needs a paired-slot plan (plain slot loop)");
     HFEM_ARG_CHECK(bc_a && bc_b && bc_a != bc_b, "need two distinct bias-correction buffers");
     plan->peer_put = peer->put_dev; plan->put_bc[0] = bc_a; plan->put_bc[1] = bc_b;
+    plan->put_pos[0] = peer->put_pos[0]; plan->put_pos[1] = peer->put_pos[1];
     return 0;
 }
 

@@ -86,6 +86,18 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         w0[j] = pd.elem_pack[i];
         w1[j] = pd.elem_pack_hi[i];
     }
+    // HFEM_FLAG_PEER_PUT: a boundary tile will publish the new rows of its interface nodes at write-out -- where each row sits
+    // in the payload is looked up NOW, behind the row maps and under the wait below, not as a late dependent load
+    int put_px[NPT], put_pu[NPT];
+    bool putting = false;
+    if constexpr (PG && ADAM) {
+        putting = lag.put && tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            put_px[j] = (putting && s[j].x >= 0) ? lag.put_pos_x[s[j].x] : -1;
+            put_pu[j] = (putting && s[j].y >= 0) ? lag.put_pos_u[s[j].y] : -1;
+        }
+    }
     if constexpr (PG) {
         if (tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end)
             peer_wait_unpacked(*lag.pg);                // a boundary tile: the rows it reads from other ranks are being copied in
@@ -238,11 +250,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];
         // HFEM_FLAG_PEER_PUT (PG instances): a boundary tile also PUBLISHES -- the new rows of its interface nodes go straight
         // into every rank's receive window (the separate put launch of a sharded step disappears)
-        bool putting = false;
         uint64_t put_seq = 0;
         size_t put_off = 0;
         if constexpr (PG) {
-            putting = lag.put && tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end;
             if (putting) {
                 put_seq = __hip_atomic_load((uint64_t *)lag.put->pv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 put_off = kPeerData + ((size_t)(put_seq & 1) * lag.put->pv.world + lag.put->pv.rank) * (size_t)lag.put->stride * sizeof(double2);
@@ -255,19 +265,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
                 if (s[j].x >= 0) {
                     const V2 pn = adam_fused_row<V2>(af, 0, s[j].x, acc0[l], acc1[l], nd_xy[l], bc1, sqrt_bc2);
                     if constexpr (PG) {
-                        if (putting) {
-                            const int pos = lag.put->pos_x[s[j].x];
-                            if (pos >= 0) peer_put_row<V2>(*lag.put, put_off, pos, pn);
-                        }
+                        if (putting && put_px[j] >= 0) peer_put_row<V2>(*lag.put, put_off, put_px[j], pn);
                     }
                 }
                 if (s[j].y >= 0) {
                     const V2 pn = adam_fused_row<V2>(af, 1, s[j].y, acc2[l], acc3[l], nd_uv[l], bc1, sqrt_bc2);
                     if constexpr (PG) {
-                        if (putting) {
-                            const int pos = lag.put->pos_u[s[j].y];
-                            if (pos >= 0) peer_put_row<V2>(*lag.put, put_off, pos, pn);
-                        }
+                        if (putting && put_pu[j] >= 0) peer_put_row<V2>(*lag.put, put_off, put_pu[j], pn);
                     }
                 }
             }

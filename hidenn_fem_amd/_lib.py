@@ -81,6 +81,7 @@ PROTOTYPES = {
     "hfem_lbfgs_shard_local": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "hfem_lbfgs_shard_finish": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f64, _f64, _f64, _vp, _vp]),
     "hfem_lbfgs_shard_apply": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "hfem_lbfgs_shard_status": (C.c_int, [_vp, _vp, _vp]),
     "hfem_tri3_von_mises": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),
     "hfem_line2_slopes": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hfem_tri3_energy_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -744,6 +744,7 @@ struct hfem_lbfgs {
     bool first = true;              // no pair yet (torch state["n_iter"] == 0)
     void *Sring = nullptr, *Yring = nullptr, *g_prev = nullptr, *d = nullptr;
     double *scal = nullptr, *status = nullptr;
+    double *status_pinned = nullptr;  // host-pinned copy of the status record (hfem_lbfgs_shard_finish without a host pointer: capturable)
     LbfgsArrays A{};
 };
 
@@ -760,6 +761,7 @@ extern "C" int hfem_lbfgs_destroy(hfem_lbfgs *o) {
         (void)hipSetDevice(o->device);
         (void)hipFree(o->Sring); (void)hipFree(o->Yring); (void)hipFree(o->g_prev); (void)hipFree(o->d);
         (void)hipFree(o->scal); (void)hipFree(o->status); (void)hipFree(o->A.part); (void)hipFree(o->A.st);
+        if (o->status_pinned) (void)hipHostFree(o->status_pinned);
     }
     delete o;
     return 0;
@@ -914,8 +916,12 @@ extern "C" int hfem_lbfgs_shard_local(hfem_lbfgs *o, const void *g, const double
 extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const double *gathered_dev, int32_t world, int32_t after_update,
                                        int32_t want_direction, double lr, double tol_grad, double tol_change, double *status_host,
                                        void *stream) {
-    HFEM_ARG_CHECK(o && g && gathered_dev && status_host, "null pointer");
+    HFEM_ARG_CHECK(o && g && gathered_dev, "null pointer");
     HFEM_ARG_CHECK(world >= 1, "world must be >= 1");
+    if (!status_host && !o->status_pinned) {          // enqueue-only form: the status record goes to a pinned buffer of the object
+        if (int rc = use_device(o->device)) return rc;
+        HFEM_HIP_CHECK(hipHostMalloc((void **)&o->status_pinned, 8 * sizeof(double)));
+    }
     if (int rc = use_device(o->device)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int first = o->first ? 1 : 0, M1 = o->M1;
@@ -938,9 +944,24 @@ extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const doubl
 #undef HFEM_DIR
     hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, nb_dir, o->status);
     if (int rc = launch_status("hfem_lbfgs_shard_finish")) return rc;
+    if (!status_host) {                                         // enqueue only (legal inside a hipGraph capture): hfem_lbfgs_shard_status reads it
+        HFEM_HIP_CHECK(hipMemcpyAsync(o->status_pinned, o->status, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+        return 0;
+    }
     HFEM_HIP_CHECK(hipMemcpyAsync(status_host, o->status, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HFEM_HIP_CHECK(hipStreamSynchronize(s));
     if (!((int)status_host[1] & 16)) o->first = false;          // a direction exists from now on
+    return 0;
+}
+
+// Status record of the last hfem_lbfgs_shard_finish that was given no host pointer (a captured / replayed iteration):
+// synchronises the stream, copies the pinned record out.
+extern "C" int hfem_lbfgs_shard_status(hfem_lbfgs *o, double *status_host, void *stream) {
+    HFEM_ARG_CHECK(o && status_host && o->status_pinned, "null pointer / no enqueue-only finish has run");
+    if (int rc = use_device(o->device)) return rc;
+    HFEM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < 8; ++i) status_host[i] = o->status_pinned[i];
+    if (!((int)status_host[1] & 16)) o->first = false;
     return 0;
 }
 

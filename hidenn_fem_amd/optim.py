@@ -440,13 +440,19 @@ class ShardedLBFGS:
     HIP evaluator only; fp64 and fp32 models; one ``step()`` = one ``optimizer.step(closure)`` of the reference's loop."""
 
     def __init__(self, sharded, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100,
-                 emulate: bool = False):
+                 emulate: bool = False, graph: bool = True):
         """``emulate=True`` (bench.py's one-GPU rehearsal of rank r of N; timing only): ``sharded`` plays one rank of a world
         that does not exist -- no interface exchange, and the payload "gather" is this rank's payload copied into every rank's
         slot, so the local passes, launches and the status read cost what they would on that rank."""
         import ctypes as C
         sh = self.sh = sharded
         self._emulate = bool(emulate)
+        # steady-state inner iterations (apply -> exchange -> energy -> gather -> local sums -> payload exchange -> finish) are a
+        # dozen short launches behind a status read that drains the stream: as ONE hipGraph the GPU no longer waits for the host
+        # between them.  Possible whenever the exchanges are capturable: one rank, the in-library RCCL communicator, or peer
+        # windows for the interface rows (torch.distributed collectives are not: those runs stay eager).
+        self._graph_ok = bool(graph)
+        self._graph = None
         if not sh._hip:
             raise RuntimeError("ShardedLBFGS needs the HIP evaluator")
         if not hasattr(sh, "iface_rows"):
@@ -513,6 +519,39 @@ class ShardedLBFGS:
                                         self._status, stream_ptr(dev)), "hfem_lbfgs_shard_finish")
         return int(self._status[1])
 
+    def _apply(self):
+        m, dev = self.sh.model, self._g.device
+        check(_lib.lib().hfem_lbfgs_shard_apply(self._h, ptr(m.node_coords_free.data), ptr(self._rx), self._rx.numel(),
+                                                ptr(m.u_free.data), ptr(self._ru), self._ru.numel(), stream_ptr(dev)), "hfem_lbfgs_shard_apply")
+
+    def _capturable(self) -> bool:
+        sh = self.sh
+        return self._graph_ok and (sh.world == 1 or self._emulate or sh.comm is not None)      # LibraryComm: in-library RCCL, capturable
+
+    def _iteration_graphed(self) -> int:
+        """apply + evaluate + reduce(after_update = 1, want_direction) of a steady-state iteration as one graph replay."""
+        sh, L = self.sh, _lib.lib()
+        dev = self._g.device
+        if self._graph is None:
+            def body():
+                self._apply()
+                self._evaluate()
+                check(L.hfem_lbfgs_shard_local(self._h, ptr(self._g), ptr(self._loss_local), ptr(self._payload), stream_ptr(dev)),
+                      "hfem_lbfgs_shard_local")
+                if sh.world > 1 and self._emulate:
+                    self._gathered.view(sh.world, -1).copy_(self._payload.unsqueeze(0).expand(sh.world, -1))
+                elif sh.world > 1:
+                    sh.comm.all_gather(self._payload, self._gathered)
+                check(L.hfem_lbfgs_shard_finish(self._h, ptr(self._g), ptr(self._gathered), int(sh.world), 1, 1, self.lr,
+                                                self.tolerance_grad, self.tolerance_change, None, stream_ptr(dev)), "hfem_lbfgs_shard_finish")
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            self._graph = g
+        self._graph.replay()
+        check(L.hfem_lbfgs_shard_status(self._h, self._status, stream_ptr(dev)), "hfem_lbfgs_shard_status")
+        return int(self._status[1])
+
     @torch.no_grad()
     def step(self) -> torch.Tensor:
         """One ``optimizer.step(closure)`` of the reference's loop; returns the (global) energy of its FIRST evaluation."""
@@ -533,14 +572,20 @@ class ShardedLBFGS:
             self.state["n_iter"] += 1
             if flags & 8:                                        # g.d > -tolerance_change: nothing is applied
                 break
-            check(L.hfem_lbfgs_shard_apply(self._h, ptr(m.node_coords_free.data), ptr(self._rx), self._rx.numel(),
-                                           ptr(m.u_free.data), ptr(self._ru), self._ru.numel(), stream_ptr(dev)), "hfem_lbfgs_shard_apply")
+            want = current_evals + 1 < self.max_eval
+            if n_iter < self.max_iter and want and self._capturable():
+                flags = self._iteration_graphed()                # apply + energy + sums + exchange + finish: one graph replay
+                current_evals += 1
+                self.state["func_evals"] += 1
+                if flags & 7:
+                    break
+                continue
+            self._apply()
             if n_iter == self.max_iter:
                 break
             self._evaluate()
             current_evals += 1
             self.state["func_evals"] += 1
-            want = current_evals < self.max_eval
             flags = self._reduce(1, want)
             if not want or flags & 7:
                 break

@@ -409,6 +409,10 @@ int hfem_lbfgs_shard_local(hfem_lbfgs *opt, const void *g, const double *loss_lo
 int hfem_lbfgs_shard_finish(hfem_lbfgs *opt, const void *g, const double *gathered_dev, int32_t world, int32_t after_update,
                             int32_t want_direction, double lr, double tol_grad, double tol_change, double *status_host,
                             void *stream);
+/* hfem_lbfgs_shard_finish with status_host = NULL only enqueues (the record goes to a pinned buffer of the optimiser): a whole
+ * steady-state iteration -- apply, energy, gather, local, the exchange, finish -- is then capturable in ONE hipGraph;
+ * hfem_lbfgs_shard_status synchronises the stream and hands the record out.                                          */
+int hfem_lbfgs_shard_status(hfem_lbfgs *opt, double *status_host, void *stream);
 int hfem_lbfgs_shard_apply(hfem_lbfgs *opt, void *x, const int32_t *rows_x, int64_t nx, void *u, const int32_t *rows_u,
                            int64_t nu, void *stream);
 

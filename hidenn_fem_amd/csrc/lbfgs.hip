@@ -792,6 +792,10 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     const size_t nscal = 4 * M1 + 5 * M1 + 2 * M1 * M1;
     if (!rc) rc = lb_malloc(&o->scal, nscal);
     if (!rc) rc = lb_malloc(&o->status, 8);
+    if (!rc && hipHostMalloc((void **)&o->status_pinned, 8 * sizeof(double)) != hipSuccess) {      // for the enqueue-only finish
+        set_error("hfem_lbfgs_create: hipHostMalloc failed");
+        rc = -1;
+    }
     const size_t npart = std::max<size_t>({(size_t)o->nb_md * M1 * 5, (size_t)o->nb_stream * 5, (size_t)o->nb_chunk,
                                            (size_t)((n + kLb - 1) / kLb) < 8192 ? (size_t)((n + kLb - 1) / kLb) : 0});
     if (!rc) rc = lb_malloc(&o->A.part, npart);
@@ -918,10 +922,7 @@ extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const doubl
                                        void *stream) {
     HFEM_ARG_CHECK(o && g && gathered_dev, "null pointer");
     HFEM_ARG_CHECK(world >= 1, "world must be >= 1");
-    if (!status_host && !o->status_pinned) {          // enqueue-only form: the status record goes to a pinned buffer of the object
-        if (int rc = use_device(o->device)) return rc;
-        HFEM_HIP_CHECK(hipHostMalloc((void **)&o->status_pinned, 8 * sizeof(double)));
-    }
+    HFEM_ARG_CHECK(status_host || o->status_pinned, "no pinned status buffer");
     if (int rc = use_device(o->device)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int first = o->first ? 1 : 0, M1 = o->M1;

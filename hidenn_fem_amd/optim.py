@@ -545,8 +545,15 @@ class ShardedLBFGS:
                 check(L.hfem_lbfgs_shard_finish(self._h, ptr(self._g), ptr(self._gathered), int(sh.world), 1, 1, self.lr,
                                                 self.tolerance_grad, self.tolerance_change, None, stream_ptr(dev)), "hfem_lbfgs_shard_finish")
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                body()
+            try:
+                with torch.cuda.graph(g):
+                    body()
+            except Exception:                                    # a transport that turned out not to be capturable: nothing of the
+                torch.cuda.synchronize()                         # body has RUN (a capture does not execute) -- this and every
+                self._graph_ok, self._graph = False, None        # later iteration take the eager launches
+                self._apply()
+                self._evaluate()
+                return self._reduce(1, True)
             self._graph = g
         self._graph.replay()
         check(L.hfem_lbfgs_shard_status(self._h, self._status, stream_ptr(dev)), "hfem_lbfgs_shard_status")

@@ -660,6 +660,7 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
         (void)hipFree(plan->d_tile_chunks);
         free_tri3_det(plan);
         (void)hipFree(plan->d_partials);
+        (void)hipFree(plan->d_f32_scale);
         (void)hipFree(plan->d_stamps);
     }
     delete plan;
@@ -1053,6 +1054,16 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
             int b = 0;
             while ((1 << b) < vmax) ++b;
             plan->f32_vbits = b;
+        }
+        if (!plan->d_f32_scale) {                           // ... and the per-tile maxima its lagged scale comes from (0 = none yet)
+            hipError_t e_ = hipMalloc((void **)&plan->d_f32_scale, sizeof(float2) * std::max<size_t>(1, h.tiles.size()));
+            if (e_ == hipSuccess) e_ = hipMemset(plan->d_f32_scale, 0, sizeof(float2) * std::max<size_t>(1, h.tiles.size()));
+            if (e_ != hipSuccess) {
+                plan->d_f32_scale = nullptr;
+                (void)hipGetLastError();
+                set_error("hfem_tri3_energy_plan_f32: the first fp32-arithmetic launch on a plan allocates its scale array and cannot be captured into a hipGraph: run one eager evaluation first");
+                return -1;
+            }
         }
         const int n = tile_end - tile_begin;
         const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0, same_bank = (flags & HFEM_FLAG_SAME_BANK) != 0;

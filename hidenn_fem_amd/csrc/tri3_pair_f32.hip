@@ -9,14 +9,18 @@
 //     registers (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): a pair costs the vector instructions of one element;
 //   * gradient rows are accumulated in 32-bit FIXED POINT, two values per ds_add_u64: gfx950 services ds_add_f32 lane by lane
 //     (194 cycles per wave-instruction; the first version of this kernel, with float accumulators, took 46.9 us on T1M), where
-//     ds_add_f64 takes 8.6 and ds_add_u64 6.5 (scripts/micro/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench.txt).  The
-//     slot loop runs in two passes over REGISTERS: pass 1 evaluates every slot of the thread and keeps its 16 row values,
-//     the tile takes the largest |contribution| of the coordinate rows and of the displacement rows (two wave / block
-//     maxima); pass 2 scales by a power of two 2^k with valence x max x 2^k < 2^30 (the valence bound comes from the plan),
-//     rounds to int32, packs (gx, gy) and (gu, gv) into one 64-bit word each (hi + borrow : lo, so that adding words adds both
-//     halves) and issues 8 ds_add_u64 per pair instead of 16 ds_add_f64.  Resolution: 2^-30 of valence x the largest
-//     contribution -- the size of fp32 accumulation's own rounding (the reference sums in fp32).  A non-finite contribution
-//     (degenerate element) poisons the tile's owned rows with NaN: NaN / Inf propagate, coarser than element by element.
+//     ds_add_f64 takes 8.6 and ds_add_u64 6.5 (scripts/micro/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench.txt): a
+//     pair issues 8 ds_add_u64 instead of 16 ds_add_f64.  Every contribution is scaled by a power of two 2^k, rounded to int32,
+//     and (gx, gy) / (gu, gv) are packed into one 64-bit word each (hi + borrow : lo, so that adding words adds both halves);
+//     k is chosen so that valence x largest |contribution| x 2^k < 2^30 (the valence bound comes from the plan).  The largest
+//     contribution of a tile is not known before the slots are evaluated, and evaluating first / adding afterwards puts
+//     all waves of a CU into the same phase (measured: 9.3 us, slower than the double accumulators' 7.3) -- so the scale is
+//     LAGGED: every tile remembers the maxima of its previous evaluation (plan-owned array), the slot loop runs ONCE with
+//     4 x that as its bound while it tracks this evaluation's maxima, and only a tile whose bound turns out too small (the
+//     first evaluation of a plan; gradients that grew more than 4 x from one evaluation to the next) clears its accumulators
+//     and redoes its slots with the exact scale.  Resolution: 2^-28 / valence of the largest contribution -- the size of fp32
+//     accumulation's own rounding (the reference sums in fp32).  A non-finite element energy (degenerate element) poisons
+//     the tile's owned rows with NaN: NaN / Inf propagate, coarser than element by element.
 //     The tile energy is accumulated in fp64 (one v_cvt + one v_add_f64 per slot): never worse than the reference's fp32 sum.
 // HBM-bound by construction, no MFMA (2x2 / 2x3 contractions).  Algorithmic bytes per launch: 12 Ne + 32 Nn + 8.
 #include <hip/hip_runtime.h>
@@ -103,12 +107,12 @@ __device__ __forceinline__ f2 tri3_pair_f32(const f2 X0x, const f2 X0y, const f2
 // strides of the default tile shape.  SP: cache policy of the gradient stores (16 sc1 write-through, 2 nt).  LDS:
 // float4 nd[cap_n] | u64 acc[2][cap_owned] | double red[BLOCK / 64] | float mred[2][BLOCK / 64] | int bad.
 template <int BLOCK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : 4) void tri3_energy_pair_f32_kernel(
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_f32_kernel(
     PlanDev pd, int tile_begin, const float2 *__restrict__ x_free, const float2 *__restrict__ x_fixed,
     const float2 *__restrict__ u_free, const float2 *__restrict__ u_fixed, Tri3ConstsF k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     float2 *__restrict__ gx_free, float2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    LagSum lag, int col_stride, int vbits) {
+    LagSum lag, int col_stride, int vbits, float2 *__restrict__ tile_scale) {
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     const int cap_n = CAPN > 0 ? CAPN : cap_nodes;
     extern __shared__ float4 lds4[];
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : 4) void tri3_energy_pair_
 #pragma unroll
     for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];
     const TileDesc d = pd.tiles[tile_begin + slot];
+    const float2 prev_max = tile_scale[tile_begin + slot];      // this tile's maxima at its previous evaluation (0: none yet)
     uint32_t w0[EPT], w1[EPT];
     const size_t rec0 = (size_t)(tile_begin + slot) * pd.elem_stride;
 #pragma unroll
@@ -175,19 +180,27 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : 4) void tri3_energy_pair_
     if (tid == 0) *bad_tile = 0;
     __syncthreads();
 
-    // ---- pass 1: every slot of this thread: rows {b, d, n, c} x {gx, gy, gu, gv}.  KEEP (<= 3 slot rows: the default tile shapes):
-    //      the 16 values of every slot stay in registers for pass 2; more rows would spill -- those instances evaluate twice
-    constexpr bool KEEP = EPT <= 3;
-    float r[KEEP ? EPT : 1][16], er[8];
-    float mx = 0.0f, mu = 0.0f;                          // largest |coordinate-row value|, |displacement-row value| so far
+    // ---- scale of this evaluation: 4 x the previous evaluation's maxima as the bound (valence x bound x 2^k < 2^30)
+    int ex, eu;
+    (void)frexpf(4.0f * prev_max.x, &ex);
+    (void)frexpf(4.0f * prev_max.y, &eu);
+    int kx = min(96, 30 - vbits - ex), ku = min(96, 30 - vbits - eu);
+    float sx = ldexpf(1.0f, kx), su = ldexpf(1.0f, ku);
+    float mx = 0.0f, mu = 0.0f;                          // this evaluation's largest |coordinate-row value|, |displacement-row value|
     bool bad = false;
     double e_loc = 0.0;
+    // fixed point, two values per 64-bit atomic: word = (int64)hi * 2^32 + (int64)lo -- adding words adds both halves
+    auto add_row = [&](int l, float gx, float gy, float gu, float gv) {
+        const int qx = __float2int_rn(gx * sx), qy = __float2int_rn(gy * sx), qu = __float2int_rn(gu * su), qv = __float2int_rn(gv * su);
+        atomicAdd(&accX[l], ((unsigned long long)(uint32_t)(qy + (qx >> 31)) << 32) | (uint32_t)qx);
+        atomicAdd(&accU[l], ((unsigned long long)(uint32_t)(qv + (qu >> 31)) << 32) | (uint32_t)qu);
+    };
     auto see = [&](float a, float b, float c, float d) {
         mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
         mu = fmaxf(mu, fmaxf(fabsf(c), fabsf(d)));
-        bad = bad || !(fabsf(a) <= 3.0e38f) || !(fabsf(b) <= 3.0e38f) || !(fabsf(c) <= 3.0e38f) || !(fabsf(d) <= 3.0e38f);
     };
-    auto eval_slot = [&](uint32_t p, uint32_t q, float (&o)[16], bool count_energy) {
+    // one slot: evaluate the pair, add its four rows {b, d, n, c}; first: also count the energy and track the maxima
+    auto do_slot = [&](uint32_t p, uint32_t q, bool first) {
         const int ln = (int)(p & kLocalMask), lb = (int)((p >> kLocalBits) & kLocalMask),
                   lc = (int)((p >> (2 * kLocalBits)) & kLocalMask);
         const bool hasB = (q & (1u << 10)) != 0;
@@ -199,43 +212,47 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : 4) void tri3_energy_pair_
             (f2){Nn.z, Nn.z}, (f2){Nn.w, Nn.w}, (f2){Nb.z, Nc.z}, (f2){Nb.w, Nc.w}, (f2){Nc.z, Nd.z}, (f2){Nc.w, Nd.w},
             k, gxx, gxy, gux, guy);
         const float mB = hasB ? 1.0f : 0.0f;                   // B's half is finite either way: a multiply masks it
-        if (count_energy) {
+        const float nx = __builtin_fmaf(mB, gxx[0].y, gxx[0].x), ny = __builtin_fmaf(mB, gxy[0].y, gxy[0].x);     // n: A + B
+        const float nu = __builtin_fmaf(mB, gux[0].y, gux[0].x), nv = __builtin_fmaf(mB, guy[0].y, guy[0].x);
+        const float cx = __builtin_fmaf(mB, gxx[1].y, gxx[2].x), cy = __builtin_fmaf(mB, gxy[1].y, gxy[2].x);     // c: A + B
+        const float cu = __builtin_fmaf(mB, gux[1].y, gux[2].x), cv = __builtin_fmaf(mB, guy[1].y, guy[2].x);
+        if (first) {
             if (p & kHomeBit) e_loc += (double)e.x;
             if (q & (1u << 11)) e_loc += (double)e.y;
+            bad = bad || !(fabsf(e.x) <= 3.0e38f) || (hasB && !(fabsf(e.y) <= 3.0e38f));       // a degenerate element: non-finite energy
+            see(gxx[1].x, gxy[1].x, gux[1].x, guy[1].x);
+            see(mB * gxx[2].y, mB * gxy[2].y, mB * gux[2].y, mB * guy[2].y);
+            see(nx, ny, nu, nv);
+            see(cx, cy, cu, cv);
         }
-        o[0] = gxx[1].x; o[1] = gxy[1].x; o[2] = gux[1].x; o[3] = guy[1].x;                                   // b
-        o[4] = mB * gxx[2].y; o[5] = mB * gxy[2].y; o[6] = mB * gux[2].y; o[7] = mB * guy[2].y;               // d
-        o[8] = __builtin_fmaf(mB, gxx[0].y, gxx[0].x); o[9] = __builtin_fmaf(mB, gxy[0].y, gxy[0].x);         // n (A + B)
-        o[10] = __builtin_fmaf(mB, gux[0].y, gux[0].x); o[11] = __builtin_fmaf(mB, guy[0].y, guy[0].x);
-        o[12] = __builtin_fmaf(mB, gxx[1].y, gxx[2].x); o[13] = __builtin_fmaf(mB, gxy[1].y, gxy[2].x);       // c (A + B)
-        o[14] = __builtin_fmaf(mB, gux[1].y, gux[2].x); o[15] = __builtin_fmaf(mB, guy[1].y, guy[2].x);
+        if (lb < n_owned) add_row(lb, gxx[1].x, gxy[1].x, gux[1].x, guy[1].x);
+        if (hasB && ld < n_owned) add_row(ld, gxx[2].y, gxy[2].y, gux[2].y, guy[2].y);
+        if (ln < n_owned) add_row(ln, nx, ny, nu, nv);
+        if (lc < n_owned) add_row(lc, cx, cy, cu, cv);
     };
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const uint32_t p = w0[j], q = w1[j];
-        if (!(p & kSkipBit)) {
-            float (&o)[16] = r[KEEP ? j : 0];
-            eval_slot(p, q, o, true);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) see(o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]);
+    auto do_edge = [&](bool first) {                     // boundary tiles only: at most one edge per thread (host-checked), fp64 helper
+        if (tid < n_edge) {
+            const int l0 = (int)(edge_rec & kLocalMask), l1 = (int)((edge_rec >> kLocalBits) & kLocalMask);
+            const double4 tt = T_edge ? T_edge[edge_id] : Tconst;
+            const float4 N0 = nd[l0], N1 = nd[l1];
+            double2 gx[2], gu[2];
+            const double wk = edge2_element<true>(make_double2(N0.x, N0.y), make_double2(N1.x, N1.y), make_double2(N0.z, N0.w),
+                                                  make_double2(N1.z, N1.w), tt, gx, gu);
+            if (first) {
+                if (edge_rec & kHomeBit) e_loc -= wk;
+                see((float)gx[0].x, (float)gx[0].y, (float)gu[0].x, (float)gu[0].y);
+                see((float)gx[1].x, (float)gx[1].y, (float)gu[1].x, (float)gu[1].y);
+            }
+            if (l0 < n_owned) add_row(l0, (float)gx[0].x, (float)gx[0].y, (float)gu[0].x, (float)gu[0].y);
+            if (l1 < n_owned) add_row(l1, (float)gx[1].x, (float)gx[1].y, (float)gu[1].x, (float)gu[1].y);
         }
-    }
-    uint32_t edge_p = kSkipBit;
-    if (tid < n_edge) {                                  // boundary tiles only: at most one edge per thread (host-checked), fp64 helper
-        edge_p = edge_rec;
-        const int l0 = (int)(edge_p & kLocalMask), l1 = (int)((edge_p >> kLocalBits) & kLocalMask);
-        const double4 tt = T_edge ? T_edge[edge_id] : Tconst;
-        const float4 N0 = nd[l0], N1 = nd[l1];
-        double2 gx[2], gu[2];
-        const double wk = edge2_element<true>(make_double2(N0.x, N0.y), make_double2(N1.x, N1.y), make_double2(N0.z, N0.w),
-                                              make_double2(N1.z, N1.w), tt, gx, gu);
-        if (edge_p & kHomeBit) e_loc -= wk;
-        er[0] = (float)gx[0].x; er[1] = (float)gx[0].y; er[2] = (float)gu[0].x; er[3] = (float)gu[0].y;
-        er[4] = (float)gx[1].x; er[5] = (float)gx[1].y; er[6] = (float)gu[1].x; er[7] = (float)gu[1].y;
-        see(er[0], er[1], er[2], er[3]);
-        see(er[4], er[5], er[6], er[7]);
-    }
-    // ---- the tile's two maxima -> one power-of-two scale per row kind
+    };
+    // ---- the slot loop, ONCE, with the lagged scale
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (!(w0[j] & kSkipBit)) do_slot(w0[j], w1[j], true);
+    do_edge(true);
+    // ---- this evaluation's maxima; was the bound large enough?
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -247,38 +264,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : 4) void tri3_energy_pair_
     float Mx = 0.0f, Mu = 0.0f;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w) { Mx = fmaxf(Mx, mred[w]); Mu = fmaxf(Mu, mred[BLOCK / 64 + w]); }
-    int ex, eu;
-    (void)frexpf(Mx, &ex);                               // Mx < 2^ex
-    (void)frexpf(Mu, &eu);
-    const int kx = min(96, 30 - vbits - ex), ku = min(96, 30 - vbits - eu);     // valence x max x 2^k < 2^30
-    const float sx = ldexpf(1.0f, kx), su = ldexpf(1.0f, ku);
-    // ---- pass 2: fixed point, two values per 64-bit atomic: word = (int64)hi * 2^32 + (int64)lo -- adding words adds both halves
-    auto add_row = [&](int l, float gx, float gy, float gu, float gv) {
-        const int qx = __float2int_rn(gx * sx), qy = __float2int_rn(gy * sx), qu = __float2int_rn(gu * su), qv = __float2int_rn(gv * su);
-        atomicAdd(&accX[l], ((unsigned long long)(uint32_t)(qy + (qx >> 31)) << 32) | (uint32_t)qx);
-        atomicAdd(&accU[l], ((unsigned long long)(uint32_t)(qv + (qu >> 31)) << 32) | (uint32_t)qu);
-    };
+    int exn, eun;
+    (void)frexpf(Mx, &exn);                              // Mx < 2^exn
+    (void)frexpf(Mu, &eun);
+    if (exn + kx + vbits > 30 || eun + ku + vbits > 30) {        // uniform over the tile: its accumulators may have wrapped -> redo
+        for (int l = tid; l < n_owned; l += BLOCK) { accX[l] = 0ull; accU[l] = 0ull; }
+        kx = min(96, 30 - vbits - exn); ku = min(96, 30 - vbits - eun);
+        sx = ldexpf(1.0f, kx); su = ldexpf(1.0f, ku);
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const uint32_t p = w0[j], q = w1[j];
-        if (!(p & kSkipBit)) {
-            const int ln = (int)(p & kLocalMask), lb = (int)((p >> kLocalBits) & kLocalMask),
-                      lc = (int)((p >> (2 * kLocalBits)) & kLocalMask);
-            const bool hasB = (q & (1u << 10)) != 0;
-            const int ld = (int)(q & kLocalMask);
-            float (&o)[16] = r[KEEP ? j : 0];
-            if constexpr (!KEEP) eval_slot(p, q, o, false);
-            if (lb < n_owned) add_row(lb, o[0], o[1], o[2], o[3]);
-            if (hasB && ld < n_owned) add_row(ld, o[4], o[5], o[6], o[7]);
-            if (ln < n_owned) add_row(ln, o[8], o[9], o[10], o[11]);
-            if (lc < n_owned) add_row(lc, o[12], o[13], o[14], o[15]);
-        }
+        for (int j = 0; j < EPT; ++j)
+            if (!(w0[j] & kSkipBit)) do_slot(w0[j], w1[j], false);
+        do_edge(false);
     }
-    if (!(edge_p & kSkipBit)) {
-        const int l0 = (int)(edge_p & kLocalMask), l1 = (int)((edge_p >> kLocalBits) & kLocalMask);
-        if (l0 < n_owned) add_row(l0, er[0], er[1], er[2], er[3]);
-        if (l1 < n_owned) add_row(l1, er[4], er[5], er[6], er[7]);
-    }
+    if (tid == 0) tile_scale[tile_begin + slot] = make_float2(Mx, Mu);      // the next evaluation's bound
     {
         const double w = wave_sum(e_loc);
         if ((tid & 63) == 0) red[tid >> 6] = w;
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : 4) void tri3_energy_pair_
     __syncthreads();
 
     // ---- every owned gradient row is written exactly once: unpack (lo signed, hi + the borrow it took), back to float
-    const bool poison = *bad_tile != 0;
+    const bool poison = *bad_tile != 0 || !(Mx <= 3.0e38f) || !(Mu <= 3.0e38f);
     const float isx = ldexpf(1.0f, -kx), isu = ldexpf(1.0f, -ku), qnan = __builtin_nanf("");
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
@@ -325,7 +324,8 @@ static void launch_pair_f32_inst(const PairLaunch &A, const Tri3ConstsF &kf, con
     hipLaunchKernelGGL((tri3_energy_pair_f32_kernel<BLK, NPT, EPT, CAPO, CAPN, SP, HASB>), dim3(A.grid), dim3(BLK), lds, A.s, A.pd,
                        A.tile_begin, (const float2 *)A.x_free, (const float2 *)A.x_fixed, (const float2 *)A.u_free,
                        (const float2 *)A.u_fixed, kf, A.T_edge, A.tc, A.partials, (float2 *)A.gx, (float2 *)A.gu, cap_n, cap_o,
-                       A.skip_edges, lag, A.col_stride, A.lab_bits /* = valence bits of the plan (launch_tri3_pair_f32) */);
+                       A.skip_edges, lag, A.col_stride, A.lab_bits /* = valence bits of the plan (launch_tri3_pair_f32) */,
+                       reinterpret_cast<float2 *>(const_cast<unsigned long long *>(A.span)) /* = the plan's per-tile maxima */);
 }
 
 // Launch on a paired plan without chained records; 1 = launched, 0 = no instance holds the plan's tile shape.
@@ -335,8 +335,9 @@ int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const L
     // the fixed-point accumulation needs a bound on the contributions a row can receive (valence: element corners + edge
     // ends of a node, from the plan's copy of the mesh; <= 64 keeps >= 24 bits below the largest contribution) and at most one
     // Neumann edge per thread
-    if (plan->f32_vbits < 0 || plan->f32_vbits > 6 || h.max_edges > (h.pair_block == 512 ? 512 : 256)) return 0;
+    if (plan->f32_vbits < 0 || plan->f32_vbits > 6 || !plan->d_f32_scale || h.max_edges > (h.pair_block == 512 ? 512 : 256)) return 0;
     A.lab_bits = plan->f32_vbits;
+    A.span = reinterpret_cast<unsigned long long *>(plan->d_f32_scale);      // PairLaunch fields this launcher borrows (no span stamps here)
     A.pd = plan_dev(plan);
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned;
     A.col_stride = h.col_stride;

@@ -303,8 +303,6 @@ struct hfem_plan {
     double *put_bc[2] = {nullptr, nullptr};       // ... and the two bias-correction buffers its steps alternate between
     const int32_t *put_pos[2] = {nullptr, nullptr};   // ... and the row -> payload position tables (by value into the launch)
     int peer_wait_begin = 0, peer_wait_end = 0;   // the tiles that wait for it (the rank's boundary tiles)
-    float2 *d_f32_scale = nullptr;   // fp32 kernel: every tile's largest |contribution| {coordinate rows, displacement rows} at its last evaluation
-    int f32_vbits = -1;           // ceil(log2(max contributions a node row receives)) -- the fp32 kernel's fixed-point headroom; -1: not computed yet
     int32_t lds_bytes = 0;        // tiled kernel: nodes + accumulators + reduction scratch
     int32_t lds_bytes_pipe = 0;   // pipelined kernel: + descriptor cache + element records
 };

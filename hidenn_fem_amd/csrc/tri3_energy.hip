@@ -660,7 +660,6 @@ extern "C" int hfem_plan_destroy(hfem_plan *plan) {
         (void)hipFree(plan->d_tile_chunks);
         free_tri3_det(plan);
         (void)hipFree(plan->d_partials);
-        (void)hipFree(plan->d_f32_scale);
         (void)hipFree(plan->d_stamps);
     }
     delete plan;
@@ -1037,7 +1036,6 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
     HFEM_ARG_CHECK(h.ned == 0 || T_edge || Tconst, "plan has Neumann edges: need a traction table");
     bool hasb = false;
     for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
-    bool f32_done = !f32math;
     if (f32math) {
         // fp32 ARITHMETIC (tri3_pair_f32.hip): paired-slot plans without chained records; body force, tile ranges, the lagged
         // loss sum and the partials banks as hfem_tri3_energy_plan; no in-launch get
@@ -1045,26 +1043,6 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
         HFEM_ARG_CHECK(!(flags & HFEM_FLAG_PEER_GET), "HFEM_FLAG_FP32_MATH: no in-launch get (the sharded steps run the fp64-arithmetic float-row instances)");
         if (int rc = use_device(plan->device)) return rc;
         PlanLock lock(plan);
-        if (plan->f32_vbits < 0) {                          // once per plan: the valence bound of the fixed-point accumulators
-            std::vector<int32_t> cnt((size_t)h.nn, 0);
-            for (int32_t v : h.conn32) ++cnt[(size_t)v];
-            for (int32_t v : h.edges32) ++cnt[(size_t)v];
-            int32_t vmax = 1;
-            for (int32_t c : cnt) vmax = std::max(vmax, c);
-            int b = 0;
-            while ((1 << b) < vmax) ++b;
-            plan->f32_vbits = b;
-        }
-        if (!plan->d_f32_scale) {                           // ... and the per-tile maxima its lagged scale comes from (0 = none yet)
-            hipError_t e_ = hipMalloc((void **)&plan->d_f32_scale, sizeof(float2) * std::max<size_t>(1, h.tiles.size()));
-            if (e_ == hipSuccess) e_ = hipMemset(plan->d_f32_scale, 0, sizeof(float2) * std::max<size_t>(1, h.tiles.size()));
-            if (e_ != hipSuccess) {
-                plan->d_f32_scale = nullptr;
-                (void)hipGetLastError();
-                set_error("hfem_tri3_energy_plan_f32: the first fp32-arithmetic launch on a plan allocates its scale array and cannot be captured into a hipGraph: run one eager evaluation first");
-                return -1;
-            }
-        }
         const int n = tile_end - tile_begin;
         const bool lag_consume = (flags & HFEM_FLAG_SUM_PREVIOUS) != 0, same_bank = (flags & HFEM_FLAG_SAME_BANK) != 0;
         HFEM_ARG_CHECK(!lag_consume || (flags & HFEM_FLAG_NO_LOSS_SUM), "HFEM_FLAG_SUM_PREVIOUS needs HFEM_FLAG_NO_LOSS_SUM");
@@ -1088,18 +1066,9 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
             P.partials = pb + tile_begin;
             P.gx = (flags & HFEM_FLAG_NO_GX) ? nullptr : gx_free; P.gu = (flags & HFEM_FLAG_NO_GU) ? nullptr : gu_free;
             P.skip_edges = (flags & HFEM_FLAG_NO_EDGES) ? 1 : 0; P.s = (hipStream_t)stream;
-            const int launched = launch_tri3_pair_f32(plan, P, hasb, lag);
-            // no instance (a tile shape outside the instances, a node of valence > 64, more Neumann edges in a tile than threads):
-            // the fp64-arithmetic float-row instance below takes the launch where it can (zero body force, no lagged sum)
-            HFEM_ARG_CHECK(launched == 1 || (!hasb && !lag_consume && !same_bank), "HFEM_FLAG_FP32_MATH: no fp32 instance for this plan, and the fp64-arithmetic float-row path has no body force / lagged loss sum");
-            if (launched == 1) {
-                f32_done = true;
-                if (int rc = launch_status("hfem_tri3_energy_plan_f32(fp32 arithmetic)")) return rc;
-            }
-        } else {
-            f32_done = true;
+            HFEM_ARG_CHECK(launch_tri3_pair_f32(plan, P, hasb, lag) == 1, "HFEM_FLAG_FP32_MATH: tile shape outside the fp32 pair kernel's instances");
+            if (int rc = launch_status("hfem_tri3_energy_plan_f32(fp32 arithmetic)")) return rc;
         }
-        if (f32_done) {
         if (flags & HFEM_FLAG_NO_LOSS_SUM) {              // the partials-bank bookkeeping of hfem_tri3_energy_plan
             if (same_bank && plan->prev_n > 0 && n > 0 && (tile_end == plan->prev_begin || tile_begin == plan->prev_begin + plan->prev_n)) {
                 plan->prev_begin = std::min(plan->prev_begin, (int)tile_begin);
@@ -1112,7 +1081,6 @@ extern "C" int hfem_tri3_energy_plan_f32(hfem_plan *plan, const float *x_free, c
         }
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pb + tile_begin, n, loss_out);
         return launch_status("hfem_tri3_energy_plan_f32(sum)");
-        }
     }
     HFEM_ARG_CHECK(!hasb && h.max_nodes <= 2 * 512 && h.max_elems <= 4 * 512,
                    "fp32-storage path: needs a zero body force and tiles of <= 1024 nodes / 2048 slots");

@@ -7,21 +7,20 @@
 //     two), the node image is half the bytes;
 //   * the two elements of a slot, A = (n, b, c) and B = (n, c, d), are evaluated SIDE BY SIDE in the two halves of packed fp32
 //     registers (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): a pair costs the vector instructions of one element;
-//   * gradient rows are accumulated in 32-bit FIXED POINT, two values per ds_add_u64: gfx950 services ds_add_f32 lane by lane
-//     (194 cycles per wave-instruction; the first version of this kernel, with float accumulators, took 46.9 us on T1M), where
-//     ds_add_f64 takes 8.6 and ds_add_u64 6.5 (scripts/micro/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench.txt): a
-//     pair issues 8 ds_add_u64 instead of 16 ds_add_f64.  Every contribution is scaled by a power of two 2^k, rounded to int32,
-//     and (gx, gy) / (gu, gv) are packed into one 64-bit word each (hi + borrow : lo, so that adding words adds both halves);
-//     k is chosen so that valence x largest |contribution| x 2^k < 2^30 (the valence bound comes from the plan).  The largest
-//     contribution of a tile is not known before the slots are evaluated, and evaluating first / adding afterwards puts
-//     all waves of a CU into the same phase (measured: 9.3 us, slower than the double accumulators' 7.3) -- so the scale is
-//     LAGGED: every tile remembers the maxima of its previous evaluation (plan-owned array), the slot loop runs ONCE with
-//     4 x that as its bound while it tracks this evaluation's maxima, and only a tile whose bound turns out too small (the
-//     first evaluation of a plan; gradients that grew more than 4 x from one evaluation to the next) clears its accumulators
-//     and redoes its slots with the exact scale.  Resolution: 2^-28 / valence of the largest contribution -- the size of fp32
-//     accumulation's own rounding (the reference sums in fp32).  A non-finite element energy (degenerate element) poisons
-//     the tile's owned rows with NaN: NaN / Inf propagate, coarser than element by element.
-//     The tile energy is accumulated in fp64 (one v_cvt + one v_add_f64 per slot): never worse than the reference's fp32 sum.
+//   * gradient accumulators stay four DOUBLE arrays in LDS (ds_add_f64): gfx950 services ds_add_f32 lane by lane -- the
+//     first version of this kernel, with float accumulators, took 46.9 us on T1M against 9.1 us for the fp64-arithmetic
+//     float-row instance (profiles/r04: fp32_first_try.json) --, while ds_add_f64 goes 16 lanes per LDS cycle; each
+//     contribution is widened (v_cvt_f64_f32) on the way in, rows are rounded ONCE on the way out, as float2.
+//     Measured per wave-instruction per CU (scripts/micro/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench.txt): ds_add_f64
+//     8.6 cycles, ds_add_u64 6.5, ds_add_u32 4.5, ds_add_f32 194.  Two fixed-point variants built on that (32-bit fixed
+//     point, two values per ds_add_u64: 8 atomics per pair instead of 16) were correct and SLOWER than this kernel's 7.3 us:
+//     evaluate-all-slots-first / scale by the tile's maximum / add afterwards 9.3 us (every wave of a CU in the same phase),
+//     one pass with a lagged per-tile scale 8.6-8.8 us (the scale / convert / pack / track-the-maximum instructions double the
+//     slot loop's vector work, which then binds) -- DESIGN.md 10.2.
+// The tile energy is accumulated in fp64 too (one v_cvt + one v_add_f64 per slot): loss and gradient SUMS are better than the
+// reference's fp32 sums, never worse.  Accuracy contract (tests/test_gpu_tri3_f32.py): within the band the reference's own fp32 run occupies
+// around exact arithmetic on the same float inputs (gradients <= 4e-6 x max|g|); the fp64-arithmetic float-row instances of
+// tri3_pair.hip stay available as the accurate option (hfem_tri3_energy_plan_f32 without HFEM_FLAG_FP32_MATH).
 // HBM-bound by construction, no MFMA (2x2 / 2x3 contractions).  Algorithmic bytes per launch: 12 Ne + 32 Nn + 8.
 #include <hip/hip_runtime.h>
 
@@ -105,23 +104,21 @@ __device__ __forceinline__ f2 tri3_pair_f32(const f2 X0x, const f2 X0y, const f2
 
 // BLOCK threads per tile; NPT >= ceil(max nodes / BLOCK), EPT >= ceil(max slots / BLOCK); CAPO / CAPN > 0: compile-time LDS
 // strides of the default tile shape.  SP: cache policy of the gradient stores (16 sc1 write-through, 2 nt).  LDS:
-// float4 nd[cap_n] | u64 acc[2][cap_owned] | double red[BLOCK / 64] | float mred[2][BLOCK / 64] | int bad.
+// float4 nd[cap_n] | double acc[4][cap_owned] | double red[BLOCK / 64].
 template <int BLOCK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
 __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_f32_kernel(
     PlanDev pd, int tile_begin, const float2 *__restrict__ x_free, const float2 *__restrict__ x_fixed,
     const float2 *__restrict__ u_free, const float2 *__restrict__ u_fixed, Tri3ConstsF k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     float2 *__restrict__ gx_free, float2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    LagSum lag, int col_stride, int vbits, float2 *__restrict__ tile_scale) {
+    LagSum lag, int col_stride) {
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     const int cap_n = CAPN > 0 ? CAPN : cap_nodes;
     extern __shared__ float4 lds4[];
     float4 *nd = lds4;
-    unsigned long long *accX = reinterpret_cast<unsigned long long *>(lds4 + cap_n);
-    unsigned long long *accU = accX + cap_owned;
-    double *red = reinterpret_cast<double *>(accU + cap_owned);
-    float *mred = reinterpret_cast<float *>(red + BLOCK / 64);
-    int *bad_tile = reinterpret_cast<int *>(mred + 2 * (BLOCK / 64));
+    double *acc0 = reinterpret_cast<double *>(lds4 + cap_n);
+    double *acc1 = acc0 + cap_owned, *acc2 = acc1 + cap_owned, *acc3 = acc2 + cap_owned;
+    double *red = acc3 + cap_owned;
 
     const int tid = threadIdx.x;
     const int bid = (int)blockIdx.x;
@@ -141,7 +138,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
 #pragma unroll
     for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];
     const TileDesc d = pd.tiles[tile_begin + slot];
-    const float2 prev_max = tile_scale[tile_begin + slot];      // this tile's maxima at its previous evaluation (0: none yet)
     uint32_t w0[EPT], w1[EPT];
     const size_t rec0 = (size_t)(tile_begin + slot) * pd.elem_stride;
 #pragma unroll
@@ -175,109 +171,54 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
         if (l < d.n_node) nd[l] = make_float4(vx[j].x, vx[j].y, vu[j].x, vu[j].y);
-        if (l < n_owned) { accX[l] = 0ull; accU[l] = 0ull; }
+        if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
-    if (tid == 0) *bad_tile = 0;
     __syncthreads();
 
-    // ---- scale of this evaluation: 4 x the previous evaluation's maxima as the bound (valence x bound x 2^k < 2^30)
-    int ex, eu;
-    (void)frexpf(4.0f * prev_max.x, &ex);
-    (void)frexpf(4.0f * prev_max.y, &eu);
-    int kx = min(96, 30 - vbits - ex), ku = min(96, 30 - vbits - eu);
-    float sx = ldexpf(1.0f, kx), su = ldexpf(1.0f, ku);
-    float mx = 0.0f, mu = 0.0f;                          // this evaluation's largest |coordinate-row value|, |displacement-row value|
-    bool bad = false;
-    double e_loc = 0.0;
-    // fixed point, two values per 64-bit atomic: word = (int64)hi * 2^32 + (int64)lo -- adding words adds both halves
     auto add_row = [&](int l, float gx, float gy, float gu, float gv) {
-        const int qx = __float2int_rn(gx * sx), qy = __float2int_rn(gy * sx), qu = __float2int_rn(gu * su), qv = __float2int_rn(gv * su);
-        atomicAdd(&accX[l], ((unsigned long long)(uint32_t)(qy + (qx >> 31)) << 32) | (uint32_t)qx);
-        atomicAdd(&accU[l], ((unsigned long long)(uint32_t)(qv + (qu >> 31)) << 32) | (uint32_t)qu);
+        unsafeAtomicAdd(&acc0[l], (double)gx); unsafeAtomicAdd(&acc1[l], (double)gy);
+        unsafeAtomicAdd(&acc2[l], (double)gu); unsafeAtomicAdd(&acc3[l], (double)gv);
     };
-    auto see = [&](float a, float b, float c, float d) {
-        mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
-        mu = fmaxf(mu, fmaxf(fabsf(c), fabsf(d)));
-    };
-    // one slot: evaluate the pair, add its four rows {b, d, n, c}; first: also count the energy and track the maxima
-    auto do_slot = [&](uint32_t p, uint32_t q, bool first) {
-        const int ln = (int)(p & kLocalMask), lb = (int)((p >> kLocalBits) & kLocalMask),
-                  lc = (int)((p >> (2 * kLocalBits)) & kLocalMask);
-        const bool hasB = (q & (1u << 10)) != 0;
-        const int ld = hasB ? (int)(q & kLocalMask) : lb;      // no partner: the B half re-evaluates (n, c, b) -- finite, unused
-        const float4 Nn = nd[ln], Nb = nd[lb], Nc = nd[lc], Nd = nd[ld];
-        f2 gxx[3], gxy[3], gux[3], guy[3];
-        const f2 e = tri3_pair_f32<HASB>(
-            (f2){Nn.x, Nn.x}, (f2){Nn.y, Nn.y}, (f2){Nb.x, Nc.x}, (f2){Nb.y, Nc.y}, (f2){Nc.x, Nd.x}, (f2){Nc.y, Nd.y},
-            (f2){Nn.z, Nn.z}, (f2){Nn.w, Nn.w}, (f2){Nb.z, Nc.z}, (f2){Nb.w, Nc.w}, (f2){Nc.z, Nd.z}, (f2){Nc.w, Nd.w},
-            k, gxx, gxy, gux, guy);
-        const float mB = hasB ? 1.0f : 0.0f;                   // B's half is finite either way: a multiply masks it
-        const float nx = __builtin_fmaf(mB, gxx[0].y, gxx[0].x), ny = __builtin_fmaf(mB, gxy[0].y, gxy[0].x);     // n: A + B
-        const float nu = __builtin_fmaf(mB, gux[0].y, gux[0].x), nv = __builtin_fmaf(mB, guy[0].y, guy[0].x);
-        const float cx = __builtin_fmaf(mB, gxx[1].y, gxx[2].x), cy = __builtin_fmaf(mB, gxy[1].y, gxy[2].x);     // c: A + B
-        const float cu = __builtin_fmaf(mB, gux[1].y, gux[2].x), cv = __builtin_fmaf(mB, guy[1].y, guy[2].x);
-        if (first) {
+    double e_loc = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t p = w0[j], q = w1[j];
+        if (!(p & kSkipBit)) {
+            const int ln = (int)(p & kLocalMask), lb = (int)((p >> kLocalBits) & kLocalMask),
+                      lc = (int)((p >> (2 * kLocalBits)) & kLocalMask);
+            const bool hasB = (q & (1u << 10)) != 0;
+            const int ld = hasB ? (int)(q & kLocalMask) : lb;      // no partner: the B half re-evaluates (n, c, b) -- finite, unused
+            const float4 Nn = nd[ln], Nb = nd[lb], Nc = nd[lc], Nd = nd[ld];
+            f2 gxx[3], gxy[3], gux[3], guy[3];
+            const f2 e = tri3_pair_f32<HASB>(
+                (f2){Nn.x, Nn.x}, (f2){Nn.y, Nn.y}, (f2){Nb.x, Nc.x}, (f2){Nb.y, Nc.y}, (f2){Nc.x, Nd.x}, (f2){Nc.y, Nd.y},
+                (f2){Nn.z, Nn.z}, (f2){Nn.w, Nn.w}, (f2){Nb.z, Nc.z}, (f2){Nb.w, Nc.w}, (f2){Nc.z, Nd.z}, (f2){Nc.w, Nd.w},
+                k, gxx, gxy, gux, guy);
+            const float mB = hasB ? 1.0f : 0.0f;                   // B's half is finite either way: a multiply masks it
             if (p & kHomeBit) e_loc += (double)e.x;
             if (q & (1u << 11)) e_loc += (double)e.y;
-            bad = bad || !(fabsf(e.x) <= 3.0e38f) || (hasB && !(fabsf(e.y) <= 3.0e38f));       // a degenerate element: non-finite energy
-            see(gxx[1].x, gxy[1].x, gux[1].x, guy[1].x);
-            see(mB * gxx[2].y, mB * gxy[2].y, mB * gux[2].y, mB * guy[2].y);
-            see(nx, ny, nu, nv);
-            see(cx, cy, cu, cv);
+            if (lb < n_owned) add_row(lb, gxx[1].x, gxy[1].x, gux[1].x, guy[1].x);
+            if (hasB && ld < n_owned) add_row(ld, gxx[2].y, gxy[2].y, gux[2].y, guy[2].y);
+            if (ln < n_owned)
+                add_row(ln, __builtin_fmaf(mB, gxx[0].y, gxx[0].x), __builtin_fmaf(mB, gxy[0].y, gxy[0].x),
+                        __builtin_fmaf(mB, gux[0].y, gux[0].x), __builtin_fmaf(mB, guy[0].y, guy[0].x));
+            if (lc < n_owned)
+                add_row(lc, __builtin_fmaf(mB, gxx[1].y, gxx[2].x), __builtin_fmaf(mB, gxy[1].y, gxy[2].x),
+                        __builtin_fmaf(mB, gux[1].y, gux[2].x), __builtin_fmaf(mB, guy[1].y, guy[2].x));
         }
-        if (lb < n_owned) add_row(lb, gxx[1].x, gxy[1].x, gux[1].x, guy[1].x);
-        if (hasB && ld < n_owned) add_row(ld, gxx[2].y, gxy[2].y, gux[2].y, guy[2].y);
-        if (ln < n_owned) add_row(ln, nx, ny, nu, nv);
-        if (lc < n_owned) add_row(lc, cx, cy, cu, cv);
-    };
-    auto do_edge = [&](bool first) {                     // boundary tiles only: at most one edge per thread (host-checked), fp64 helper
-        if (tid < n_edge) {
-            const int l0 = (int)(edge_rec & kLocalMask), l1 = (int)((edge_rec >> kLocalBits) & kLocalMask);
-            const double4 tt = T_edge ? T_edge[edge_id] : Tconst;
-            const float4 N0 = nd[l0], N1 = nd[l1];
-            double2 gx[2], gu[2];
-            const double wk = edge2_element<true>(make_double2(N0.x, N0.y), make_double2(N1.x, N1.y), make_double2(N0.z, N0.w),
-                                                  make_double2(N1.z, N1.w), tt, gx, gu);
-            if (first) {
-                if (edge_rec & kHomeBit) e_loc -= wk;
-                see((float)gx[0].x, (float)gx[0].y, (float)gu[0].x, (float)gu[0].y);
-                see((float)gx[1].x, (float)gx[1].y, (float)gu[1].x, (float)gu[1].y);
-            }
-            if (l0 < n_owned) add_row(l0, (float)gx[0].x, (float)gx[0].y, (float)gu[0].x, (float)gu[0].y);
-            if (l1 < n_owned) add_row(l1, (float)gx[1].x, (float)gx[1].y, (float)gu[1].x, (float)gu[1].y);
-        }
-    };
-    // ---- the slot loop, ONCE, with the lagged scale
-#pragma unroll
-    for (int j = 0; j < EPT; ++j)
-        if (!(w0[j] & kSkipBit)) do_slot(w0[j], w1[j], true);
-    do_edge(true);
-    // ---- this evaluation's maxima; was the bound large enough?
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        mu = fmaxf(mu, __shfl_xor(mu, off, 64));
     }
-    if ((tid & 63) == 0) { mred[tid >> 6] = mx; mred[BLOCK / 64 + (tid >> 6)] = mu; }
-    if (bad) *bad_tile = 1;
-    __syncthreads();
-    float Mx = 0.0f, Mu = 0.0f;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) { Mx = fmaxf(Mx, mred[w]); Mu = fmaxf(Mu, mred[BLOCK / 64 + w]); }
-    int exn, eun;
-    (void)frexpf(Mx, &exn);                              // Mx < 2^exn
-    (void)frexpf(Mu, &eun);
-    if (exn + kx + vbits > 30 || eun + ku + vbits > 30) {        // uniform over the tile: its accumulators may have wrapped -> redo
-        for (int l = tid; l < n_owned; l += BLOCK) { accX[l] = 0ull; accU[l] = 0ull; }
-        kx = min(96, 30 - vbits - exn); ku = min(96, 30 - vbits - eun);
-        sx = ldexpf(1.0f, kx); su = ldexpf(1.0f, ku);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < EPT; ++j)
-            if (!(w0[j] & kSkipBit)) do_slot(w0[j], w1[j], false);
-        do_edge(false);
+    for (int i = tid; i < n_edge; i += BLOCK) {          // boundary tiles only: a handful of edges, fp64 helper on the float image
+        const uint32_t p = i == tid ? edge_rec : pd.edge_pack[d.edge_off + i];
+        const int l0 = (int)(p & kLocalMask), l1 = (int)((p >> kLocalBits) & kLocalMask);
+        const double4 tt = T_edge ? T_edge[i == tid ? edge_id : pd.edge_gid[d.edge_off + i]] : Tconst;
+        const float4 N0 = nd[l0], N1 = nd[l1];
+        double2 gx[2], gu[2];
+        const double wk = edge2_element<true>(make_double2(N0.x, N0.y), make_double2(N1.x, N1.y), make_double2(N0.z, N0.w),
+                                              make_double2(N1.z, N1.w), tt, gx, gu);
+        if (p & kHomeBit) e_loc -= wk;
+        if (l0 < n_owned) add_row(l0, (float)gx[0].x, (float)gx[0].y, (float)gu[0].x, (float)gu[0].y);
+        if (l1 < n_owned) add_row(l1, (float)gx[1].x, (float)gx[1].y, (float)gu[1].x, (float)gu[1].y);
     }
-    if (tid == 0) tile_scale[tile_begin + slot] = make_float2(Mx, Mu);      // the next evaluation's bound
     {
         const double w = wave_sum(e_loc);
         if ((tid & 63) == 0) red[tid >> 6] = w;
@@ -285,9 +226,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // all loads returned long ago: no per-store vmcnt waits below
     __syncthreads();
 
-    // ---- every owned gradient row is written exactly once: unpack (lo signed, hi + the borrow it took), back to float
-    const bool poison = *bad_tile != 0 || !(Mx <= 3.0e38f) || !(Mu <= 3.0e38f);
-    const float isx = ldexpf(1.0f, -kx), isu = ldexpf(1.0f, -ku), qnan = __builtin_nanf("");
+    // ---- every owned gradient row is written exactly once
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
     __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)gu_free, 0, 0x7FFFFFF0, 0x00020000);
@@ -296,15 +235,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
         const int l = tid + j * BLOCK;
         if (l < n_owned) {
             if (gx_free && s[j].x >= 0) {
-                const unsigned long long t = accX[l];
-                const int lo = (int)(uint32_t)t, hi = (int)((uint32_t)(t >> 32) - (uint32_t)(lo >> 31));
-                const float2 v = poison ? make_float2(qnan, qnan) : make_float2((float)lo * isx, (float)hi * isx);
+                const float2 v = make_float2((float)acc0[l], (float)acc1[l]);       // rounded once
                 __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), rx, s[j].x * 8, 0, SP);
             }
             if (gu_free && s[j].y >= 0) {
-                const unsigned long long t = accU[l];
-                const int lo = (int)(uint32_t)t, hi = (int)((uint32_t)(t >> 32) - (uint32_t)(lo >> 31));
-                const float2 v = poison ? make_float2(qnan, qnan) : make_float2((float)lo * isu, (float)hi * isu);
+                const float2 v = make_float2((float)acc2[l], (float)acc3[l]);
                 __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2 *>(&v), ru, s[j].y * 8, 0, SP);
             }
         }
@@ -320,24 +255,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
 template <int BLK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
 static void launch_pair_f32_inst(const PairLaunch &A, const Tri3ConstsF &kf, const LagSum &lag) {
     const int cap_n = CAPN > 0 ? CAPN : ((A.max_nodes + 1) & ~1), cap_o = CAPO > 0 ? CAPO : ((A.max_owned + 1) & ~1);
-    const size_t lds = (size_t)cap_n * 16 + (size_t)cap_o * 16 + 16 * (BLK / 64) + 16;
+    const size_t lds = (size_t)cap_n * 16 + (size_t)cap_o * 32 + 8 * (BLK / 64);
     hipLaunchKernelGGL((tri3_energy_pair_f32_kernel<BLK, NPT, EPT, CAPO, CAPN, SP, HASB>), dim3(A.grid), dim3(BLK), lds, A.s, A.pd,
                        A.tile_begin, (const float2 *)A.x_free, (const float2 *)A.x_fixed, (const float2 *)A.u_free,
                        (const float2 *)A.u_fixed, kf, A.T_edge, A.tc, A.partials, (float2 *)A.gx, (float2 *)A.gu, cap_n, cap_o,
-                       A.skip_edges, lag, A.col_stride, A.lab_bits /* = valence bits of the plan (launch_tri3_pair_f32) */,
-                       reinterpret_cast<float2 *>(const_cast<unsigned long long *>(A.span)) /* = the plan's per-tile maxima */);
+                       A.skip_edges, lag, A.col_stride);
 }
 
 // Launch on a paired plan without chained records; 1 = launched, 0 = no instance holds the plan's tile shape.
 int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const LagSum &lag) {
     const HostPlan &h = plan->host;
     if (!h.paired || !plan->d_elem_pack_hi || h.n_chained > 0 || lag.pg_blocks) return 0;
-    // the fixed-point accumulation needs a bound on the contributions a row can receive (valence: element corners + edge
-    // ends of a node, from the plan's copy of the mesh; <= 64 keeps >= 24 bits below the largest contribution) and at most one
-    // Neumann edge per thread
-    if (plan->f32_vbits < 0 || plan->f32_vbits > 6 || !plan->d_f32_scale || h.max_edges > (h.pair_block == 512 ? 512 : 256)) return 0;
-    A.lab_bits = plan->f32_vbits;
-    A.span = reinterpret_cast<unsigned long long *>(plan->d_f32_scale);      // PairLaunch fields this launcher borrows (no span stamps here)
     A.pd = plan_dev(plan);
     A.max_nodes = h.max_nodes; A.max_owned = h.max_owned;
     A.col_stride = h.col_stride;

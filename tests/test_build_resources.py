@@ -31,4 +31,4 @@ def test_no_kernel_uses_scratch_and_the_instance_matrix_is_bounded():
     graded = [v for k, v in use.items() if "tri3_energy_pair_kernelILi256ELi3ELi3ELi4ELi560ELb0ELb0E15HIP_vector_typeIdLj2EELb0ELb0ELi656ELi16ELb0E" in k]
     assert len(graded) == 1 and graded[0]["vgprs"] <= 96 and graded[0]["occupancy"] >= 4, graded
     f32 = [v for k, v in use.items() if "tri3_energy_pair_f32_kernelILi256ELi3ELi3ELi560ELi656ELi16ELb0E" in k]
-    assert len(f32) == 1 and f32[0]["vgprs"] <= 128 and f32[0]["occupancy"] >= 4, f32      # 16 row values x 3 slots kept in registers
+    assert len(f32) == 1 and f32[0]["vgprs"] <= 96, f32

@@ -289,3 +289,15 @@ def test_sharded_lbfgs_processes_follow_the_unsharded_trajectory(world):
             assert (o["n_iter"], o["evals"]) == (st["n_iter"], st["func_evals"])
             if len(o["seen_x"]):                                # finish(): the interface rows this rank reads are the owners' final values
                 assert np.abs(o["x_seen"] - x_all[o["seen_x"]]).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_example4_runs_owner_sharded_end_to_end():
+    """examples/example4.py --sharded (one process here): the reference's Example 4 loop with the sharded energy and the
+    node-sharded L-BFGS -- the same optimisation as the FusedLBFGS path of the example (an fp64 run: same closure count, losses
+    equal to the tolerance of the trajectory tests)."""
+    import examples.example4 as e4
+    torch.manual_seed(0)                                         # the sharded run seeds 0 itself (every rank must draw the same u_free)
+    _, fused = e4.run(nx=60, ny=30, steps=3, dtype=F64, log_every=1, fused_lbfgs=True)
+    _, shard = e4.run(nx=60, ny=30, steps=3, dtype=F64, log_every=1, sharded=True)
+    assert np.isfinite(shard) and abs(shard - fused) <= 1e-7 * abs(fused), (shard, fused)

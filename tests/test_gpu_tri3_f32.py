@@ -109,3 +109,74 @@ def test_example1_as_shipped_fp32_adam_trajectory(g_line):
             opt.step()
             got.append(loss.item())
         np.testing.assert_allclose(got, g_line[f"ex1_f32_r{int(r_adapt)}/adam_losses"], rtol=2e-4)
+
+
+def test_fp32_arithmetic_entry_point_ranges_lagged_sum_and_body_force():
+    """hfem_tri3_energy_plan_f32 with HFEM_FLAG_FP32_MATH through the C ABI on a 60 k-element mesh: tile ranges are additive and
+    write disjoint rows, the lagged loss sum (NO_LOSS_SUM -> SUM_PREVIOUS -> hfem_plan_loss_sum) delivers the same energies as
+    separate reductions, a body force is taken (the fp64-arithmetic float-row instance refuses one) -- all against the C closed
+    forms evaluated in fp64 on the same float values (fp32 band: loss 2e-6, gradients 4e-6 x max|g|)."""
+    import ctypes as C
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.mesh import structured_tri_mesh
+    from hidenn_fem_amd.plan import TilePlan
+    from oracle import closed_form as CF
+    d = torch.device("cuda:0")
+    coords, conn, geom, bc, mn, edges = structured_tri_mesh(201, 151, jitter=0.2, seed=5, dtype=F64)
+    rng = np.random.default_rng(5)
+    X = coords.numpy().astype(np.float32)
+    U = (1e-5 * rng.standard_normal(X.shape)).astype(np.float32)
+    mat, W = CF.plane_stress(), 0.25
+    Bk = (rng.standard_normal(6) * 1e4).astype(np.float32).astype(np.float64)
+    Tc = np.array([2e5, 0.0, 0.0, 1e4])
+    L = _lib.lib()
+    s = _lib.stream_ptr(d)
+    dv = lambda a: (C.c_double * len(a))(*a)
+    Xd, Ud = torch.from_numpy(X).to(d), torch.from_numpy(U).to(d)
+    plan = TilePlan(conn, X.shape[0], coords_hint=coords, edges=edges, device=d)
+    assert plan.stats["paired"] == 1
+
+    def launch(lo, hi, flags, bk, loss, gx, gu):
+        _lib.check(L.hfem_tri3_energy_plan_f32(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv(bk), None, dv(Tc),
+                                               lo, hi, loss.data_ptr(), gx.data_ptr(), gu.data_ptr(), flags | 1024, s), "f32 math")
+
+    for bk in (np.zeros(6), Bk):
+        e_ref, gX_ref, gU_ref = CF.tri3_energy(X.astype(np.float64), U.astype(np.float64), conn.numpy(), mat, W, bk)
+        e_ref -= CF.edge2_energy(X.astype(np.float64), U.astype(np.float64), edges.numpy(), Tconst=Tc, gX=gX_ref, gU=gU_ref)
+        loss = torch.zeros((), dtype=F64, device=d)
+        gx, gu = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+        launch(0, -1, 0, bk, loss, gx, gu)
+        assert abs(loss.item() - e_ref) <= 2e-6 * abs(e_ref)
+        assert _err(gx, gX_ref) <= 4e-6 and _err(gu, gU_ref) <= 4e-6
+        # three tile ranges: additive energies, every row written by exactly one range
+        acc, cover = 0.0, torch.zeros(X.shape[0], dtype=torch.int32, device=d)
+        gxa, gua = torch.zeros_like(Xd), torch.zeros_like(Ud)
+        for r in range(3):
+            lo, hi = plan.shard_range(r, 3)
+            l3 = torch.zeros((), dtype=F64, device=d)
+            g3x, g3u = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+            launch(lo, hi, 0, bk, l3, g3x, g3u)
+            acc += l3.item()
+            cover += (~torch.isnan(g3x[:, 0])).int()
+            gxa += torch.nan_to_num(g3x)
+            gua += torch.nan_to_num(g3u)
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+        assert abs(acc - loss.item()) <= 1e-12 * abs(acc)
+        assert torch.equal(gxa, gx) and torch.equal(gua, gu) or (_err(gxa, gx.double().cpu().numpy()) <= 2 * EPS32)
+    # lagged loss sum (zero body force): launch k delivers the energy of launch k - 1, the flush the last one
+    got = torch.zeros(3, dtype=F64, device=d)
+    launch(0, -1, 8, np.zeros(6), got[0:1], gx, gu)                   # NO_LOSS_SUM: nothing delivered
+    Ud2 = (Ud * 1.5).contiguous()
+    _lib.check(L.hfem_tri3_energy_plan_f32(plan.handle, Xd.data_ptr(), None, Ud2.data_ptr(), None, dv(mat), W, dv(np.zeros(6)), None, dv(Tc),
+                                           0, -1, got[0:1].data_ptr(), gx.data_ptr(), gu.data_ptr(), 8 | 32 | 1024, s), "lagged")
+    _lib.check(L.hfem_plan_loss_sum(plan.handle, 0, -1, got[1:2].data_ptr(), s), "flush")
+    l_a, l_b = torch.zeros((), dtype=F64, device=d), torch.zeros((), dtype=F64, device=d)
+    launch(0, -1, 0, np.zeros(6), l_a, gx, gu)
+    _lib.check(L.hfem_tri3_energy_plan_f32(plan.handle, Xd.data_ptr(), None, Ud2.data_ptr(), None, dv(mat), W, dv(np.zeros(6)), None, dv(Tc),
+                                           0, -1, l_b.data_ptr(), gx.data_ptr(), gu.data_ptr(), 1024, s), "plain")
+    assert got[0].item() == l_a.item() and got[1].item() == l_b.item(), (got.tolist(), l_a.item(), l_b.item())
+    # the fp64-arithmetic float-row instance refuses a body force (the caller widens instead); with the flag it is taken
+    with pytest.raises(RuntimeError):
+        _lib.check(L.hfem_tri3_energy_plan_f32(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv(Bk), None, dv(Tc),
+                                               0, -1, loss.data_ptr(), gx.data_ptr(), gu.data_ptr(), 0, s), "no flag")
+    plan.close()

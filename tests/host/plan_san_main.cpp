@@ -5,8 +5,10 @@
 //   int64 ne, nn, ned, npe, tile_elems, node_cap, elem_order, chunk_cap, has_maps
 //   int64 conn[ne*npe]; double xy[nn*2]; int64 edges[ned*2]; int32 x_src[nn], u_src[nn] (if has_maps)
 // Exit code 0 = plan built and self-checked; any ASan / UBSan finding aborts with a non-zero code.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../hidenn_fem_amd/csrc/hfem_common.h"
@@ -64,6 +66,53 @@ int main(int argc, char **argv) {
         }
         for (int64_t e = 0; e < ne; ++e)
             if (home[e] != 1) { fprintf(stderr, "element %lld counted %d times\n", (long long)e, home[e]); return 1; }
+        // plan blobs (hfem_plan_serialize / hfem_plan_deserialize): the round trip reproduces every array, and a damaged blob --
+        // truncated at any of 64 cut points, a flipped byte in the header / counts / payload, counts that point outside the
+        // blob (the checksum is recomputed so that the parser itself is reached) -- is rejected without touching memory it
+        // does not own (ASan / UBSan watch)
+        {
+            const double trailer[3] = {1.0, 2.0, 3.0};
+            std::vector<unsigned char> blob;
+            serialize_host_plan(P, trailer, sizeof(trailer), blob);
+            HostPlan Q;
+            double back[3] = {0, 0, 0};
+            if (deserialize_host_plan(blob.data(), blob.size(), Q, back, sizeof(back)) != 0) { fprintf(stderr, "blob round trip failed: %s\n", get_error()); return 1; }
+            if (Q.elem_pack != P.elem_pack || Q.node_src != P.node_src || Q.elem_gid != P.elem_gid || Q.shard_desc != P.shard_desc ||
+                Q.owned_gid != P.owned_gid || Q.conn32 != P.conn32 || Q.tiles.size() != P.tiles.size() || back[2] != 3.0 ||
+                Q.paired != P.paired || Q.max_nodes != P.max_nodes || Q.elem_stride != P.elem_stride) { fprintf(stderr, "blob round trip differs\n"); return 1; }
+            auto fnv = [](const unsigned char *p_, size_t n) {
+                uint64_t h = 1469598103934665603ull;
+                size_t i = 0;
+                for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p_ + i, 8); h = (h ^ w) * 1099511628211ull; }
+                for (; i < n; ++i) h = (h ^ p_[i]) * 1099511628211ull;
+                return h;
+            };
+            int rejected = 0, tried = 0;
+            for (int c = 0; c < 64; ++c) {                       // truncations
+                const size_t cut = blob.size() * (size_t)c / 64;
+                HostPlan R;
+                ++tried;
+                if (deserialize_host_plan(blob.data(), cut, R, back, sizeof(back)) != 0) ++rejected;
+            }
+            for (int c = 0; c < 96; ++c) {                       // a flipped byte; every other case with the checksum repaired
+                std::vector<unsigned char> bad = blob;
+                const size_t at = c < 48 ? (size_t)c * 4 % std::min<size_t>(bad.size() - 8, 400) : (bad.size() - 8) * (size_t)(c - 47) / 50;
+                bad[at] ^= (unsigned char)(1u << (c % 8));
+                if (c % 2) { const uint64_t h = fnv(bad.data(), bad.size() - 8); memcpy(bad.data() + bad.size() - 8, &h, 8); }
+                HostPlan R;
+                ++tried;
+                const int rc2 = deserialize_host_plan(bad.data(), bad.size(), R, back, sizeof(back));
+                if (rc2 != 0) ++rejected;
+                else {                                           // accepted (a payload byte with the checksum repaired): must still be a
+                    for (const TileDesc &d : R.tiles)            // structurally safe plan -- what a kernel indexes stays inside the arrays
+                        if ((size_t)d.node_off + d.n_node > R.node_src.size() / 2 || (size_t)d.elem_off + d.n_elem > R.elem_pack.size()) {
+                            fprintf(stderr, "accepted blob with a descriptor outside its arrays\n");
+                            return 1;
+                        }
+                }
+            }
+            if (rejected < 64 + 48) { fprintf(stderr, "only %d of %d damaged blobs rejected\n", rejected, tried); return 1; }
+        }
         printf("%s: ok tiles=%zu slots=%zu nodes=%zu max_nodes=%d max_elems=%d chunked=%d\n", argv[a], P.tiles.size(),
                P.elem_pack.size(), P.node_src.size() / 2, P.max_nodes, P.max_elems, P.max_chunk_elems);
     }

@@ -471,7 +471,12 @@ __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, i
 // of the next block are requested before the current block is solved.  Same recursion, same operands; the pending sums are
 // accumulated block by block instead of step by step (differences at rounding level).
 constexpr int kRecB = 16;
-__global__ __launch_bounds__(kRecT) void recursion_blocked_kernel(LbfgsArrays A, int M1, double lr, double tol_change) {
+// sy_in_lds: the launch carries M1 x M1 doubles of dynamic LDS and S^T Y is staged there first (one coalesced sweep): the block
+// solves and rank-16 updates then read LDS instead of waiting for scattered L2 / memory round trips -- with ONE workgroup on
+// the chip nothing hides those (41 us at 100 pairs with global reads, most of it load latency).  Histories whose Gram block does
+// not fit (M1 > 128) read global memory.
+__global__ __launch_bounds__(kRecT) void recursion_blocked_kernel(LbfgsArrays A, int M1, double lr, double tol_change, int sy_in_lds) {
+    extern __shared__ double sy_lds[];
     __shared__ double al_[kRecMax], c_[kRecMax], ro_[kRecMax], sg_[kRecMax], yg_[kRecMax], v_[kRecMax], pend_[kRecMax];
     __shared__ int slot_[kRecMax];
     __shared__ double red[kRecT / 64];
@@ -491,6 +496,12 @@ __global__ __launch_bounds__(kRecT) void recursion_blocked_kernel(LbfgsArrays A,
     slot_[k] = sk; ro_[k] = ro; sg_[k] = sg; yg_[k] = yg;
     __syncthreads();                                      // also orders the Gram writes above before the reads below (one block)
     __threadfence_block();
+    const double *SYp = A.SY;
+    if (sy_in_lds) {
+        for (int i = k; i < M1 * M1; i += kRecT) sy_lds[i] = A.SY[i];
+        SYp = sy_lds;
+        __syncthreads();
+    }
     const double H = S.H_diag;
     const int lane = k & 63;
     const bool w0 = k < 64;
@@ -504,9 +515,9 @@ __global__ __launch_bounds__(kRecT) void recursion_blocked_kernel(LbfgsArrays A,
             for (int q = 0; q < kRecB; ++q) {
                 const int i = hi - q;                       // the block's q-th row (newest first)
                 // every older row k outside the block: s_k . y_i;  wave 0, lane r = row hi - r: its entries with the newer rows of the block
-                f[q] = (hi >= 0 && i >= lo && live && k < lo) ? A.SY[sk * M1 + slot_[i]] : 0.0;
+                f[q] = (hi >= 0 && i >= lo && live && k < lo) ? SYp[sk * M1 + slot_[i]] : 0.0;
                 const int ir = hi - lane;
-                e[q] = (hi >= 0 && w0 && i >= lo && ir >= lo && q < lane) ? A.SY[slot_[ir] * M1 + slot_[i]] : 0.0;
+                e[q] = (hi >= 0 && w0 && i >= lo && ir >= lo && q < lane) ? SYp[slot_[ir] * M1 + slot_[i]] : 0.0;
             }
         };
         fetch(count - 1, E, F);
@@ -557,9 +568,9 @@ __global__ __launch_bounds__(kRecT) void recursion_blocked_kernel(LbfgsArrays A,
 #pragma unroll
             for (int q = 0; q < kRecB; ++q) {
                 const int i = lo + q;                       // the block's q-th row (oldest first)
-                f[q] = (lo < count && i <= hi && live && k > hi) ? A.SY[slot_[i] * M1 + sk] : 0.0;       // s_i . y_k for every newer row k outside
+                f[q] = (lo < count && i <= hi && live && k > hi) ? SYp[slot_[i] * M1 + sk] : 0.0;       // s_i . y_k for every newer row k outside
                 const int ir = lo + lane;
-                e[q] = (lo < count && w0 && i <= hi && ir <= hi && q < lane) ? A.SY[slot_[i] * M1 + slot_[ir]] : 0.0;
+                e[q] = (lo < count && w0 && i <= hi && ir <= hi && q < lane) ? SYp[slot_[i] * M1 + slot_[ir]] : 0.0;
             }
         };
         fetch(0, E, F);
@@ -948,6 +959,8 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     if (!rc) rc = lb_malloc(&o->A.part, npart);
     if (!rc) rc = lb_malloc(&o->A.st, 1);
     if (rc) { hfem_lbfgs_destroy(o); return rc; }
+    // the blocked recursion stages S^T Y in up to 128 KB of dynamic LDS (above the 64 KB a launch may take without saying so)
+    (void)hipFuncSetAttribute((const void *)recursion_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8);
     double *s = o->scal;
     o->A.ro = s; s += M1; o->A.al = s; s += M1; o->A.cy = s; s += M1; o->A.cs = s; s += M1;
     o->A.dots = s; s += 5 * M1; o->A.SY = s; s += M1 * M1; o->A.YY = s;
@@ -994,7 +1007,11 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
 #undef HFEM_MD
         hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_md, M1);
     }
-    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_blocked_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
+    if (M1 - 1 <= kRecMax) {
+        const int in_lds = M1 <= 128 ? 1 : 0;             // 128 x 128 doubles = 128 KB of the CU's 160 KB
+        hipLaunchKernelGGL(recursion_blocked_kernel, dim3(1), dim3(kRecT), in_lds ? (size_t)M1 * M1 * sizeof(double) : 0, s, o->A, M1, lr,
+                           tol_change, in_lds);
+    }
     else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
     // elements per thread of the direction pass: 8 for very long vectors (fewer, fatter workgroups), 1 for short ones (more
     // workgroups), in between 2 (fp64) / 4 (fp32) -- measured on 2 x 10^6 parameters with 100 pairs: fp64 1.29 -> 1.26 ms, fp32
@@ -1075,7 +1092,11 @@ extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const doubl
     const int first = o->first ? 1 : 0, M1 = o->M1;
     hipLaunchKernelGGL(shard_finish_kernel, dim3(1), dim3(kLb), 0, s, o->A, gathered_dev, (int)world, 5 * M1 + kShardTail, M1, first,
                        (int)after_update, (int)want_direction, tol_grad, tol_change);
-    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_blocked_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
+    if (M1 - 1 <= kRecMax) {
+        const int in_lds = M1 <= 128 ? 1 : 0;             // 128 x 128 doubles = 128 KB of the CU's 160 KB
+        hipLaunchKernelGGL(recursion_blocked_kernel, dim3(1), dim3(kRecT), in_lds ? (size_t)M1 * M1 * sizeof(double) : 0, s, o->A, M1, lr,
+                           tol_change, in_lds);
+    }
     else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
     const int per_dir = o->nb_chunk >= 1024 ? kLbPer : (o->n >= (1 << 20) ? (o->dtype == 0 ? 2 : 4) : 1);
     const int nb_dir = (int)((o->n + (int64_t)per_dir * kLb - 1) / ((int64_t)per_dir * kLb));

@@ -463,164 +463,6 @@ __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, i
     }
 }
 
-// ---- the same two loops, BLOCKED (round 4): the rank-1 form above still pays one workgroup barrier per sequential step
-// (2 x count barriers: 52 us at 100 pairs -- half of an inner iteration on the reference's own example-4 mesh, a fifth of a
-// node-sharded iteration at BASELINE size).  Here the rows are taken kRecB at a time: wave 0 solves the block's small
-// triangular system by itself (lane r = the block's r-th row; al / c travel by wave shuffles, no barrier), publishes the
-// block's values, and every row outside the block takes ONE rank-kRecB update; two barriers per block, and the Gram entries
-// of the next block are requested before the current block is solved.  Same recursion, same operands; the pending sums are
-// accumulated block by block instead of step by step (differences at rounding level).
-constexpr int kRecB = 16;
-// sy_in_lds: the launch carries M1 x M1 doubles of dynamic LDS and S^T Y is staged there first (one coalesced sweep): the block
-// solves and rank-16 updates then read LDS instead of waiting for scattered L2 / memory round trips -- with ONE workgroup on
-// the chip nothing hides those (41 us at 100 pairs with global reads, most of it load latency).  Histories whose Gram block does
-// not fit (M1 > 128) read global memory.
-__global__ __launch_bounds__(kRecT) void recursion_blocked_kernel(LbfgsArrays A, int M1, double lr, double tol_change, int sy_in_lds) {
-    extern __shared__ double sy_lds[];
-    __shared__ double al_[kRecMax], c_[kRecMax], ro_[kRecMax], sg_[kRecMax], yg_[kRecMax], v_[kRecMax], pend_[kRecMax];
-    __shared__ int slot_[kRecMax];
-    __shared__ double red[kRecT / 64];
-    LbfgsState &S = *A.st;
-    if (S.skip) return;
-    const int count = S.count, head = S.head, ns = S.new_slot, k = threadIdx.x;
-    if (ns >= 0 && k < count) {                           // Gram row / column of the new pair
-        const int j = (head + k) % M1;
-        A.SY[ns * M1 + j] = A.dots[j * 5 + 2];
-        A.SY[j * M1 + ns] = A.dots[j * 5 + 4];
-        A.YY[ns * M1 + j] = A.dots[j * 5 + 3];
-        A.YY[j * M1 + ns] = A.dots[j * 5 + 3];
-    }
-    const bool live = k < count;
-    const int sk = live ? (head + k) % M1 : 0;
-    const double ro = live ? A.ro[sk] : 0.0, sg = live ? A.dots[sk * 5 + 1] : 0.0, yg = live ? A.dots[sk * 5] : 0.0;
-    slot_[k] = sk; ro_[k] = ro; sg_[k] = sg; yg_[k] = yg;
-    __syncthreads();                                      // also orders the Gram writes above before the reads below (one block)
-    __threadfence_block();
-    const double *SYp = A.SY;
-    if (sy_in_lds) {
-        for (int i = k; i < M1 * M1; i += kRecT) sy_lds[i] = A.SY[i];
-        SYp = sy_lds;
-        __syncthreads();
-    }
-    const double H = S.H_diag;
-    const int lane = k & 63;
-    const bool w0 = k < 64;
-    double t = 0.0, w = 0.0, al_k = 0.0, c_k = 0.0;
-    // ---- first loop, rows count-1 .. 0 in blocks [lo, hi]: al_i = ro_i (-s_i.g - sum_{j newer} al_j s_i.y_j)
-    {
-        double E[kRecB], F[kRecB], E2[kRecB], F2[kRecB];
-        auto fetch = [&](int hi, double (&e)[kRecB], double (&f)[kRecB]) {
-            const int lo = hi - kRecB + 1 < 0 ? 0 : hi - kRecB + 1;
-#pragma unroll
-            for (int q = 0; q < kRecB; ++q) {
-                const int i = hi - q;                       // the block's q-th row (newest first)
-                // every older row k outside the block: s_k . y_i;  wave 0, lane r = row hi - r: its entries with the newer rows of the block
-                f[q] = (hi >= 0 && i >= lo && live && k < lo) ? SYp[sk * M1 + slot_[i]] : 0.0;
-                const int ir = hi - lane;
-                e[q] = (hi >= 0 && w0 && i >= lo && ir >= lo && q < lane) ? SYp[slot_[ir] * M1 + slot_[i]] : 0.0;
-            }
-        };
-        fetch(count - 1, E, F);
-        for (int hi = count - 1; hi >= 0; hi -= kRecB) {
-            const int lo = hi - kRecB + 1 < 0 ? 0 : hi - kRecB + 1, nb = hi - lo + 1;
-            fetch(hi - kRecB, E2, F2);                     // the next block's entries land under this block's solve
-            if (live && k >= lo && k <= hi) pend_[k] = t;
-            __syncthreads();
-            if (w0) {                                      // wave 0 alone: the block's triangular system, values by shuffle
-                const int i = hi - lane;
-                const bool mine = lane < nb;
-                double tt = mine ? pend_[i] : 0.0;
-                const double r_ = mine ? ro_[i] : 0.0, s_ = mine ? sg_[i] : 0.0;
-                double mine_al = 0.0;
-#pragma unroll
-                for (int q = 0; q < kRecB; ++q) {
-                    const double cand = r_ * (-s_ - tt);
-                    const double a = __shfl(cand, q, 64);  // row hi - q is final once the newer rows of the block are in
-                    if (lane == q) mine_al = cand;
-                    if (lane > q) tt += a * E[q];
-                }
-                if (mine) al_[i] = mine_al;
-            }
-            __syncthreads();
-            if (live && k < lo) {
-#pragma unroll
-                for (int q = 0; q < kRecB; ++q)
-                    if (q < nb) t += al_[hi - q] * F[q];
-            }
-            if (live && k >= lo && k <= hi) al_k = al_[k];
-#pragma unroll
-            for (int q = 0; q < kRecB; ++q) { E[q] = E2[q]; F[q] = F2[q]; }
-        }
-    }
-    __syncthreads();
-    // ---- v_k = sum_j al_j y_k.y_j : every row streams its own Gram row (no dependence between rows)
-    double v = 0.0;
-    if (live) {
-#pragma unroll 8
-        for (int j = 0; j < count; ++j) v += al_[j] * A.YY[sk * M1 + slot_[j]];
-    }
-    v_[k] = v;
-    // ---- second loop, rows 0 .. count-1 in blocks [lo, hi]: c_i = al_i - ro_i (H (-y_i.g - v_i) + sum_{j older} c_j s_j.y_i)
-    {
-        double E[kRecB], F[kRecB], E2[kRecB], F2[kRecB];
-        auto fetch = [&](int lo, double (&e)[kRecB], double (&f)[kRecB]) {
-            const int hi = lo + kRecB - 1 >= count ? count - 1 : lo + kRecB - 1;
-#pragma unroll
-            for (int q = 0; q < kRecB; ++q) {
-                const int i = lo + q;                       // the block's q-th row (oldest first)
-                f[q] = (lo < count && i <= hi && live && k > hi) ? SYp[slot_[i] * M1 + sk] : 0.0;       // s_i . y_k for every newer row k outside
-                const int ir = lo + lane;
-                e[q] = (lo < count && w0 && i <= hi && ir <= hi && q < lane) ? SYp[slot_[i] * M1 + slot_[ir]] : 0.0;
-            }
-        };
-        fetch(0, E, F);
-        for (int lo = 0; lo < count; lo += kRecB) {
-            const int hi = lo + kRecB - 1 >= count ? count - 1 : lo + kRecB - 1, nb = hi - lo + 1;
-            fetch(lo + kRecB, E2, F2);
-            if (live && k >= lo && k <= hi) pend_[k] = w;
-            __syncthreads();                               // (the first one also publishes v_)
-            if (w0) {
-                const int i = lo + lane;
-                const bool mine = lane < nb;
-                double ww = mine ? pend_[i] : 0.0;
-                const double r_ = mine ? ro_[i] : 0.0, a_ = mine ? al_[i] : 0.0, base = mine ? H * (-yg_[i] - v_[i]) : 0.0;
-                double mine_c = 0.0;
-#pragma unroll
-                for (int q = 0; q < kRecB; ++q) {
-                    const double cand = a_ - r_ * (base + ww);
-                    const double cq = __shfl(cand, q, 64);
-                    if (lane == q) mine_c = cand;
-                    if (lane > q) ww += cq * E[q];
-                }
-                if (mine) c_[i] = mine_c;
-            }
-            __syncthreads();
-            if (live && k > hi) {
-#pragma unroll
-                for (int q = 0; q < kRecB; ++q)
-                    if (q < nb) w += c_[lo + q] * F[q];
-            }
-            if (live && k >= lo && k <= hi) c_k = c_[k];
-#pragma unroll
-            for (int q = 0; q < kRecB; ++q) { E[q] = E2[q]; F[q] = F2[q]; }
-        }
-    }
-    // ---- coefficients by slot, g.d, step, break flag
-    double part = 0.0;
-    if (live) {
-        const double cyj = -H * al_k;
-        A.al[sk] = al_k; A.cy[sk] = cyj; A.cs[sk] = c_k;
-        part = cyj * yg + c_k * sg;
-    }
-    const double sum = block_sum(part, red);
-    if (k == 0) {
-        S.cg = -H;
-        S.gtd = -H * S.gg + sum;
-        S.t = S.n_iter == 1 ? fmin(1.0, 1.0 / S.g_abssum) * lr : lr;
-        S.stop_gtd = S.gtd > -tol_change ? 1 : 0;
-    }
-}
-
 // ---- d = cg g + sum_j cy_j Y_j + cs_j S_j (one pass over the history), max|d| partials [nb]
 // PER elements per thread: 8 for long vectors (fewer, fatter workgroups), 1 for short ones (more workgroups); the slot
 // loop is unrolled so that several slots' loads are in flight (it is latency-bound otherwise).  Same sums either way.
@@ -959,8 +801,6 @@ extern "C" int hfem_lbfgs_create(int device, int64_t n, int32_t history, int32_t
     if (!rc) rc = lb_malloc(&o->A.part, npart);
     if (!rc) rc = lb_malloc(&o->A.st, 1);
     if (rc) { hfem_lbfgs_destroy(o); return rc; }
-    // the blocked recursion stages S^T Y in up to 128 KB of dynamic LDS (above the 64 KB a launch may take without saying so)
-    (void)hipFuncSetAttribute((const void *)recursion_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8);
     double *s = o->scal;
     o->A.ro = s; s += M1; o->A.al = s; s += M1; o->A.cy = s; s += M1; o->A.cs = s; s += M1;
     o->A.dots = s; s += 5 * M1; o->A.SY = s; s += M1 * M1; o->A.YY = s;
@@ -1007,11 +847,7 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
 #undef HFEM_MD
         hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_md, M1);
     }
-    if (M1 - 1 <= kRecMax) {
-        const int in_lds = M1 <= 128 ? 1 : 0;             // 128 x 128 doubles = 128 KB of the CU's 160 KB
-        hipLaunchKernelGGL(recursion_blocked_kernel, dim3(1), dim3(kRecT), in_lds ? (size_t)M1 * M1 * sizeof(double) : 0, s, o->A, M1, lr,
-                           tol_change, in_lds);
-    }
+    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
     else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
     // elements per thread of the direction pass: 8 for very long vectors (fewer, fatter workgroups), 1 for short ones (more
     // workgroups), in between 2 (fp64) / 4 (fp32) -- measured on 2 x 10^6 parameters with 100 pairs: fp64 1.29 -> 1.26 ms, fp32
@@ -1092,11 +928,7 @@ extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const doubl
     const int first = o->first ? 1 : 0, M1 = o->M1;
     hipLaunchKernelGGL(shard_finish_kernel, dim3(1), dim3(kLb), 0, s, o->A, gathered_dev, (int)world, 5 * M1 + kShardTail, M1, first,
                        (int)after_update, (int)want_direction, tol_grad, tol_change);
-    if (M1 - 1 <= kRecMax) {
-        const int in_lds = M1 <= 128 ? 1 : 0;             // 128 x 128 doubles = 128 KB of the CU's 160 KB
-        hipLaunchKernelGGL(recursion_blocked_kernel, dim3(1), dim3(kRecT), in_lds ? (size_t)M1 * M1 * sizeof(double) : 0, s, o->A, M1, lr,
-                           tol_change, in_lds);
-    }
+    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
     else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
     const int per_dir = o->nb_chunk >= 1024 ? kLbPer : (o->n >= (1 << 20) ? (o->dtype == 0 ? 2 : 4) : 1);
     const int nb_dir = (int)((o->n + (int64_t)per_dir * kLb - 1) / ((int64_t)per_dir * kLb));

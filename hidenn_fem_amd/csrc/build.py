@@ -1,6 +1,6 @@
 """Build libhidenn_hip.so in-tree with hipcc for gfx950 (MI355X / CDNA4 only).
 
-    python hidenn_fem_amd/csrc/build.py [--force] [--keep-temps] [--lab]
+    python hidenn_fem_amd/csrc/build.py [--force] [--keep-temps] [--lab] [--tag NAME --define MACRO=VALUE ...]
 
 One object per source (compiled in parallel), one link.  ``-munsafe-fp-atomics``
 selects the hardware fp64 atomics (``global_atomic_add_f64`` / ``ds_add_f64``)
@@ -32,15 +32,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, keep_temps: bool = False, lab: bool = False) -> str:
+def build(force: bool = False, keep_temps: bool = False, lab: bool = False, tag: str = "", defines=()) -> str:
     """``lab=True`` builds the second target, ``libhidenn_hip_lab.so`` (``-DHFEM_LAB``): the same library plus the
     kernel-lab instrumentation -- ablation instances, s_memrealtime stamps, start staggers, the pipelined and the
     streamed kernel variants -- that ``scripts/`` drives (``HFEM_LAB=1`` selects it in ``hidenn_fem_amd._lib``).
-    None of that is compiled into the product library."""
+    None of that is compiled into the product library.  ``tag`` + ``defines`` (dev tool, A/B timing of a compile-time choice):
+    a third target ``libhidenn_hip_<tag>.so`` of the product sources with ``-D<define>`` added, built in ``build/<tag>``; a
+    script selects it by setting ``hidenn_fem_amd._lib.LIB_PATH`` before the first call."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bdir = os.path.join(HERE, "build", "lab") if lab else os.path.join(HERE, "build")
     out = OUT_LAB if lab else OUT
     flags = CXXFLAGS + (["-DHFEM_LAB"] if lab else [])
+    if tag:
+        bdir, out = os.path.join(HERE, "build", tag), os.path.join(HERE, f"libhidenn_hip_{tag}.so")
+        flags = flags + ["-D" + d for d in defines]
     srcs = [os.path.join(HERE, s) for s in SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     objs = [os.path.join(bdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
@@ -91,4 +96,6 @@ def resource_usage(lab: bool = False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv, lab="--lab" in sys.argv))
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
+    defs = [sys.argv[i + 1] for i, v in enumerate(sys.argv) if v == "--define"]
+    print(build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv, lab="--lab" in sys.argv, tag=tag, defines=defs))

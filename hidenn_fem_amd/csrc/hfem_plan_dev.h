@@ -252,6 +252,23 @@ __device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSu
 // L2).  Map block -> tile so that each XCD walks one contiguous run of the
 // Morton-ordered tiles: neighbouring tiles share halo nodes, which then hit the
 // same L2.  Bijective for any grid size; placement only affects speed.
+// Wave priority through a tile's memory phases (round 4).  A workgroup that arrives on a CU whose other workgroups are in
+// their fp64 slot loops has ~60 prologue instructions (index loads, address selects, the gather) to issue before its first
+// byte is requested, and they queue behind the resident waves' VALU work at equal priority; the same holds for the write-out
+// of a tile that finishes while its neighbours compute.  s_setprio raises the wave over the arithmetic ones for exactly those
+// stretches: the memory requests go out earlier and overlap the neighbours' arithmetic.  Measured (scripts/quad4_lab.py --bits,
+// scripts/ab_lib.py, profiles/r04/ab_mem_prio.jsonl): Q1M 22.3 -> 21.8 us (rotating sets 22.5 -> 21.8; 22.3 -> 21.1 in the lab sweep), the paired fp64 TRI3 kernel
+// 8.82 -> 8.72 us, T2M and the fused Adam step unchanged; the fp32-arithmetic kernel (shorter slot loop) loses 1 % and does not use it.  HFEM_MEM_PRIO = 0 compiles it out.
+#ifndef HFEM_MEM_PRIO
+#define HFEM_MEM_PRIO 3
+#endif
+__device__ __forceinline__ void mem_phase_begin() {
+    if (HFEM_MEM_PRIO) __builtin_amdgcn_s_setprio(HFEM_MEM_PRIO);
+}
+__device__ __forceinline__ void mem_phase_end() {
+    if (HFEM_MEM_PRIO) __builtin_amdgcn_s_setprio(0);
+}
+
 __device__ __forceinline__ int xcd_tile(int b, int nb) {
     const int q = nb >> 3, r = nb & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -381,7 +398,7 @@ struct hfem_peer {
 };
 namespace hfem {
 extern int g_quad4_stagger, g_quad4_stagger_shift, g_quad4_stagger_groups;
-extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps;   // quad4.hip (lab option "quad4_ablate")
+extern int g_quad4_ablate, g_quad4_pipe, g_quad4_const_caps, g_quad4_bits;   // quad4.hip (lab option "quad4_ablate")
 
 }  // namespace hfem
 

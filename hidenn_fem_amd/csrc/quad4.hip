@@ -26,6 +26,7 @@ int g_quad4_const_caps = 1;   // default tile shape: instance with a compile-tim
 int g_quad4_stagger_groups = 2;
 int g_quad4_stagger = 0, g_quad4_stagger_shift = 8;
 int g_quad4_pipe = 0;     // 0: one workgroup per tile; k > 0: persistent pipelined kernel, k workgroups per CU
+int g_quad4_bits = 0;     // lab: bit 0 = NO raised wave priority through the memory phases, bit 1 = leftover slot chunk rotates over the waves
 int g_quad4_ablate = 0;   // bit 0 = no element math, bit 1 = no LDS atomics (tiled kernel)
 
 struct JacGrad {          // dL/d(a,b,c,d), dL/dG0, dL/dG1
@@ -355,6 +356,15 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     const int tid = threadIdx.x;
     const int slot = xcd_tile(blockIdx.x, gridDim.x);
 #ifdef HFEM_LAB
+    const int lab_bits = skip_edges >> 8;
+    skip_edges &= 1;
+    if (!(lab_bits & 1)) mem_phase_begin();             // lab bit 0: NO raised priority through the memory phases
+    const int rtid = (lab_bits & 2) ? ((tid + 64 * (slot & 3)) & (BLOCK - 1)) : tid;      // record lane: which wave takes the short last chunk
+#else
+    const int rtid = tid;
+    mem_phase_begin();                                  // prologue at raised wave priority (hfem_plan_dev.h)
+#endif
+#ifdef HFEM_LAB
     // Phase offset between co-resident workgroups: without it every resident tile gathers at the same time and
     // then computes at the same time (HBM idle while the fp64 VALU works and vice versa).
     if (stagger_ticks > 0) {
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     for (int j = 0; j < NPT; ++j) s[j] = src[min(tid + j * BLOCK, pd.node_stride - 1)];      // lanes past the stride repeat its last record
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const size_t i = rec0 + min(tid + j * BLOCK, pd.elem_stride - 1);
+        const size_t i = rec0 + min(rtid + j * BLOCK, pd.elem_stride - 1);
         pk[j] = pd.elem_pack[i];
         pk3[j] = pd.elem_pack_hi[i];
     }
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     __builtin_amdgcn_sched_barrier(0);                  // all gather loads are issued before the first is waited for
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
-        if (tid + j * BLOCK >= d.n_elem) { pk[j] = kSkipBit; pk3[j] = 0u; }
+        if (rtid + j * BLOCK >= d.n_elem) { pk[j] = kSkipBit; pk3[j] = 0u; }
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int l = tid + j * BLOCK;
@@ -402,6 +412,10 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
     HFEM_QSTAMP(2)
     __syncthreads();
     HFEM_QSTAMP(3)
+#ifdef HFEM_LAB
+    if (!(lab_bits & 1))
+#endif
+    mem_phase_end();
 
     double e_loc = 0.0;
 #pragma unroll
@@ -461,6 +475,10 @@ __global__ __launch_bounds__(BLOCK) void quad4_energy_fast_kernel(
         if ((tid & 63) == 0) red[tid >> 6] = w;          // one slot per wave: summed in wave order below
     }
     HFEM_QSTAMP(4)
+#ifdef HFEM_LAB
+    if (!(lab_bits & 1))
+#endif
+    mem_phase_begin();                                  // write-out
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): all loads returned long ago; keeps per-store vmcnt waits out of the write-out
     __syncthreads();
     HFEM_QSTAMP(5)
@@ -940,11 +958,12 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
     hipLaunchKernelGGL((quad4_energy_fast_kernel<256, __VA_ARGS__>), dim3(n), dim3(256), (size_t)plan->lds_bytes, s,          \
                        plan_dev(plan), (int)tile_begin, (const V *)x_free, (const V *)x_fixed, (const V *)u_free,            \
                        (const V *)u_fixed, k, (const double4 *)T_edge, tc, plan->d_partials + tile_begin, (V *)gx, (V *)gu,   \
-                       h.max_nodes, h.max_owned, skip_edges, stagger, sshift, plan->d_stamps, body)
+                       h.max_nodes, h.max_owned, skip_k, stagger, sshift, plan->d_stamps, body)
 #define HFEM_LAUNCH_Q4(NPT, EPT, ...) HFEM_LAUNCH_Q4V(double2, NPT, EPT, __VA_ARGS__)
 #ifdef HFEM_LAB
         const int abl = g_quad4_ablate;
         const int stagger = g_quad4_stagger >= 0 ? g_quad4_stagger : (n >= 1536 ? 200 : 0);
+        const int skip_k = skip_edges | (g_quad4_bits << 8);      // the tiled kernel's lab bits ride above the flag
         if (dtype == 0 && !phys && g_quad4_pipe > 0 && abl == 0 && h.max_nodes <= 3 * 256 && h.max_elems <= 4 * 256 &&
             plan->lds_bytes_pipe <= 64 * 1024) {
             int G = g_quad4_pipe * 256;
@@ -968,6 +987,7 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
         else
 #else
         const int stagger = 0;
+        const int skip_k = skip_edges;
 #endif
         if (dtype == 1) {                                                // fp32 rows: general instances (runtime strides)
             if (phys && hasb) HFEM_LAUNCH_Q4V(float2, 4, 4, 0, 0, true, 0, float2, true);
@@ -983,7 +1003,7 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 3, 3, 0, 560, false, 672, double2, false, 2>), dim3(n), dim3(256), (size_t)39552, s,
                                plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,
                                (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
-                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, 672, 560, skip_edges, stagger, sshift,
+                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, 672, 560, skip_k, stagger, sshift,
                                plan->d_stamps, body);
         } else if (plan->tune.store_policy == 2) HFEM_LAUNCH_Q4(4, 4, 0, 0, false, 0, double2, false, 2);
         else if (g_quad4_const_caps && h.max_nodes <= 672 && h.max_owned <= 560 && h.max_elems <= 3 * 256) {
@@ -991,7 +1011,7 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
             hipLaunchKernelGGL((quad4_energy_fast_kernel<256, 3, 3, 0, 560, false, 672>), dim3(n), dim3(256), (size_t)39552, s,
                                plan_dev(plan), (int)tile_begin, (const double2 *)x_free, (const double2 *)x_fixed,
                                (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
-                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, 672, 560, skip_edges, stagger, sshift,
+                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, 672, 560, skip_k, stagger, sshift,
                                plan->d_stamps, body);
         } else if (h.max_nodes <= 3 * 256 && h.max_elems <= 3 * 256) HFEM_LAUNCH_Q4(3, 3, 0);
         else if (g_quad4_const_caps && h.max_owned <= 560 && h.max_nodes * 32 + 560 * 32 + 128 <= 40960) {
@@ -1000,7 +1020,7 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
                                (size_t)(h.max_nodes * 32 + 560 * 32 + 128), s, plan_dev(plan), (int)tile_begin,
                                (const double2 *)x_free, (const double2 *)x_fixed, (const double2 *)u_free,
                                (const double2 *)u_fixed, k, (const double4 *)T_edge, tc, plan->d_partials + tile_begin,
-                               (double2 *)gx, (double2 *)gu, h.max_nodes, 560, skip_edges, stagger, sshift, plan->d_stamps, body);
+                               (double2 *)gx, (double2 *)gu, h.max_nodes, 560, skip_k, stagger, sshift, plan->d_stamps, body);
         } else HFEM_LAUNCH_Q4(4, 4, 0);
 #undef HFEM_LAUNCH_Q4
 #undef HFEM_LAUNCH_Q4V

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         return;
     }
     const int slot = xcd_tile(bid, n_launch);
+    mem_phase_begin();                                  // prologue at raised wave priority (hfem_plan_dev.h)
     // span stamps (hfem_plan_set_span_stamps, off by default): when this workgroup started -- scalar registers only
     unsigned long long t_start = 0;
     if (pd.span) t_start = __builtin_amdgcn_s_memrealtime();
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     __syncthreads();
+    mem_phase_end();
 
     auto add_row = [&](int l, const double2 gx, const double2 gu) {
         unsafeAtomicAdd(&acc0[l], gx.x); unsafeAtomicAdd(&acc1[l], gx.y);
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
     }
     // every load has long returned; saying so keeps the compiler from guarding each write-out store with a vmcnt(0) of its
     // own (gfx9 counts stores in vmcnt: the stores would wait for one another -- seen in the ISA of the carrying slot loop)
+    mem_phase_begin();                                  // write-out
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 

@@ -66,6 +66,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_lab_kernel(
     }
     if (HFEM_PAIR_LAB(16)) return;                      // lab: dispatch cost of this grid shape alone
     const int slot = xcd_tile(blockIdx.x, n_launch);
+    // lab bits 16384 / 65536 / 131072: wave priority 3 / 1 / 2 through the prologue (index loads, gather, LDS fill) and, unless bit
+    // 32768 is set, again through the write-out; the slot loop runs at priority 0.  262144: the plain lab kernel (no change).
+    const bool prio_on = HFEM_PAIR_LAB(16384 | 65536 | 131072);
+    if (HFEM_PAIR_LAB(16384)) __builtin_amdgcn_s_setprio(3);
+    else if (HFEM_PAIR_LAB(65536)) __builtin_amdgcn_s_setprio(1);
+    else if (HFEM_PAIR_LAB(131072)) __builtin_amdgcn_s_setprio(2);
     // span stamps (hfem_plan_set_span_stamps, off by default): when this workgroup started -- scalar registers only
     unsigned long long t_start = 0;
     if (pd.span) t_start = __builtin_amdgcn_s_memrealtime();
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_lab_kernel(
         if (l < n_owned) { acc0[l] = 0.0; acc1[l] = 0.0; acc2[l] = 0.0; acc3[l] = 0.0; }
     }
     __syncthreads();
+    if (prio_on) __builtin_amdgcn_s_setprio(0);
     if (HFEM_PAIR_LAB(128)) {                           // lab: + LDS fill and the first barrier
         uint32_t acc = 0;
         for (int j = 0; j < EPT; ++j) acc += w0[j] ^ w1[j];
@@ -262,6 +269,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_lab_kernel(
     }
     // every load has long returned; saying so keeps the compiler from guarding each write-out store with a vmcnt(0) of its
     // own (gfx9 counts stores in vmcnt: the stores would wait for one another -- seen in the ISA of the carrying slot loop)
+    if (prio_on && !HFEM_PAIR_LAB(32768)) __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 

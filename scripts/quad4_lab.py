@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--ccaps", default="1", help="compile-time accumulator stride instance (1) or runtime strides (0)")
     ap.add_argument("--pipes", default="0", help="persistent pipelined kernel: workgroups per CU (0 = off)")
     ap.add_argument("--ablate", default="0", help="lab bits: 1 no element math, 2 no LDS atomics")
+    ap.add_argument("--bits", default="0", help="lab bits: 1 NO raised wave priority through the memory phases, 2 rotating short slot chunk")
     ap.add_argument("--snaps", default="0", help="plan_snap values (tile cuts snap to coarse curve cells, percent of a tile)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -106,8 +107,9 @@ def main():
         for abl, stg, sh, grp, pipe in [(int(x), int(y), int(z), int(w), int(q)) for x in a.ablate.split(",")
                                         for y in a.staggers.split(",") for z in (a.shifts.split(",") if int(y) else ["8"])
                                         for w in (a.groups.split(",") if int(y) else ["2"]) for q in a.pipes.split(",")]:
-          for cc in [int(c_) for c_ in a.ccaps.split(",")]:
+          for cc, bits in [(int(c_), int(b_)) for c_ in a.ccaps.split(",") for b_ in a.bits.split(",")]:
               _lib.check(L.hfem_set_option(b"quad4_const_caps", cc))
+              _lib.check(L.hfem_set_option(b"quad4_bits", bits))
               _lib.check(L.hfem_set_option(b"quad4_pipe", pipe))
               if abl == 0:                                   # correctness of the variant vs the first one
                   tiled(torch.cuda.current_stream().cuda_stream, 0)
@@ -127,7 +129,7 @@ def main():
               _lib.check(L.hfem_set_option(b"quad4_stagger", 0))
               _lib.check(L.hfem_set_option(b"quad4_pipe", 0))
               st = plan.stats
-              print(json.dumps(dict(kernel="quad4_tiled", ablate=abl, stagger=stg, shift=sh, groups=grp, pipe=pipe, ccaps=cc, check=chk if abl == 0 else "", tile_elems=T, cap=cap, snap=snap, us=round(us, 2),
+              print(json.dumps(dict(kernel="quad4_tiled", ablate=abl, stagger=stg, shift=sh, groups=grp, pipe=pipe, ccaps=cc, bits=bits, check=chk if abl == 0 else "", tile_elems=T, cap=cap, snap=snap, us=round(us, 2),
                                     alg_TBps=round(alg / us * 1e-6, 3), frac=round(alg / us * 1e-6 / 8.0, 3),
                                     n_tiles=st["n_tiles"], lds=st["lds_bytes"], slots=st["tile_elem_total"],
                                     max_nodes=st["max_tile_nodes"], max_elems=st["max_tile_elems"])), flush=True)

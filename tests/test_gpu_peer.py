@@ -181,6 +181,12 @@ def test_peer_windows_one_rank_every_step_matches_the_collective_path():
     for _ in range(2):
         got.owner_step_overlapped()
     assert got.finish_overlapped().item() == l0.item() and got.peer.status() == (0, 2)
+    # recovery path: new windows in place of the old ones (what a caller does after a timed-out get), counters start again
+    got.reset_peer_exchange()
+    assert got.peer is not None and got.peer.status() == (0, 0) and got.inkernel_get
+    got.owner_step_overlapped()
+    assert got.finish_overlapped().item() == l0.item() and got.peer.status() == (0, 1)
+    got.check_exchange()
     got.close_peer_exchange()
     comm.close()
 

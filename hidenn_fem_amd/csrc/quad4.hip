@@ -980,6 +980,14 @@ extern "C" int hfem_quad4_energy_plan_ex(hfem_plan *plan, int32_t dtype, const v
             hipLaunchKernelGGL(quad4_sum_partials_kernel, dim3(1), dim3(256), 0, s, plan->d_partials + tile_begin, G, loss_out);
             return launch_status("hfem_quad4_energy_plan(sum)");
         }
+        if (dtype == 0 && !phys && !hasb && (g_quad4_bits & 4) && h.max_nodes <= 3 * 128 && h.max_elems <= 3 * 128) {
+            // lab: 128-thread workgroups on half-size tiles (8 per CU by LDS and registers alike)
+            hipLaunchKernelGGL((quad4_energy_fast_kernel<128, 3, 3, 0, 0, false, 0, double2, false, 2>), dim3(n), dim3(128),
+                               (size_t)plan->lds_bytes, s, plan_dev(plan), (int)tile_begin, (const double2 *)x_free,
+                               (const double2 *)x_fixed, (const double2 *)u_free, (const double2 *)u_fixed, k, (const double4 *)T_edge, tc,
+                               plan->d_partials + tile_begin, (double2 *)gx, (double2 *)gu, h.max_nodes, h.max_owned, skip_k, stagger,
+                               sshift, plan->d_stamps, body);
+        } else
         if (dtype == 0 && !phys && abl == 1) HFEM_LAUNCH_Q4(4, 4, 1);        // lab instances (hfem_set_option("quad4_ablate"))
         else if (dtype == 0 && !phys && abl == 2) HFEM_LAUNCH_Q4(4, 4, 2);
         else if (dtype == 0 && !phys && abl == 3) HFEM_LAUNCH_Q4(4, 4, 3);

@@ -194,16 +194,28 @@ __global__ __launch_bounds__(kLb) void pair_reduce_kernel(LbfgsArrays A, int nb,
 // L-BFGS iteration against 1.35).
 // VEC consecutive elements per load (fp32 histories: 2 -> 8-byte loads like the fp64 ones, needs an even n); a thread owns
 // PER loads = PER * VEC elements of the chunk.
-template <typename T, int VEC>
+// HFEM_LBFGS_VARIANT (build.py --tag/--define, A/B timing): 2 = non-temporal loads of the history in the multidot pass, 8 = 16-byte
+// loads in the fp64 multidot pass.  Measured on T1M (2 x 10^6 fp64 parameters, 100 pairs, three alternating runs each,
+// profiles/r04/lbfgs_load_variants.jsonl): 0 -> 1.335 ms per inner iteration, 2 -> 1.255 (the history is read once per pass and
+// is 12 x the Infinity Cache: keeping it out of the caches leaves them to g, the new pair and the partials), 8 -> 1.32.  The same
+// two changes in the direction pass (bits 1 and 4 of that experiment) gained nothing in fp64 -- 1.265 / 1.35 -- and its
+// unguarded-load form ran the fp32 pass at HALF speed (760 us against ~300: profiles/r04/lbfgs_fp32_direction_regression.csv), so
+// the direction pass keeps its round-3 form.  Default: 2.  scripts/micro/history_stream_bench.hip: the access pattern itself
+// allows 5.5-6.0 TB/s in every shape tried (block 64...1024, 8 / 16-byte loads, 1...8 loads per thread, nt or not).
+#ifndef HFEM_LBFGS_VARIANT
+#define HFEM_LBFGS_VARIANT 2
+#endif
+template <typename T, int VEC, bool NT = false>
 __device__ __forceinline__ void lb_load(const T *__restrict__ p, int64_t i, int64_t n, T *out) {
     if constexpr (VEC == 2) {
         if (i < n) {                                           // n even, i even: the pair is inside and 2 sizeof(T)-aligned
             typedef T pair_t __attribute__((ext_vector_type(2)));
-            const pair_t v = *reinterpret_cast<const pair_t *>(p + i);
+            const pair_t *q = reinterpret_cast<const pair_t *>(p + i);
+            const pair_t v = NT ? __builtin_nontemporal_load(q) : *q;
             out[0] = v.x; out[1] = v.y;
         } else { out[0] = (T)0; out[1] = (T)0; }
     } else {
-        out[0] = i < n ? p[i] : (T)0;
+        out[0] = i < n ? (NT ? __builtin_nontemporal_load(p + i) : p[i]) : (T)0;
     }
 }
 
@@ -231,8 +243,8 @@ __global__ __launch_bounds__(kLb) void multidot_kernel(LbfgsArrays A, const T *_
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int64_t i = base + (int64_t)k * kLb * VEC;
-            lb_load<T, VEC>(Yj, i, n, y + k * VEC);
-            lb_load<T, VEC>(Sj, i, n, s + k * VEC);
+            lb_load<T, VEC, (HFEM_LBFGS_VARIANT & 2) != 0>(Yj, i, n, y + k * VEC);
+            lb_load<T, VEC, (HFEM_LBFGS_VARIANT & 2) != 0>(Sj, i, n, s + k * VEC);
         }
     };
     auto reduce_store = [&](int l, const T (&yr)[E], const T (&sr)[E], int buf) {
@@ -841,7 +853,8 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
         int gy = 2048 / o->nb_chunk;                      // slot classes: fill the chip when the vectors are short
         gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
 #define HFEM_MD(T, P, V) hipLaunchKernelGGL((multidot_kernel<T, P, V>), dim3(o->nb_md, gy), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, o->n, M1)
-        if (o->dtype == 0) HFEM_MD(double, kLbPer, 1);
+        if (o->dtype == 0 && (HFEM_LBFGS_VARIANT & 8) && o->n % 2 == 0) HFEM_MD(double, kLbPer / 2, 2);
+        else if (o->dtype == 0) HFEM_MD(double, kLbPer, 1);
         else if (o->per == 16) HFEM_MD(float, 8, 2);
         else HFEM_MD(float, kLbPer, 1);
 #undef HFEM_MD
@@ -903,7 +916,8 @@ extern "C" int hfem_lbfgs_shard_local(hfem_lbfgs *o, const void *g, const double
         int gy = 2048 / o->nb_chunk;
         gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
 #define HFEM_MD(T, P, V) hipLaunchKernelGGL((multidot_kernel<T, P, V>), dim3(o->nb_md, gy), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, o->n, M1, 1)
-        if (o->dtype == 0) HFEM_MD(double, kLbPer, 1);
+        if (o->dtype == 0 && (HFEM_LBFGS_VARIANT & 8) && o->n % 2 == 0) HFEM_MD(double, kLbPer / 2, 2);
+        else if (o->dtype == 0) HFEM_MD(double, kLbPer, 1);
         else if (o->per == 16) HFEM_MD(float, 8, 2);
         else HFEM_MD(float, kLbPer, 1);
 #undef HFEM_MD

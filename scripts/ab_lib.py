@@ -104,7 +104,12 @@ def child(lib_name):
     c, _ = case(t1m, torch.float32, False, 1, 8 | 1024)
     q1m = structured_quad_mesh(1001, 1001, length=2.0, height=2.0, jitter=0.2, seed=0, dtype=f64)
     d, e = case(q1m, f64, True, 6, 8)
-    print(json.dumps(dict(lib=lib_name, t1m_replayed_us=a, t1m_rotating_us=b, t1m_adam_step_us=f, t2m_replayed_us=t2, t1m_fp32_us=c, q1m_replayed_us=d, q1m_rotating_us=e)), flush=True)
+    big = {}
+    if os.environ.get("AB_BIG") == "1":        # the 4 x 10^6-element extras of bench.py (several resident rounds per launch)
+        cfg5 = structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=f64)
+        r, ro = case(cfg5, f64, False, 3, 8)
+        big = dict(cfg5auto_replayed_us=r, cfg5auto_rotating_us=ro)
+    print(json.dumps(dict(lib=lib_name, **big, t1m_replayed_us=a, t1m_rotating_us=b, t1m_adam_step_us=f, t2m_replayed_us=t2, t1m_fp32_us=c, q1m_replayed_us=d, q1m_rotating_us=e)), flush=True)
 
 
 def main():
@@ -116,7 +121,7 @@ def main():
     res = {l: [] for l in libs}
     for r in range(rounds):
         for l in libs:
-            out = subprocess.run([sys.executable, __file__, "--child", l], capture_output=True, text=True, timeout=400)
+            out = subprocess.run([sys.executable, __file__, "--child", l], capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(out.stderr[-2000:], file=sys.stderr)
                 return 1

@@ -262,6 +262,14 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr)
 
+    wall = {}                                    # section -> seconds since start when it finished (rank 0's clock) -> config.wall_s
+
+    def progress(section):
+        """One stderr line per finished section with the elapsed time: a driver log shows where an N-rank run spends its limit."""
+        wall[section] = round(time.perf_counter() - t_start, 1)
+        if rank == 0:
+            print(f"[bench] {wall[section]:7.1f} s  {section}", file=sys.stderr, flush=True)
+
     for kv in a.option:
         name, val = kv.split("=")
         _lib.check(L.hfem_set_option(name.encode(), int(val)), "hfem_set_option")
@@ -598,6 +606,7 @@ def main():
                                 per_rank_model_plan_and_sharded_plan=got, blob_bytes=int(plan.to_bytes().size) if rank == 0 else None,
                                 model_and_plans_s=round(time.perf_counter() - t_plan0, 2))
 
+    progress("mesh, model, host plans")
     if world > 1:
         sh.setup_interfaces()
         sh.init_owner_adam(lr_x=1e-9, lr_u=1e-12, fused=True)      # tiny steps: the mesh stays valid over any number of iterations
@@ -640,6 +649,7 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
+    progress("headline step timed")
     # ---- N = 1, reported beside the headline: the step of a caller that needs ITS OWN loss before it goes on (a line
     #      search, an L-BFGS check): the 1-block reduction launched right after every energy launch, on the critical path
     inline_step = None
@@ -727,6 +737,8 @@ def main():
         else:
             note("fused training legs skipped: --steps must be even (ping-pong parameter buffers inside one hipGraph)")
 
+    if world > 1:
+        progress("collective-path legs")
     # ---- N > 1: the same steps with the interface rows written straight into the peers' receive windows (csrc/peer.hip): no
     #      collective, no second stream.  Verified in this run against the collective path before anything is timed; a failure
     #      (IPC mapping, a flag that never arrives) is reported in notes and the legs are dropped -- never a silent fallback.
@@ -786,6 +798,8 @@ def main():
             sh.close_peer_exchange(check=False)
         peer_on[0] = False
 
+    if world > 1 and not a.no_peer:
+        progress("peer-window legs")
     # ---- N > 1: Example 4's own optimiser, node-sharded (weak: N x 10^6 elements, every rank keeps 2 x 10^6 parameters' history)
     if world > 1 and not a.no_lbfgs:
         try:
@@ -796,6 +810,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             note(f"lbfgs_step leg failed: {type(e).__name__}: {str(e)[:160]}")
 
+    if world > 1 and not a.no_lbfgs:
+        progress("sharded L-BFGS leg (weak)")
     # ---- N > 1: BASELINE configs[3] / [4] as stated -- a FIXED mesh sharded over the N ranks (strong scaling)
     def strong_leg(name, mesh6_s):
         m_s = staged(lambda: build_model(mesh6_s))
@@ -869,6 +885,8 @@ def main():
             strong.append(strong_leg("cfg5u FIXED (BASELINE configs[4]): ~4.1 x 10^6 TRI3 Delaunay mesh sharded over the ranks",
                                      unstructured_tri_mesh(2_050_000, seed=2, dtype=f64)))
 
+    if world > 1 and not a.no_strong:
+        progress("strong-scaling legs")
     # ------------------------------------------------------------------------------------------------ roofline legs
     kreps = max(a.steps, 200)      # kernel-only legs: >= 200 launches per graph whatever --steps is (amortises the ~20 us graph launch)
     ko_main = KernelOnly(model, loss_fn, plan, lo, hi)
@@ -1023,6 +1041,8 @@ def main():
                                "; this rank's tile range of the weak-scaling mesh"),
                         alg_bytes_per_launch=alg_bytes, elems_per_launch=ne_launch, nodes_per_launch=nn_launch)
 
+    if world == 1:
+        progress("roofline legs (regimes, in-run PMC traffic)")
     # ---- config.extra (N = 1): the other readings of "1 M quad elements" and BASELINE config 5, kernel only, each with
     #      its own roofline figures (algorithmic bytes of ITS element type over ITS kernel's average launch time) in the HBM
     #      regime (rotating sets; `replayed_*` = the same buffers every launch):
@@ -1106,6 +1126,8 @@ def main():
             print(json.dumps(dict(only_extra=a.only_extra, extras=extras)), flush=True)
         return None
 
+    if world == 1:
+        progress("config.extra workloads")
     # ---- config.fp32_rows (N = 1): T1M as the reference would run it by default -- an fp32 model (src/loss.py:16,
     #      src/models.py:274): float rows widened on load, gradients rounded once on store, fp64 arithmetic and loss; kernel
     #      only, its own algorithmic bytes (12 Ne + 32 Nn + 8)
@@ -1218,6 +1240,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             note(f"train_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
 
+    if world == 1:
+        progress("fp32 rows, training-step legs")
     # ---- N = 1: Example 4's optimiser at full size -- LBFGS as the reference drives it (examples/example4.py:68-78: lr 1, max_iter 20,
     #      history 100, no line search) on T1M.  With the history full an inner iteration streams the 2 x 100 history vectors twice
     #      (multidot + direction passes, csrc/lbfgs.hip): 4 h n 8 B = 6.4 GB -- the optimiser, not the 9 us energy launch, is the iteration.
@@ -1273,6 +1297,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             note(f"lbfgs_sharded_emulated leg failed: {type(e).__name__}: {str(e)[:160]}")
 
+    if world == 1:
+        progress("L-BFGS legs")
     # ---- N = 1: what the owner-sharded step machinery costs on ONE rank (no peer to talk to: every microsecond above the
     #      plain iteration is overhead of the exchange path) -- all_gather stand-in on one stream, the side-stream overlap,
     #      and the peer-window put / get; plain and fused (Adam inside the energy launch); K iterations per hipGraph.
@@ -1309,6 +1335,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             note(f"sharded_step_1gpu leg failed: {type(e).__name__}: {str(e)[:160]}")
 
+    if world == 1:
+        progress("owner-sharded steps on one rank")
     out = None
     if rank == 0:
         cpu = None
@@ -1317,6 +1345,7 @@ def main():
             rel = abs(loss_cpu - loss_gpu) / abs(loss_cpu)
             assert rel <= 1e-12, f"GPU loss {loss_gpu!r} != oracle loss {loss_cpu!r} (rel {rel:.2e})"
             cpu["loss_rel_err_vs_gpu"] = rel
+        progress("cpu_baseline" if cpu is not None else "done")
         st = plan.stats
         out = dict(
             metric="element-evals/sec (fwd+bwd energy) + achieved HBM GB/s, 2D quad mesh",
@@ -1382,6 +1411,8 @@ def main():
             out["config"]["lbfgs_sharded_emulated"] = lbfgs_emu
         if notes:
             out["config"]["notes"] = notes
+        out["config"]["wall_s"] = dict(wall, what="seconds since the start of main() when each section finished (rank 0); the stderr "
+                                                  "lines `[bench] <s> s  <section>` carry the same")
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

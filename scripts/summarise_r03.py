@@ -23,8 +23,8 @@ if bench is not None:
         shapes[e["key"]] = (f"{e['elements']}/{e['nodes']}/{e['tiles']}", e["alg_bytes_per_launch"])
 ALG = 12 * 1000000 + 64 * 501501 + 8
 if os.path.exists(os.path.join(src, "kernel_stats_replayed.csv")):
-    out = {"source": "rocprofv3 --kernel-trace --stats on `bench.py --no-cpu-baseline --only-regime <r>` (scripts/prof_r03.sh), MI355X, "
-                     "round 3; hipGraph launches traced",
+    out = {"source": "rocprofv3 --kernel-trace --stats on `bench.py --no-cpu-baseline --only-regime <r>` (scripts/prof_r03.sh / prof_r04.sh), MI355X; "
+                     "hipGraph launches traced",
            "shape": shapes.get("T1M", ("1000000/501501/1024",))[0], "alg_bytes_per_launch": ALG, "regimes": {}}
     for r in ("replayed", "rewritten_inputs", "rotating_sets"):
         rows = [x for x in csv.DictReader(open(os.path.join(src, f"kernel_stats_{r}.csv"))) if "tri3_energy_" in x["Name"]]

@@ -170,3 +170,86 @@ def test_tiny_models_through_every_planned_entry_point():
         assert abs(l0 - l1) <= 1e-12 * abs(l1)
     assert torch.allclose(models[0].u_free, models[1].u_free, rtol=1e-12, atol=0)
     assert torch.allclose(models[0].node_coords_free, models[1].node_coords_free, rtol=1e-13, atol=0)
+
+
+@pytest.mark.gpu
+def test_fp32_arithmetic_kernel_on_degenerate_paired_plans():
+    """hfem_tri3_energy_plan_f32 + HFEM_FLAG_FP32_MATH (csrc/tri3_pair_f32.hip) on paired plans that are almost entirely stride
+    padding: no element at all (zero energy, every row written with zeros), one unpaired element, one split quad (one full
+    pair), and the pair among 700 unreferenced nodes -- against the C closed forms in fp64 on the same float values."""
+    from hidenn_fem_amd import _lib
+    from hidenn_fem_amd.plan import TilePlan
+    from oracle import closed_form as CF
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    dv = lambda a: (C.c_double * len(a))(*a)
+    mat, W = CF.plane_stress(), 0.25
+    rng = np.random.default_rng(1)
+    cases = {
+        "no elements": (np.zeros((0, 3), dtype=np.int64), 40),
+        "one element": (np.array([[0, 1, 2]], dtype=np.int64), 3),
+        "one pair": (np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int64), 4),
+        "one pair + orphans": (np.array([[5, 9, 2], [5, 2, 700]], dtype=np.int64), 703),
+    }
+    for name, (conn, nn) in cases.items():
+        X = rng.random((nn, 2)).astype(np.float32)
+        quad = np.array([[0.0, 0.0], [1.0, 0.1], [1.1, 1.0], [0.1, 0.9]], dtype=np.float32)      # a proper quad for the element cases
+        X[:min(nn, 4)] = quad[:min(nn, 4)]
+        if nn > 700:
+            X[[5, 9, 2, 700]] = quad
+        U = (1e-3 * rng.standard_normal((nn, 2))).astype(np.float32)
+        plan = TilePlan(conn, nn, coords_hint=X.astype(np.float64), edges=np.zeros((0, 2), dtype=np.int64), device=d, elem_order=5)
+        assert plan.stats["paired"] == 1, name
+        Xd, Ud = torch.from_numpy(X).to(d), torch.from_numpy(U).to(d)
+        loss = torch.full((), 7.0, dtype=F64, device=d)
+        gX, gU = torch.full_like(Xd, float("nan")), torch.full_like(Ud, float("nan"))
+        _lib.check(L.hfem_tri3_energy_plan_f32(plan.handle, Xd.data_ptr(), None, Ud.data_ptr(), None, dv(mat), W, dv([0.0] * 6),
+                                               None, dv([0.0] * 4), 0, -1, loss.data_ptr(), gX.data_ptr(), gU.data_ptr(), 1024, st))
+        torch.cuda.synchronize()
+        if conn.shape[0]:
+            e_ref, gX_ref, gU_ref = CF.tri3_energy(X.astype(np.float64), U.astype(np.float64), conn, mat, W)
+        else:
+            e_ref, gX_ref, gU_ref = 0.0, np.zeros((nn, 2)), np.zeros((nn, 2))
+        assert abs(loss.item() - e_ref) <= 2e-6 * max(abs(e_ref), 1e-300), (name, loss.item(), e_ref)
+        assert not torch.isnan(gX).any() and not torch.isnan(gU).any(), name                        # every row written
+        assert np.abs(gX.double().cpu().numpy() - gX_ref).max() <= 4e-6 * max(np.abs(gX_ref).max(), 1e-300), name
+        assert np.abs(gU.double().cpu().numpy() - gU_ref).max() <= 4e-6 * max(np.abs(gU_ref).max(), 1e-300), name
+        plan.close()
+
+
+@pytest.mark.gpu
+def test_sharded_lbfgs_on_a_tiny_model_matches_fused_lbfgs():
+    """ShardedLBFGS (one rank, eager and with the steady-state iteration as a hipGraph) on a four-triangle model -- 8 owned
+    parameters, history far longer than the problem is wide, tiles that are all padding: same losses and parameters as
+    FusedLBFGS on the same energy."""
+    from hidenn_fem_amd.loss import EnergyLoss2D
+    from hidenn_fem_amd.models import PiecewiseLinearShapeNN2D
+    from hidenn_fem_amd.optim import FusedLBFGS, ShardedLBFGS
+    from hidenn_fem_amd.sharded import ShardedTri3Energy
+    d = torch.device("cuda:0")
+    coords = torch.tensor([[0.0, 0.0], [1.0, 0.0], [1.1, 0.9], [0.0, 1.0], [2.0, 0.1], [2.1, 1.2]], dtype=F64)
+    bc = torch.tensor([True, False, False, True, False, False])
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3], [1, 4, 5], [1, 5, 2]])
+    edges = torch.tensor([[4, 5]])
+
+    def model():
+        torch.manual_seed(5)
+        m = PiecewiseLinearShapeNN2D(coords, tri, boundary_mask=None, dirichlet_mask=bc, u_fixed=0.0, neumann_edges=edges).double().to(d)
+        with torch.no_grad():
+            m.u_free.mul_(1e-3)
+        return m
+
+    lf = EnergyLoss2D(E=10.0, nu=0.3, device=d, dtype=F64)
+    ref_m = model()
+    ref = FusedLBFGS(ref_m.parameters())
+    ref_l = [ref.step(lambda: lf.value_and_grad_(ref_m)).item() for _ in range(3)]
+    for graph in (False, True):
+        m = model()
+        opt = ShardedLBFGS(ShardedTri3Energy(m, lf).setup_interfaces(), graph=graph)
+        got = [opt.step().item() for _ in range(3)]
+        opt.finish()
+        np.testing.assert_allclose(got, ref_l, rtol=1e-9, atol=1e-14, err_msg=f"graph={graph}")
+        assert opt.state["func_evals"] == ref.state[ref._params[0]]["func_evals"], graph
+        assert torch.allclose(m.u_free, ref_m.u_free, rtol=1e-7, atol=1e-12), graph
+        assert torch.allclose(m.node_coords_free, ref_m.node_coords_free, rtol=1e-9, atol=1e-12), graph

@@ -361,7 +361,7 @@ struct PairLaunch {
 int launch_tri3_pair(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,
                      const AdamFuse &af);
 // tri3_pair_f32.hip: the paired-slot pass in fp32 ARITHMETIC on float rows (HFEM_FLAG_FP32_MATH); 1 = launched, 0 = no instance
-int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const LagSum &lag);
+int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const LagSum &lag, const AdamFuse *adam = nullptr);
 #ifdef HFEM_LAB
 // tri3_pair_lab.hip (lab build only): the instrumented copy of the paired-slot kernel (ablation bits, forced slot loops)
 int launch_tri3_pair_lab(const hfem_plan *plan, PairLaunch A, int mode, bool hasb, bool phys, const LagSum &lag,

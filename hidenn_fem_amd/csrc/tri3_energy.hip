@@ -1169,6 +1169,11 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
                    "fused Adam step: needs tiles of <= 1024 nodes / 2048 element slots");
     HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_NO_GX | HFEM_FLAG_NO_GU)), "fused Adam step updates both parameter tensors");
     HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PHYSICAL_GRAD | HFEM_FLAG_DETERMINISTIC)), "fused Adam step: reference convention, atomic accumulation");
+    if (flags & HFEM_FLAG_FP32_MATH) {
+        HFEM_ARG_CHECK(dtype == 1, "HFEM_FLAG_FP32_MATH: fp32 rows (dtype 1)");
+        HFEM_ARG_CHECK(plan->host.paired && plan->host.n_chained == 0, "HFEM_FLAG_FP32_MATH: paired-slot plans only (this mesh's plan keeps one element per slot: drop the flag)");
+        HFEM_ARG_CHECK(!(flags & (HFEM_FLAG_PEER_GET | HFEM_FLAG_PEER_PUT)), "HFEM_FLAG_FP32_MATH: no in-launch get / put (the sharded steps run the fp64-arithmetic float-row instances)");
+    }
     bool hasb = false;
     for (int i = 0; i < 6; ++i) hasb = hasb || (Bk && Bk[i] != 0.0);
     if (int rc = use_device(plan->device)) return rc;
@@ -1236,6 +1241,10 @@ extern "C" int hfem_tri3_energy_adam_step_ex(hfem_plan *plan, int32_t dtype, con
             P.grid = grid; P.tile_begin = tile_begin;
             P.x_free = x_free; P.x_fixed = x_fixed; P.u_free = u_free; P.u_fixed = u_fixed;
             P.k = A.k; P.T_edge = A.T_edge; P.tc = A.tc; P.partials = pbase; P.skip_edges = A.skip_edges; P.s = s;
+            if (flags & HFEM_FLAG_FP32_MATH) {          // fp32 rows AND fp32 arithmetic (csrc/tri3_pair_f32.hip, ADAM instances)
+                HFEM_ARG_CHECK(launch_tri3_pair_f32(plan, P, hasb, lag, &af) == 1,
+                               "HFEM_FLAG_FP32_MATH: tile shape outside the fp32 pair kernel's instances");
+            } else
             HFEM_ARG_CHECK(launch_tri3_pair(plan, P, dtype == 0 ? 3 : 4, hasb, false, lag, af) == 1,
                            "paired plan: tile shape outside the pair kernel's instances");
         } else {

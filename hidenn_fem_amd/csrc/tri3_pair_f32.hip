@@ -105,13 +105,15 @@ __device__ __forceinline__ f2 tri3_pair_f32(const f2 X0x, const f2 X0y, const f2
 // BLOCK threads per tile; NPT >= ceil(max nodes / BLOCK), EPT >= ceil(max slots / BLOCK); CAPO / CAPN > 0: compile-time LDS
 // strides of the default tile shape.  SP: cache policy of the gradient stores (16 sc1 write-through, 2 nt).  LDS:
 // float4 nd[cap_n] | double acc[4][cap_owned] | double red[BLOCK / 64].
-template <int BLOCK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_f32_kernel(
+// ADAM: the write-out applies torch.optim.Adam's update to the rows the tile owns instead of storing the gradient
+// (hfem_tri3_energy_adam_step_ex with HFEM_FLAG_FP32_MATH; arithmetic = adam_fused_row<float2>, the float-row instance's).
+template <int BLOCK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB, bool ADAM = false>
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : (ADAM && EPT > 4 ? 4 : 5)) void tri3_energy_pair_f32_kernel(
     PlanDev pd, int tile_begin, const float2 *__restrict__ x_free, const float2 *__restrict__ x_fixed,
     const float2 *__restrict__ u_free, const float2 *__restrict__ u_fixed, Tri3ConstsF k,
     const double4 *__restrict__ T_edge, double4 Tconst, double *__restrict__ partials,
     float2 *__restrict__ gx_free, float2 *__restrict__ gu_free, int cap_nodes, int cap_owned_rt, int skip_edges,
-    LagSum lag, int col_stride) {
+    LagSum lag, int col_stride, AdamFuse af) {
     const int cap_owned = CAPO > 0 ? CAPO : cap_owned_rt;
     const int cap_n = CAPN > 0 ? CAPN : cap_nodes;
     extern __shared__ float4 lds4[];
@@ -226,6 +228,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // all loads returned long ago: no per-store vmcnt waits below
     __syncthreads();
 
+    if constexpr (ADAM) {
+        // the tile owns the row: complete gradient (acc*) and current value (nd) are in LDS -- m, v read-modify-written, the NEW
+        // row to the OTHER parameter buffer (ping-pong); the gradient is rounded to float once, as the store below would
+        const double bc1 = af.bc[0], sqrt_bc2 = af.bc[1];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int l = tid + j * BLOCK;
+            if (l < n_owned) {
+                const float4 v = nd[l];
+                if (s[j].x >= 0) adam_fused_row<float2>(af, 0, s[j].x, acc0[l], acc1[l], make_double2((double)v.x, (double)v.y), bc1, sqrt_bc2);
+                if (s[j].y >= 0) adam_fused_row<float2>(af, 1, s[j].y, acc2[l], acc3[l], make_double2((double)v.z, (double)v.w), bc1, sqrt_bc2);
+            }
+        }
+    } else {
     // ---- every owned gradient row is written exactly once
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)gx_free, 0, 0x7FFFFFF0, 0x00020000);
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
             }
         }
     }
+    }   // !ADAM
     if (tid == 0) {                                     // fixed order: the tile energy is bit-reproducible for given gradients
         double tile_e = 0.0;
 #pragma unroll
@@ -252,18 +269,19 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 3 : 5) void tri3_energy_pair_
     }
 }
 
-template <int BLK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB>
-static void launch_pair_f32_inst(const PairLaunch &A, const Tri3ConstsF &kf, const LagSum &lag) {
+template <int BLK, int NPT, int EPT, int CAPO, int CAPN, int SP, bool HASB, bool ADAM = false>
+static void launch_pair_f32_inst(const PairLaunch &A, const Tri3ConstsF &kf, const LagSum &lag, const AdamFuse &af = AdamFuse{}) {
     const int cap_n = CAPN > 0 ? CAPN : ((A.max_nodes + 1) & ~1), cap_o = CAPO > 0 ? CAPO : ((A.max_owned + 1) & ~1);
     const size_t lds = (size_t)cap_n * 16 + (size_t)cap_o * 32 + 8 * (BLK / 64);
-    hipLaunchKernelGGL((tri3_energy_pair_f32_kernel<BLK, NPT, EPT, CAPO, CAPN, SP, HASB>), dim3(A.grid), dim3(BLK), lds, A.s, A.pd,
+    hipLaunchKernelGGL((tri3_energy_pair_f32_kernel<BLK, NPT, EPT, CAPO, CAPN, SP, HASB, ADAM>), dim3(A.grid), dim3(BLK), lds, A.s, A.pd,
                        A.tile_begin, (const float2 *)A.x_free, (const float2 *)A.x_fixed, (const float2 *)A.u_free,
                        (const float2 *)A.u_fixed, kf, A.T_edge, A.tc, A.partials, (float2 *)A.gx, (float2 *)A.gu, cap_n, cap_o,
-                       A.skip_edges, lag, A.col_stride);
+                       A.skip_edges, lag, A.col_stride, af);
 }
 
 // Launch on a paired plan without chained records; 1 = launched, 0 = no instance holds the plan's tile shape.
-int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const LagSum &lag) {
+// adam != NULL: the fused optimiser step (instances of the plain shapes; a body force takes the generic one).
+int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const LagSum &lag, const AdamFuse *adam) {
     const HostPlan &h = plan->host;
     if (!h.paired || !plan->d_elem_pack_hi || h.n_chained > 0 || lag.pg_blocks) return 0;
     A.pd = plan_dev(plan);
@@ -273,6 +291,20 @@ int launch_tri3_pair_f32(const hfem_plan *plan, PairLaunch A, bool hasb, const L
     kf.c11 = (float)A.k.c11; kf.c12 = (float)A.k.c12; kf.c22 = (float)A.k.c22; kf.c33 = (float)A.k.c33; kf.W = (float)A.k.W;
     for (int i = 0; i < 6; ++i) kf.Bk[i] = (float)A.k.Bk[i];
     const int ept = h.max_rows > 0 ? h.max_rows : 1;
+    if (adam) {
+        if (h.pair_block == 512) {
+            if (h.max_nodes > 2 * 512 || ept > 2) return 0;
+            if (hasb) launch_pair_f32_inst<512, 2, 2, 0, 0, 16, true, true>(A, kf, lag, *adam);
+            else launch_pair_f32_inst<512, 2, 2, 0, 0, 16, false, true>(A, kf, lag, *adam);
+            return 1;
+        }
+        if (h.max_nodes > 4 * 256 || ept > 6) return 0;
+        if (hasb) launch_pair_f32_inst<256, 4, 6, 0, 0, 16, true, true>(A, kf, lag, *adam);
+        else if (h.max_owned <= 560 && h.max_nodes <= 656 && ept <= 3) launch_pair_f32_inst<256, 3, 3, 560, 656, 16, false, true>(A, kf, lag, *adam);
+        else if (h.max_nodes <= 3 * 256 && ept <= 3) launch_pair_f32_inst<256, 3, 3, 0, 0, 16, false, true>(A, kf, lag, *adam);
+        else launch_pair_f32_inst<256, 4, 6, 0, 0, 16, false, true>(A, kf, lag, *adam);
+        return 1;
+    }
     if (h.pair_block == 512) {
         if (h.max_nodes > 2 * 512 || ept > 2) return 0;
         if (hasb) launch_pair_f32_inst<512, 2, 2, 0, 0, 16, true>(A, kf, lag);

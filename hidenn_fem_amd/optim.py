@@ -618,7 +618,8 @@ class EnergyAdamStep:
     The new parameter rows go to a second buffer (tiles that are still gathering must see the old ones); ``step()``
     swaps ``param.data`` between the two after every launch.  Same arithmetic as ``FusedAdam`` / ``torch.optim.Adam``
     (betas, eps, bias correction; one learning rate per tensor: ``lr_x`` for ``node_coords_free``, ``lr_u`` for
-    ``u_free``).  TRI3 models in fp64 or fp32, optional body force, constant traction, whole mesh on one GPU.  Capture-safe: use
+    ``u_free``).  TRI3 models in fp64 or fp32 (an fp32 model runs fp32 ARITHMETIC too unless the loss was built with
+    ``arithmetic="fp64"``), optional body force, constant traction, whole mesh on one GPU.  Capture-safe: use
     ``GraphedTraining(trainer.step, None, steps_per_replay=<even>, direct=True)``."""
 
     def __init__(self, model, loss_fn, lr_x, lr_u, betas=(0.9, 0.999), eps=1e-8, b_force=None):
@@ -652,6 +653,10 @@ class EnergyAdamStep:
         self._xfix = model.node_coords_fixed.to(xf.dtype).contiguous()
         self._ufix = model.u_fixed_rows().to(xf.dtype).contiguous()
         self._flags = 0 if model.N_edges else 4          # HFEM_FLAG_NO_EDGES
+        # fp32 models: fp32 arithmetic as well (HFEM_FLAG_FP32_MATH, csrc/tri3_pair_f32.hip) when the loss says so
+        # (EnergyLoss2D(arithmetic="auto" | "fp32") on a paired-slot plan; "fp64" keeps the accurate float-row instance)
+        if self._dtype == 1 and loss_fn._f32_math(model, self.plan, 0):
+            self._flags |= 1024
         self.k = 0
 
     # lagged loss (HFEM_FLAG_SUM_PREVIOUS): iteration k's energy is reduced by an extra workgroup of launch k+1

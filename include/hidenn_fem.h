@@ -164,7 +164,7 @@ int hfem_plan_deserialize(int device, const void *blob, int64_t n_bytes, hfem_pl
 #define HFEM_FLAG_PEER_PUT 2048  /* hfem_tri3_energy_adam_step_ex with HFEM_FLAG_PEER_GET, after hfem_plan_set_peer_put: the launch also PUBLISHES --
                                  * its boundary tiles store the new rows of their interface nodes into every rank's window at
                                  * write-out and the last of them completes the put: one launch per owner-sharded training step */
-#define HFEM_FLAG_FP32_MATH 1024 /* hfem_tri3_energy_plan_f32 only: fp32 ARITHMETIC as well as fp32 rows -- what the reference itself
+#define HFEM_FLAG_FP32_MATH 1024 /* hfem_tri3_energy_plan_f32, hfem_tri3_energy_adam_step_ex(dtype 1): fp32 ARITHMETIC as well as fp32 rows -- what the reference itself
                                  * computes in for its default dtype (src/loss.py:16): packed-fp32 element math (the two elements of
                                  * a slot side by side), float LDS accumulators; the tile energies and the loss stay fp64.  Paired-slot
                                  * plans; body force, tile ranges, NO_LOSS_SUM / SUM_PREVIOUS / SAME_BANK as the fp64 entry point. */

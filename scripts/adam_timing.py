@@ -44,6 +44,10 @@ for dt in (f64, torch.float32):
     m2 = model(dt)
     tr = EnergyAdamStep(m2, lf, lr_x=1e-9, lr_u=1e-12)
     print(dt, "one-launch EnergyAdamStep:        %.2f us/iteration" % timeit(GraphedTraining(tr.step_lagged, None, steps_per_replay=K, direct=True, begin=tr.begin_lagged, end=tr.flush_loss)), flush=True)
+    if dt == torch.float32:          # the same one-launch step with fp64 arithmetic on the float rows (round 3's instance)
+        m4 = model(dt)
+        tr4 = EnergyAdamStep(m4, EnergyLoss2D(device=d, dtype=dt, arithmetic="fp64"), lr_x=1e-9, lr_u=1e-12)
+        print(dt, "one-launch, fp64 arithmetic:      %.2f us/iteration" % timeit(GraphedTraining(tr4.step_lagged, None, steps_per_replay=K, direct=True, begin=tr4.begin_lagged, end=tr4.flush_loss)), flush=True)
     m3 = model(dt)
     only = FusedAdam([dict(params=[m3.node_coords_free], lr=1e-9), dict(params=[m3.u_free], lr=1e-12)], capturable=True)
     lf.value_and_grad_(m3)

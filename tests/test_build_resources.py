@@ -30,5 +30,7 @@ def test_no_kernel_uses_scratch_and_the_instance_matrix_is_bounded():
     # the graded instance keeps its shape: 256 threads, <= 96 VGPRs (five waves per SIMD would fit), four workgroups per CU by LDS
     graded = [v for k, v in use.items() if "tri3_energy_pair_kernelILi256ELi3ELi3ELi4ELi560ELb0ELb0E15HIP_vector_typeIdLj2EELb0ELb0ELi656ELi16ELb0E" in k]
     assert len(graded) == 1 and graded[0]["vgprs"] <= 96 and graded[0]["occupancy"] >= 4, graded
-    f32 = [v for k, v in use.items() if "tri3_energy_pair_f32_kernelILi256ELi3ELi3ELi560ELi656ELi16ELb0E" in k]
-    assert len(f32) == 1 and f32[0]["vgprs"] <= 96, f32
+    # <BLOCK, NPT, EPT, CAPO, CAPN, SP, HASB, ADAM>: the fp32-arithmetic instance of the default tile, plain and with the fused Adam write-out
+    for adam in (0, 1):
+        f32 = [v for k, v in use.items() if f"tri3_energy_pair_f32_kernelILi256ELi3ELi3ELi560ELi656ELi16ELb0ELb{adam}EE" in k]
+        assert len(f32) == 1 and f32[0]["vgprs"] <= 96 and f32[0]["occupancy"] >= 5, (adam, f32)

@@ -357,6 +357,40 @@ def test_fused_energy_adam_step_fp32_rows_and_body_force(mesh_kw):
             assert (pa - pb).abs().max().item() <= 4 * torch.finfo(torch.float32).eps * pa.abs().max().item()
             assert (pa == pb).float().mean().item() > 0.98
         assert (b32.u_free - base32.u_free).abs().max().item() > 0
+    # ---- fp32 rows AND fp32 arithmetic (round 4: HFEM_FLAG_FP32_MATH in the fused step, csrc/tri3_pair_f32.hip ADAM instances):
+    #      what EnergyLoss2D(arithmetic="auto") selects for an fp32 model on a paired plan -- against the two-launch loop on the
+    #      same arithmetic (the fp32-arithmetic energy kernel + FusedAdam), and close to the fp64-arithmetic trajectory above
+    lf32a = EnergyLoss2D(device=d, dtype=torch.float32)
+    for bf in (None, b_force_fn):
+        b32 = copy.deepcopy(base32)
+        tr32 = EnergyAdamStep(b32, lf32a, lr_x=lr_x, lr_u=lr_u, b_force=bf)
+        assert bool(tr32._flags & 1024) == (not mesh_kw), "fp32 arithmetic exactly when the plan has paired slots"
+        a32 = copy.deepcopy(base32)
+        o32 = FusedAdam([dict(params=[a32.node_coords_free], lr=lr_x), dict(params=[a32.u_free], lr=lr_u)])
+        ref32 = []
+        for _ in range(n_steps):
+            o32.zero_grad()
+            loss = lf32a(a32, b_force=bf)
+            loss.backward()
+            ref32.append(loss.double().item())
+            o32.step()
+        got32 = [tr32.step().item() for _ in range(n_steps)]
+        np.testing.assert_allclose(got32, ref32, rtol=2e-6)
+        for pa, pb in zip(a32.parameters(), b32.parameters()):
+            assert (pa - pb).abs().max().item() <= 4 * torch.finfo(torch.float32).eps * pa.abs().max().item()
+            assert (pa == pb).float().mean().item() > 0.98
+        # captured: K iterations per hipGraph continue the same trajectory
+        from hidenn_fem_amd.graphed import GraphedTraining
+        gt = GraphedTraining(tr32.step, None, steps_per_replay=4, direct=True, warmup=2)      # 2 eager iterations, then 4 per replay
+        gt.replay()
+        torch.cuda.synchronize()
+        for _ in range(6):
+            o32.zero_grad()
+            loss = lf32a(a32, b_force=bf)
+            loss.backward()
+            o32.step()
+        for pa, pb in zip(a32.parameters(), b32.parameters()):
+            assert (pa - pb).abs().max().item() <= 8 * torch.finfo(torch.float32).eps * pa.abs().max().item()
 
 
 @pytest.mark.gpu

@@ -212,7 +212,8 @@ def test_fp32_model_owner_sharded_steps_one_rank():
     third = lambda sh: sh.plan.n_tiles // 3
     n = 8
     m0 = _model(d).float()
-    tr = EnergyAdamStep(m0, EnergyLoss2D(device=d, dtype=torch.float32), lr_x=LR_X, lr_u=LR_U)
+    # the sharded steps compute in fp64 on float rows: so does the unsharded step they are held against (arithmetic="fp64")
+    tr = EnergyAdamStep(m0, EnergyLoss2D(device=d, dtype=torch.float32, arithmetic="fp64"), lr_x=LR_X, lr_u=LR_U)
     l0 = [tr.step().item() for _ in range(n)]
     for name, over in (("owner_train_step_fused", False), ("owner_train_step_fused_overlapped", True)):
         for peer in (False, True):

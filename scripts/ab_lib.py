@@ -3,7 +3,7 @@
 processes on the same box: the T1M paired kernel (same buffers / rotating sets), its fp32-arithmetic instance and the Q1M
 QUAD4 kernel, kernel only (hipGraph of K launches between HIP events, median of 5).
 
-    python scripts/ab_lib.py libhidenn_hip.so libhidenn_hip_noprio.so [rounds]
+    python scripts/ab_lib.py libhidenn_hip.so libhidenn_hip_noprio.so [more .so ...] [rounds]
 """
 import ctypes as C
 import json
@@ -115,7 +115,8 @@ def child(lib_name):
 def main():
     if sys.argv[1] == "--child":
         return child(sys.argv[2])
-    libs, rounds = sys.argv[1:3], int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    libs = [v for v in sys.argv[1:] if v.endswith(".so")]
+    rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
     os.environ.setdefault("HFEM_PLAN_CACHE", "/tmp/hfem_plan_cache")
     os.makedirs(os.environ["HFEM_PLAN_CACHE"], exist_ok=True)
     res = {l: [] for l in libs}

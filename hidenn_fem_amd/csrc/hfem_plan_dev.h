@@ -258,7 +258,8 @@ __device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSu
 // of a tile that finishes while its neighbours compute.  s_setprio raises the wave over the arithmetic ones for exactly those
 // stretches: the memory requests go out earlier and overlap the neighbours' arithmetic.  Measured (scripts/quad4_lab.py --bits,
 // scripts/ab_lib.py, profiles/r04/ab_mem_prio.jsonl): Q1M 22.3 -> 21.8 us (rotating sets 22.5 -> 21.8; 22.3 -> 21.1 in the lab sweep), the paired fp64 TRI3 kernel
-// 8.82 -> 8.72 us, T2M and the fused Adam step unchanged; the fp32-arithmetic kernel (shorter slot loop) loses 1 % and does not use it.  HFEM_MEM_PRIO = 0 compiles it out.
+// 8.82 -> 8.72 us, T2M and the fused Adam step unchanged; the fp32-arithmetic kernel (shorter slot loop) loses 1 % and the
+// one-element-per-slot kernel gains nothing (zigzag 11.1 -> 11.3, Delaunay 4 M unchanged; ab_mem_prio_one_element_per_slot.jsonl): neither uses it.  HFEM_MEM_PRIO = 0 compiles it out.
 #ifndef HFEM_MEM_PRIO
 #define HFEM_MEM_PRIO 3
 #endif

@@ -109,6 +109,11 @@ def child(lib_name):
         cfg5 = structured_tri_mesh(2001, 1001, jitter=0.3, seed=11, diagonal="random", permute=True, dtype=f64)
         r, ro = case(cfg5, f64, False, 3, 8)
         big = dict(cfg5auto_replayed_us=r, cfg5auto_rotating_us=ro)
+    if os.environ.get("AB_UNPAIRED") == "1":   # one element per slot (tri3_energy_fast_kernel): zigzag diagonals at T1M size, Delaunay at 4 M
+        z, zo = case(structured_tri_mesh(1001, 501, length=2.0, height=1.0, jitter=0.2, seed=0, dtype=f64, diagonal="zigzag"), f64, False, 10, 8)
+        from hidenn_fem_amd.mesh import unstructured_tri_mesh
+        dl, dlo = case(unstructured_tri_mesh(2_050_000, seed=2, dtype=f64), f64, False, 3, 8)
+        big.update(zigzag_replayed_us=z, zigzag_rotating_us=zo, cfg5u_replayed_us=dl, cfg5u_rotating_us=dlo)
     print(json.dumps(dict(lib=lib_name, **big, t1m_replayed_us=a, t1m_rotating_us=b, t1m_adam_step_us=f, t2m_replayed_us=t2, t1m_fp32_us=c, q1m_replayed_us=d, q1m_rotating_us=e)), flush=True)
 
 

@@ -100,8 +100,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void tri3_energy_pair_kernel(
         }
     }
     if constexpr (PG) {
-        if (tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end)
+        if (tile_begin + slot >= lag.wait_begin && tile_begin + slot < lag.wait_end) {
+            mem_phase_end();                            // a spinning wave must not outrank the service workgroups it waits for
             peer_wait_unpacked(*lag.pg);                // a boundary tile: the rows it reads from other ranks are being copied in
+            mem_phase_begin();
+        }
     }                                                   // (its row maps and slot records are already on their way)
     // ---- gather through the row maps: issued before anything that needs the descriptor (program order = vmcnt order)
     V2 vx[NPT], vu[NPT];

@@ -534,17 +534,41 @@ def main():
         nn_ = int(td[lo:hi, 4].sum())
         return ne_, nn_, 12 * ne_ + 64 * nn_ + 8
 
+    class AdamRange:
+        """hfem_tri3_energy_adam_step_ex over a tile range (energy + Adam at write-out, no exchange): launch i reads parameter
+        buffer i mod 2 and writes the rows the range owns into the other one (both start complete; lr tiny)."""
+
+        def __init__(self, ko):
+            self.ko = ko
+            self.x, self.u = [ko.xf.clone(), ko.xf.clone()], [ko.uf.clone(), ko.uf.clone()]
+            self.st = [torch.zeros_like(ko.xf), torch.zeros_like(ko.xf), torch.zeros_like(ko.uf), torch.zeros_like(ko.uf)]
+            self.bc = torch.tensor([0.1, 0.0316], dtype=f64, device=dev)        # bias corrections of step 1 (held fixed: timing only)
+
+        def __call__(self, i):
+            k, i_, o_ = self.ko, i & 1, (i + 1) & 1
+            _lib.check(L.hfem_tri3_energy_adam_step_ex(
+                k.plan.handle, 0, self.x[i_].data_ptr(), k.xfix.data_ptr() if k.xfix.numel() else None, self.u[i_].data_ptr(),
+                k.ufix.data_ptr() if k.ufix.numel() else None, k.mat, float(k.W), None, None, k.Tc, self.x[o_].data_ptr(),
+                self.u[o_].data_ptr(), self.st[0].data_ptr(), self.st[1].data_ptr(), self.st[2].data_ptr(), self.st[3].data_ptr(),
+                1e-9, 1e-12, 0.9, 0.999, 1e-8, self.bc.data_ptr(), k.lo, k.hi, k.loss.data_ptr(), 8, stream_box[0].cuda_stream),
+                "hfem_tri3_energy_adam_step_ex")
+
     def shard_kernel_leg(model, loss_fn, nshards, ranks, kreps):
-        """Kernel-only time of the tile ranges `ranks` of an `nshards`-way sharded plan of `model` (one GPU)."""
+        """Kernel-only time of the tile ranges `ranks` of an `nshards`-way sharded plan of `model` (one GPU): the energy launch,
+        and the fused energy + Adam launch (the whole compute of the rank's one-launch training step; its in-launch put / get
+        of ~50 boundary tiles' interface rows is not emulated)."""
         plan = model.tile_plan(loss_fn.tile_elems, shards=nshards)
         out = []
         for r in ranks:
             lo, mid, hi = plan.shard_parts(r, nshards)
             ko = KernelOnly(model, loss_fn, plan, lo, hi)
             us, _ = time_launches(lambda i: ko(), kreps)
+            ar = AdamRange(ko)
+            us_adam, _ = time_launches(ar, kreps + (kreps & 1))
+            del ar
             ne_, nn_, ab = range_work(plan, lo, hi)
             out.append(dict(rank=r, tiles=hi - lo, boundary_tiles=mid - lo, elements=ne_, owned_nodes=nn_, kernel_us=us,
-                            alg_bytes=ab, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS))
+                            alg_bytes=ab, frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, energy_adam_launch_us=us_adam))
         st = plan.stats
         return dict(shards=nshards, tiles=st["n_tiles"], threads_per_tile=st["threads_per_tile"], slot_rows=st["slot_rows"],
                     max_tile_owned=st["max_tile_owned"], ranks=out, kernel_us_max=max(o["kernel_us"] for o in out))

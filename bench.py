@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--time-budget", type=float, default=600.0, help="seconds: optional N > 1 legs (the 4.1 M-element strong-scaling "
                     "mesh: ~2 min of host-side meshing and planning per rank) are skipped, with a note, when the run is already "
                     "past half of it")
+    ap.add_argument("--deadline", type=float, default=1500.0, help="self-launched N > 1 runs: seconds after which the parent stops the "
+                    "ranks and prints rank 0's last PROVISIONAL line (headline + the legs finished so far, marked `partial`) instead of nothing")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic in the run (two rocprofv3 --pmc child "
                     "passes of the replayed leg, ~15 s each); the committed figure is reported instead, labelled so")
     ap.add_argument("--no-lbfgs", action="store_true", help="skip the L-BFGS legs (config.lbfgs_step, lbfgs_step_1gpu, lbfgs_sharded_emulated)")
@@ -193,23 +195,63 @@ def self_launch(a):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] --gpus {a.gpus} without WORLD_SIZE: starting {a.gpus} rank processes as children ({' '.join(cmd[1:8])} ...)",
           file=sys.stderr, flush=True)
+    # A leg that hangs or kills a rank on hardware nobody could rehearse on must not cost the whole measurement: rank 0 rewrites
+    # a PROVISIONAL line (headline step, roofline, the legs finished so far) after every section; if the ranks fail or outlive
+    # --deadline, the parent stops them (its own children: their process group) and prints that line, marked `partial`.
+    import signal
+    import threading
+    prov = env["HFEM_BENCH_PROVISIONAL"] = os.path.join(tempfile.gettempdir(), f"hfem_bench_provisional_{os.getpid()}.json")
+    line, why = [None], None
     try:
-        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through (progress, notes)
-        line = None
-        for ln in pr.stdout:
-            if ln.startswith("{") and '"metric"' in ln:
-                line = ln.strip()                                                  # rank 0's one JSON line
-            else:
-                sys.stderr.write(ln)
-        rc = pr.wait()
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # stderr passes through
+
+        def pump():
+            for ln in pr.stdout:
+                if ln.startswith("{") and '"metric"' in ln:
+                    line[0] = ln.strip()                                           # rank 0's one JSON line
+                else:
+                    sys.stderr.write(ln)
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        try:
+            rc = pr.wait(timeout=a.deadline)
+        except subprocess.TimeoutExpired:
+            why = f"the ranks were still running after --deadline {a.deadline:.0f} s and were stopped"
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(pr.pid, sig)
+                except (ProcessLookupError, PermissionError, AttributeError):
+                    pass
+                try:
+                    rc = pr.wait(timeout=20)
+                    break
+                except subprocess.TimeoutExpired:
+                    rc = -9
+        th.join(timeout=10)
+        if line[0] is None and why is None and rc != 0:
+            why = f"a rank failed (launcher exit code {rc})"
+        if line[0] is None and why is not None and os.path.exists(prov):
+            try:
+                with open(prov) as f:
+                    d = json.loads(f.read())
+                d["partial"] = f"{why}; this is rank 0's provisional line, written after '{d.get('partial')}'"
+                d.setdefault("config", {}).setdefault("notes", []).append("PARTIAL RESULT: " + d["partial"])
+                print(f"[bench] {why}: printing the provisional line", file=sys.stderr, flush=True)
+                line[0], rc = json.dumps(d), 0
+            except (OSError, ValueError):
+                pass
     finally:
         if made:
             shutil.rmtree(made, ignore_errors=True)
-    if rc == 0 and line is None:
+        try:
+            os.unlink(prov)
+        except OSError:
+            pass
+    if rc == 0 and line[0] is None:
         print("[bench] the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
         rc = 1
-    if line is not None and rc == 0:
-        print(line, flush=True)
+    if line[0] is not None and rc == 0:
+        print(line[0], flush=True)
     return rc
 
 
@@ -264,11 +306,31 @@ def main():
 
     wall = {}                                    # section -> seconds since start when it finished (rank 0's clock) -> config.wall_s
 
+    prov_state = {}                              # what rank 0's provisional line holds so far (self-launched N > 1 runs)
+
+    def provisional(section):
+        """Rewrite the provisional result line (self_launch: $HFEM_BENCH_PROVISIONAL): headline, roofline and notes as of now."""
+        path = os.environ.get("HFEM_BENCH_PROVISIONAL")
+        if not path or rank != 0 or world == 1 or "value" not in prov_state:
+            return
+        d = dict(metric="element-evals/sec (fwd+bwd energy) + achieved HBM GB/s, 2D quad mesh", value=prov_state["value"],
+                 unit="element-evals/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=prov_state["ms_per_step"],
+                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                 config=dict(prov_state.get("config", {}), notes=list(notes), wall_s=dict(wall)), roofline=prov_state.get("roofline"),
+                 partial=section)
+        try:
+            with open(path + ".tmp", "w") as f:
+                f.write(json.dumps(d))
+            os.replace(path + ".tmp", path)
+        except OSError:
+            pass
+
     def progress(section):
         """One stderr line per finished section with the elapsed time: a driver log shows where an N-rank run spends its limit."""
         wall[section] = round(time.perf_counter() - t_start, 1)
         if rank == 0:
             print(f"[bench] {wall[section]:7.1f} s  {section}", file=sys.stderr, flush=True)
+        provisional(section)
 
     for kv in a.option:
         name, val = kv.split("=")
@@ -673,6 +735,20 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = ne / (elapsed / a.steps)          # whole-job element-evals/s (all ranks' elements)
 
+    # kernel-only time of this rank's launch (the roofline's numerator), taken HERE so that a multi-rank run has it on record
+    # before its first exchange leg
+    kreps = max(a.steps, 200)      # kernel-only legs: >= 200 launches per graph whatever --steps is (amortises the ~20 us graph launch)
+    ko_main = KernelOnly(model, loss_fn, plan, lo, hi)
+    k_us, samples = time_launches(lambda i: ko_main(), kreps) if only in ("", "replayed") and not a.only_extra else (float("nan"), [])
+    if world > 1:
+        _, _, ab_ = range_work(plan, lo, hi)
+        prov_state.update(value=value, ms_per_step=ms_per_step,
+                          config=dict(workload=f"Example 4 (T1M x {world}): {ne} TRI3, {nn} nodes, fwd+bwd (loss + dX + dU), owner-sharded",
+                                      elements=ne, nodes=nn, elements_per_gpu=ne // world, launch=launch, collectives=comm_state,
+                                      exchange_mode="serial: evaluation -> pack -> all_gather -> unpack on one stream"),
+                          roofline=dict(bound="hbm", achieved=ab_ / (k_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=ab_ / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=k_us,
+                                        alg_bytes_per_launch=ab_, regime="replayed; this rank's tile range of the weak-scaling mesh"))
     progress("headline step timed")
     # ---- N = 1, reported beside the headline: the step of a caller that needs ITS OWN loss before it goes on (a line
     #      search, an L-BFGS check): the 1-block reduction launched right after every energy launch, on the critical path
@@ -762,6 +838,8 @@ def main():
             note("fused training legs skipped: --steps must be even (ping-pong parameter buffers inside one hipGraph)")
 
     if world > 1:
+        prov_state.update(value=value, ms_per_step=ms_per_step)
+        prov_state["config"].update(exchange_mode=exchange_mode, launch=launch)
         progress("collective-path legs")
     # ---- N > 1: the same steps with the interface rows written straight into the peers' receive windows (csrc/peer.hip): no
     #      collective, no second stream.  Verified in this run against the collective path before anything is timed; a failure
@@ -823,6 +901,8 @@ def main():
         peer_on[0] = False
 
     if world > 1 and not a.no_peer:
+        prov_state.update(value=value, ms_per_step=ms_per_step)
+        prov_state["config"].update(exchange_mode=exchange_mode, launch=launch, peer_exchange=peer_state)
         progress("peer-window legs")
     # ---- N > 1: Example 4's own optimiser, node-sharded (weak: N x 10^6 elements, every rank keeps 2 x 10^6 parameters' history)
     if world > 1 and not a.no_lbfgs:
@@ -912,9 +992,7 @@ def main():
     if world > 1 and not a.no_strong:
         progress("strong-scaling legs")
     # ------------------------------------------------------------------------------------------------ roofline legs
-    kreps = max(a.steps, 200)      # kernel-only legs: >= 200 launches per graph whatever --steps is (amortises the ~20 us graph launch)
-    ko_main = KernelOnly(model, loss_fn, plan, lo, hi)
-    k_us, samples = time_launches(lambda i: ko_main(), kreps) if only in ("", "replayed") and not a.only_extra else (float("nan"), [])
+    # (ko_main, k_us, samples: timed right after the headline step)
     # The same kernel in the cache regimes a training loop sees:
     #  replayed:         the same buffers every launch (44 MB working set: Infinity-Cache resident) -- what the headline step is
     #  rewritten_inputs: x and u are rewritten by another kernel before every launch (what an optimiser step does); HIP events

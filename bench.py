@@ -78,10 +78,10 @@ def parse():
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip config.strong_scaling")
     ap.add_argument("--strong-cfg5u", action="store_true", help="N > 1: run the 4.1 M-element Delaunay strong-scaling leg at any N "
                     "(default: from N = 8; ~2 min of host-side meshing and planning per rank)")
-    ap.add_argument("--time-budget", type=float, default=600.0, help="seconds: optional N > 1 legs (the 4.1 M-element strong-scaling "
-                    "mesh: ~2 min of host-side meshing and planning per rank) are skipped, with a note, when the run is already "
-                    "past half of it")
-    ap.add_argument("--deadline", type=float, default=1500.0, help="self-launched N > 1 runs: seconds after which the parent stops the "
+    ap.add_argument("--time-budget", type=float, default=480.0, help="seconds: optional N > 1 legs are skipped, with a note, when the run "
+                    "is already past a share of it -- the peer-window legs and the sharded L-BFGS leg past 60 %, the strong-scaling legs "
+                    "past 70 %, the 4.1 M-element strong-scaling mesh (~2 min of host-side meshing and planning per rank) past half")
+    ap.add_argument("--deadline", type=float, default=540.0, help="self-launched N > 1 runs: seconds after which the parent stops the "
                     "ranks and prints rank 0's last PROVISIONAL line (headline + the legs finished so far, marked `partial`) instead of nothing")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic in the run (two rocprofv3 --pmc child "
                     "passes of the replayed leg, ~15 s each); the committed figure is reported instead, labelled so")
@@ -841,6 +841,15 @@ def main():
         prov_state.update(value=value, ms_per_step=ms_per_step)
         prov_state["config"].update(exchange_mode=exchange_mode, launch=launch)
         progress("collective-path legs")
+    def over_budget(share, what):
+        """True (on every rank: the legs contain collectives) when more than `share` of --time-budget is already spent; notes it."""
+        spent_ = torch.tensor([time.perf_counter() - t_start], dtype=f64, device=dev)
+        dist.all_reduce(spent_, op=dist.ReduceOp.MAX)
+        if spent_.item() > share * a.time_budget:
+            note(f"{what} skipped ({spent_.item():.0f} s of the {a.time_budget:.0f} s --time-budget already spent)")
+            return True
+        return False
+
     # ---- N > 1: the same steps with the interface rows written straight into the peers' receive windows (csrc/peer.hip): no
     #      collective, no second stream.  Verified in this run against the collective path before anything is timed; a failure
     #      (IPC mapping, a flag that never arrives) is reported in notes and the legs are dropped -- never a silent fallback.
@@ -860,6 +869,8 @@ def main():
             raise RuntimeError(f"{tag}: peer-window exchange disagrees with the collective path on some rank "
                                f"(this rank: status {st}, energy {l_got!r} vs {l_ref!r})")
 
+    if world > 1 and not a.no_peer and over_budget(0.6, "peer-window legs"):
+        a.no_peer = True
     if world > 1 and not a.no_peer:
         try:
             enable_peer(sh, "T1M x N")
@@ -905,6 +916,8 @@ def main():
         prov_state["config"].update(exchange_mode=exchange_mode, launch=launch, peer_exchange=peer_state)
         progress("peer-window legs")
     # ---- N > 1: Example 4's own optimiser, node-sharded (weak: N x 10^6 elements, every rank keeps 2 x 10^6 parameters' history)
+    if world > 1 and not a.no_lbfgs and over_budget(0.6, "sharded L-BFGS legs"):
+        a.no_lbfgs = True
     if world > 1 and not a.no_lbfgs:
         try:
             was_peer = sh.peer is not None
@@ -978,6 +991,8 @@ def main():
         del sh_s, m_s, ko
         return res
 
+    if world > 1 and not a.no_strong and over_budget(0.7, "strong_scaling legs"):
+        a.no_strong = True
     if world > 1 and not a.no_strong:
         strong = [strong_leg("T1M FIXED (BASELINE configs[3] as stated): 10^6 TRI3 sharded over the ranks", t1m_mesh(1))]
         spent = torch.tensor([time.perf_counter() - t_start], dtype=f64, device=dev)

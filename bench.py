@@ -9,7 +9,7 @@ parent never touches the GPU and never execs).  Every host plan is built ONCE pe
 job's plan cache, the other ranks deserialise it).
 A *step* is one pass of the hot path over the synthetic mesh: loss + d/d node_coords_free + d/d u_free, inputs resident
 in HBM.  The timed region is ONE hipGraph of exactly K steps, bracketed by barrier + synchronize on both sides; it is
-replayed ``--repeats`` (5) times and the MEDIAN replay is reported (max over ranks per replay).
+replayed ``--repeats`` (9) times and the MEDIAN replay is reported (max over ranks per replay).
 
 Workload at N = 1: BASELINE.json configs[3] "Example 4", reading (i) of SURVEY F11 = "T1M": plate [0,2]x[0,1], 1001x501
 nodes -> 1,000,000 TRI3 (each structured quad split in two), interior nodes jittered 0.2 h (seed 0), outer boundary fixed,
@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=5, help="replays of the K-step graph; the median is reported")
+    ap.add_argument("--repeats", type=int, default=9, help="replays of the K-step graph, each timed on its own; the median is reported")
     ap.add_argument("--nx", type=int, default=1001, help="nodes along x PER GPU (+1 shared column)")
     ap.add_argument("--ny", type=int, default=501)
     ap.add_argument("--tile-elems", type=int, default=0)
@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--cpu-evals", type=int, default=2)
     ap.add_argument("--inline-loss-sum", action="store_true", help="N = 1: reduce the tile energies with a separate "
                     "1-block launch after every energy kernel instead of inside the next launch")
-    ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed replays before each timed leg")
+    ap.add_argument("--prewarm", type=float, default=0.75, help="seconds of untimed replays before each timed leg")
     ap.add_argument("--option", action="append", default=[], help="name=value for hfem_set_option (lab A/B runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra / train_step_1gpu / strong_scaling_emulated")
     ap.add_argument("--no-regimes", action="store_true", help="skip the cache-regime legs (roofline = the replayed leg)")

@@ -248,10 +248,6 @@ __device__ __forceinline__ void peer_put_finish(const PeerPutDev &P, const LagSu
     }
 }
 
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
-// L2).  Map block -> tile so that each XCD walks one contiguous run of the
-// Morton-ordered tiles: neighbouring tiles share halo nodes, which then hit the
-// same L2.  Bijective for any grid size; placement only affects speed.
 // Wave priority through a tile's memory phases (round 4).  A workgroup that arrives on a CU whose other workgroups are in
 // their fp64 slot loops has ~60 prologue instructions (index loads, address selects, the gather) to issue before its first
 // byte is requested, and they queue behind the resident waves' VALU work at equal priority; the same holds for the write-out
@@ -270,6 +266,10 @@ __device__ __forceinline__ void mem_phase_end() {
     if (HFEM_MEM_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Map block -> tile so that each XCD walks one contiguous run of the
+// Morton-ordered tiles: neighbouring tiles share halo nodes, which then hit the
+// same L2.  Bijective for any grid size; placement only affects speed.
 __device__ __forceinline__ int xcd_tile(int b, int nb) {
     const int q = nb >> 3, r = nb & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);

@@ -52,16 +52,24 @@ __global__ __launch_bounds__(256) void iface_put_kernel(const V *__restrict__ x_
     const int par = (int)(seq & 1);
     const size_t slot = kPeerData + ((size_t)par * pv.world + pv.rank) * (size_t)stride * sizeof(double2);
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // window stores: system-scope relaxed atomic stores (write-through, never parked in this XCD's L2) whose completion the
+    // counted wait below observes -- the same ordering argument as the in-launch put (hfem_plan_dev.h, peer_put_finish), and no
+    // __threadfence_system (= a write-back of the XCD's whole L2) in every workgroup
+    auto put2 = [&](int p, int64_t at, double a0, double a1) {
+        double *q = reinterpret_cast<double *>(pv.win[p] + slot) + 2 * (size_t)at;
+        __hip_atomic_store(q, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(q + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     if (i < n_x + n_u) {
         const double2 v = row_widen(i < n_x ? x_free[rows[i]] : u_free[rows[i]]);
-        for (int p = 0; p < pv.world; ++p) ((double2 *)(pv.win[p] + slot))[i] = v;
+        for (int p = 0; p < pv.world; ++p) put2(p, i, v.x, v.y);
     }
     if (blockIdx.x == 0) {          // the rank's energy: the same bits as sum_partials_kernel / iface_pack_sum_kernel
         double v = 0.0;
         for (int k = threadIdx.x; k < n_partials; k += 256) v += partials[k];
         const double tot = block_sum(v, red);
         if (threadIdx.x == 0) {
-            for (int p = 0; p < pv.world; ++p) ((double2 *)(pv.win[p] + slot))[loss_slot] = make_double2(tot, 0.0);
+            for (int p = 0; p < pv.world; ++p) put2(p, loss_slot, tot, 0.0);
             if (counter) {
                 const int64_t c = counter[0] + 1;
                 counter[0] = c;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256) void iface_put_kernel(const V *__restrict__ x_
             }
         }
     }
-    __threadfence_system();          // this workgroup's rows have reached every window before it takes its ticket
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's window stores are acknowledged before the workgroup takes its ticket
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd((unsigned *)(ctl + 8), 1u) == gridDim.x - 1;
     __syncthreads();

@@ -203,7 +203,26 @@ def self_launch(a):
     prov = env["HFEM_BENCH_PROVISIONAL"] = os.path.join(tempfile.gettempdir(), f"hfem_bench_provisional_{os.getpid()}.json")
     line, why = [None], None
     try:
-        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # stderr passes through
+        def own_group_and_die_with_parent():                  # in the child, before exec: a session of its own (so that the parent
+            os.setsid()                                         # can stop launcher + ranks together) that still ends if the parent
+            try:                                                # is killed outright (PR_SET_PDEATHSIG; the launcher sets the same
+                import ctypes                                   # for its ranks)
+                ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM))
+            except OSError:
+                pass
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, preexec_fn=own_group_and_die_with_parent)   # stderr passes through
+
+        def forward(signum, frame):                             # the driver stops the parent: the ranks go with it
+            try:
+                os.killpg(pr.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+            raise SystemExit(128 + signum)
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            try:
+                signal.signal(sg, forward)
+            except ValueError:                                  # not the main thread (never the case for `python bench.py`)
+                pass
 
         def pump():
             for ln in pr.stdout:

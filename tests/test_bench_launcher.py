@@ -34,8 +34,8 @@ def _launch(monkeypatch, capsys, lines, rc, argv, hang=False, provisional=None):
     assert bench.torch is None, "importing bench.py must not import torch (the self-launching parent never touches the GPU)"
     seen = {"killed": []}
 
-    def fake_popen(cmd, env=None, stdout=None, text=None, start_new_session=None):
-        seen["cmd"], seen["env"], seen["own_group"] = cmd, env, start_new_session
+    def fake_popen(cmd, env=None, stdout=None, text=None, preexec_fn=None):
+        seen["cmd"], seen["env"], seen["own_group"] = cmd, env, callable(preexec_fn)      # own session + parent-death signal
         seen["cache_exists"] = os.path.isdir(env["HFEM_PLAN_CACHE"])
 
         def rank0_writes():                # what rank 0 does between sections: rewrite its provisional line
@@ -47,6 +47,8 @@ def _launch(monkeypatch, capsys, lines, rc, argv, hang=False, provisional=None):
     import subprocess
     monkeypatch.setattr(subprocess, "Popen", fake_popen)
     monkeypatch.setattr(os, "killpg", lambda pid, sig: seen["killed"].append((pid, sig)), raising=False)
+    import signal
+    monkeypatch.setattr(signal, "signal", lambda *a_: None)          # the parent's SIGTERM / SIGINT forwarders: not in the test process
     monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("HFEM_PLAN_CACHE", raising=False)

@@ -166,7 +166,7 @@ int hfem_plan_deserialize(int device, const void *blob, int64_t n_bytes, hfem_pl
                                  * write-out and the last of them completes the put: one launch per owner-sharded training step */
 #define HFEM_FLAG_FP32_MATH 1024 /* hfem_tri3_energy_plan_f32, hfem_tri3_energy_adam_step_ex(dtype 1): fp32 ARITHMETIC as well as fp32 rows -- what the reference itself
                                  * computes in for its default dtype (src/loss.py:16): packed-fp32 element math (the two elements of
-                                 * a slot side by side), float LDS accumulators; the tile energies and the loss stay fp64.  Paired-slot
+                                 * a slot side by side), double LDS accumulators (rows rounded once); tile energies and loss stay fp64.  Paired-slot
                                  * plans; body force, tile ranges, NO_LOSS_SUM / SUM_PREVIOUS / SAME_BANK as the fp64 entry point. */
 #define HFEM_FLAG_SAME_BANK 256 /* with NO_LOSS_SUM: another tile range of the SAME evaluation as the previous NO_LOSS_SUM
                                  * launch on this plan (a rank's boundary tiles after its interior tiles): the tile energies

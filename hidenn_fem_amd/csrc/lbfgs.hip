@@ -20,6 +20,8 @@
 // fp64 for fp32 and fp64 vectors alike; every reduction has a fixed order (bit-reproducible).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cmath>
 #include <new>
 
@@ -475,6 +477,225 @@ __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, i
     }
 }
 
+// ---- the same recursion with the two sequential loops on ONE wavefront (round 4).  The form above pays a barrier and an LDS
+// round trip per sequential step (2 x count steps: 52 us at 100 pairs -- a fifth of a sharded iteration, and it does not shrink
+// with the number of ranks).  Here the 256 threads first stage S^T Y (logical order, odd row stride: both the column reads of
+// the first loop and the row reads of the second are bank-conflict-free) into LDS -- a workgroup may take all 160 KB, 128 pairs
+// need 129 KB --, then wave 0 alone walks the two loops: lane l owns rows l, l + 64 (R per lane), the running sums stay in
+// registers, the value a step publishes travels by v_readlane (the publishing lane is wave-uniform) -- no barrier, no memory
+// round trip on the critical path; the Gram entries of the next P steps are already in registers.  The row-parallel middle
+// part (v_k) runs on all 256 threads as before.  Same operations in the same order per row, and the final g.d sum adds the
+// per-64-row wave sums in block_sum's order: BIT-IDENTICAL coefficients, g.d and step to recursion_rank1_kernel
+// (scripts/lbfgs_recursion_bits.py: same parameter bits after 160 iterations for histories 100 and 7).  Measured at 100 pairs
+// (s_memrealtime stamps, -DHFEM_REC_DEBUG): first loop 7.6-12 us, v_k 2.5 us (its Gram column is requested into registers
+// before the first loop), second loop + coefficients 12 us; 52 -> ~28 us for the launch, a sharded inner iteration of T1M / 8
+// 0.268-0.272 -> 0.250-0.259 ms.  What did NOT work: one wave with the Gram entries prefetched from global memory 8 steps
+// ahead (130 us: one wave cannot cover the load latency); publishing al_i through LDS inside the loop or guarding every
+// prefetched element (a wait / a branch per step: 15 us per loop); splitting H (..) + w_k out of the second loop's chain
+// (the product no longer contracts into the fused multiply-add of the reference form: different bits).
+__device__ __forceinline__ double readlane_f64(double v, int uniform_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), uniform_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), uniform_lane);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kRecWaveMax = 128;                          // pairs: (128 | 1) * 128 * 8 B = 129 KB of LDS for S^T Y
+template <int R>
+__global__ __launch_bounds__(kRecT) void recursion_wave_kernel(LbfgsArrays A, int M1, double lr, double tol_change, int stride) {
+    static_assert(R == 1 || R == 2, "rows per lane: 64 or 128 pairs");
+    constexpr int P = 8;                                  // steps whose Gram entries are held in registers ahead of time
+    extern __shared__ double SYl[];                       // [count][stride]: SYl[i * stride + k] = s_i . y_k, logical indices
+    __shared__ double al_[kRecMax], v_[kRecMax];
+    LbfgsState &S = *A.st;
+    if (S.skip) return;
+    const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto slot_of = [&](int l) { const int x = head + l; return x >= M1 ? x - M1 : x; };      // l < M1, head < M1: no division
+    if (ns >= 0 && tid < count) {                         // Gram row / column of the new pair
+        const int j = slot_of(tid);
+        A.SY[ns * M1 + j] = A.dots[j * 5 + 2];
+        A.SY[j * M1 + ns] = A.dots[j * 5 + 4];
+        A.YY[ns * M1 + j] = A.dots[j * 5 + 3];
+        A.YY[j * M1 + ns] = A.dots[j * 5 + 3];
+    }
+    __syncthreads();                                      // orders the Gram writes above before the reads below (one block)
+    __threadfence_block();
+    // S^T Y into LDS: wave w takes rows w, w + 4, ...; lanes take the columns; four rows' loads in flight per lane
+    for (int i0 = wave; i0 < count; i0 += 16) {
+        double x[4][R];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 4 * u, si = slot_of(min(i, count - 1));
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int k = lane + 64 * j;
+                x[u][j] = (i < count && k < count) ? A.SY[si * M1 + slot_of(k)] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 4 * u;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int k = lane + 64 * j;
+                if (i < count && k < count) SYl[i * stride + k] = x[u][j];
+            }
+        }
+    }
+    const double H = S.H_diag;
+    bool live[R];
+    int sk[R], rowc[R];
+    double ro[R], sg[R], yg[R], al_k[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = lane + 64 * j;
+        live[j] = k < count;
+        sk[j] = live[j] ? slot_of(k) : 0;
+        ro[j] = live[j] ? A.ro[sk[j]] : 0.0;
+        sg[j] = live[j] ? A.dots[sk[j] * 5 + 1] : 0.0;
+        yg[j] = live[j] ? A.dots[sk[j] * 5] : 0.0;
+        al_k[j] = 0.0;
+        rowc[j] = min(k, count > 0 ? count - 1 : 0);       // a staged row for every lane (rows past count read row count - 1, masked)
+    }
+    __syncthreads();                                      // S^T Y staged
+#ifdef HFEM_REC_DEBUG
+    const unsigned long long T0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // column tid of Y^T Y (stored symmetric: = row tid, but the 64 lanes of a load read consecutive addresses) requested NOW (after the barrier: nothing in the first loop waits for memory), into
+    // registers: the loads land under the first loop, and v_k below is a chain of fused multiply-adds without a memory round trip
+    double yyc[64 * R];
+    {
+        const int skk = slot_of(min(tid, count > 0 ? count - 1 : 0));
+#pragma unroll
+        for (int j = 0; j < 64 * R; ++j) yyc[j] = j < count ? A.YY[slot_of(j) * M1 + skk] : 0.0;
+    }
+    double a[R][P], b[R][P];
+    // ---- first loop (wave 0), i = count-1 .. 0: column i of S^T Y.  Row k takes t_k += al_i s_k.y_i for every i > k and is
+    //      final from step k on, so al_k = ro_k (-s_k.g - t_k) is what step k publishes AND what the row holds after the loop;
+    //      entries a row must not take are zeroed when they are fetched (P steps ahead, off the chain): the step itself is
+    //      one add, one multiply, two v_readlane and R fused multiply-adds
+    if (wave == 0) {
+        double t[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) t[j] = 0.0;
+        auto fetch = [&](int i_hi, double (&x)[R][P]) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int i = i_hi - q, ic = max(i, 0);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const double e = SYl[rowc[j] * stride + ic];          // unguarded LDS read
+                    x[j][q] = (lane + 64 * j < i) ? e : 0.0;
+                }
+            }
+        };
+        fetch(count - 1, a);
+        for (int ih = count - 1; ih >= 0; ih -= P) {
+            fetch(ih - P, b);                             // the next group's entries, read under this group's steps
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int i = ih - q;
+                if (i >= 0) {                             // uniform
+                    double cand;
+                    if (R == 1 || i < 64) cand = ro[0] * (-sg[0] - t[0]);           // uniform: the publishing row's register
+                    else cand = ro[R - 1] * (-sg[R - 1] - t[R - 1]);
+                    const double al_i = readlane_f64(cand, i & 63);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) t[j] += al_i * a[j][q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int j = 0; j < R; ++j) a[j][q] = b[j][q];
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            al_k[j] = ro[j] * (-sg[j] - t[j]);
+            if (live[j]) al_[lane + 64 * j] = al_k[j];
+        }
+    }
+    __syncthreads();                                      // al_[] complete
+#ifdef HFEM_REC_DEBUG
+    const unsigned long long T1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- v_k = sum_j al_j y_k.y_j (all threads, thread k = row k), from the registers filled before the first loop
+    if (tid < count) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 64 * R; ++j)
+            if (j < count) v += al_[j] * yyc[j];          // uniform guard; the sum in recursion_rank1_kernel's order
+        v_[tid] = v;
+    }
+    __syncthreads();
+#ifdef HFEM_REC_DEBUG
+    const unsigned long long T2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (wave != 0) return;
+    // ---- second loop (wave 0), i = 0 .. count-1: row i of S^T Y.  Row k takes w_k += c_i s_i.y_k for every i < k and is
+    //      final from step k on: c_k = al_k - ro_k (H (-y_k.g - v_k) + w_k)
+    double w[R], c_k[R], v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { w[j] = 0.0; c_k[j] = 0.0; v[j] = live[j] ? v_[lane + 64 * j] : 0.0; }
+    {
+        auto fetch = [&](int i_lo, double (&x)[R][P]) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int i = i_lo + q, ic = max(min(i, count - 1), 0);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const double e = SYl[ic * stride + rowc[j]];
+                    x[j][q] = (i < count && lane + 64 * j > i && live[j]) ? e : 0.0;
+                }
+            }
+        };
+        fetch(0, a);
+        for (int il = 0; il < count; il += P) {
+            fetch(il + P, b);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int i = il + q;
+                if (i < count) {                          // uniform
+                    double cand;
+                    // (the expression as recursion_rank1_kernel writes it: H * (...) + w contracts to one fused multiply-add)
+                    if (R == 1 || i < 64) cand = al_k[0] - ro[0] * (H * (-yg[0] - v[0]) + w[0]);
+                    else cand = al_k[R - 1] - ro[R - 1] * (H * (-yg[R - 1] - v[R - 1]) + w[R - 1]);
+                    const double c_i = readlane_f64(cand, i & 63);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) w[j] += c_i * a[j][q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int j = 0; j < R; ++j) a[j][q] = b[j][q];
+        }
+    }
+    // ---- coefficients by slot, g.d (the per-64-row sums added in block_sum's wave order), step, break flag
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        double part = 0.0;
+        if (live[j]) {
+            c_k[j] = al_k[j] - ro[j] * (H * (-yg[j] - v[j]) + w[j]);
+            const double cyj = -H * al_k[j];
+            A.al[sk[j]] = al_k[j]; A.cy[sk[j]] = cyj; A.cs[sk[j]] = c_k[j];
+            part = cyj * yg[j] + c_k[j] * sg[j];
+        }
+        sum += wave_sum(part);                            // valid in lane 0
+    }
+    if (lane == 0) {
+        S.cg = -H;
+        S.gtd = -H * S.gg + sum;
+        S.t = S.n_iter == 1 ? fmin(1.0, 1.0 / S.g_abssum) * lr : lr;
+        S.stop_gtd = S.gtd > -tol_change ? 1 : 0;
+#ifdef HFEM_REC_DEBUG
+        const unsigned long long T3 = __builtin_amdgcn_s_memrealtime();
+        if (count >= 100 && S.n_iter % 20 == 0)
+            printf("rec: count %d  loop1 %.2f us  v %.2f us  loop2+tail %.2f us\n", count, (T1 - T0) * 0.01, (T2 - T1) * 0.01, (T3 - T2) * 0.01);
+#endif
+    }
+}
+
 // ---- d = cg g + sum_j cy_j Y_j + cs_j S_j (one pass over the history), max|d| partials [nb]
 // PER elements per thread: 8 for long vectors (fewer, fatter workgroups), 1 for short ones (more workgroups); the slot
 // loop is unrolled so that several slots' loads are in flight (it is latency-bound otherwise).  Same sums either way.
@@ -839,6 +1060,29 @@ extern "C" int hfem_lbfgs_check(hfem_lbfgs *o, const void *g, const double *loss
     return 0;
 }
 
+// the two loops in coefficient space: one wavefront (histories up to 256 pairs; HFEM_LBFGS_RECURSION=1 at build time keeps the
+// 256-thread form for A/B runs), else the reduction form
+#ifndef HFEM_LBFGS_RECURSION
+#define HFEM_LBFGS_RECURSION 0
+#endif
+static void launch_recursion(hfem_lbfgs *o, int M1, double lr, double tol_change, hipStream_t s) {
+    const int pairs = M1 - 1;
+    if (pairs > kRecMax) { hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change); return; }
+    if (HFEM_LBFGS_RECURSION == 1 || pairs > kRecWaveMax) {
+        hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
+        return;
+    }
+    const int stride = pairs | 1;                         // odd: column reads (stride apart) and row reads both hit distinct banks
+    const size_t lds = (size_t)pairs * stride * sizeof(double);
+    static std::once_flag big_lds;                        // up to 129 KB of dynamic LDS: say so once (64 KB is the default ceiling)
+    std::call_once(big_lds, [] {
+        (void)hipFuncSetAttribute((const void *)recursion_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        (void)hipFuncSetAttribute((const void *)recursion_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    });
+    if (pairs <= 64) hipLaunchKernelGGL(recursion_wave_kernel<1>, dim3(1), dim3(kRecT), lds, s, o->A, M1, lr, tol_change, stride);
+    else hipLaunchKernelGGL(recursion_wave_kernel<2>, dim3(1), dim3(kRecT), lds, s, o->A, M1, lr, tol_change, stride);
+}
+
 // Memory update + direction for the gradient `g` (the one hfem_lbfgs_check saw last): d, t, g.d and the g.d break
 // flag stay on the device.
 extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, double tol_change, void *stream) {
@@ -860,8 +1104,7 @@ extern "C" int hfem_lbfgs_direction(hfem_lbfgs *o, const void *g, double lr, dou
 #undef HFEM_MD
         hipLaunchKernelGGL(multidot_reduce_kernel, dim3(M1 - 1), dim3(kLb), 0, s, o->A, o->nb_md, M1);
     }
-    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
-    else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
+    launch_recursion(o, M1, lr, tol_change, s);
     // elements per thread of the direction pass: 8 for very long vectors (fewer, fatter workgroups), 1 for short ones (more
     // workgroups), in between 2 (fp64) / 4 (fp32) -- measured on 2 x 10^6 parameters with 100 pairs: fp64 1.29 -> 1.26 ms, fp32
     // 0.79 -> 0.77 ms per iteration; 8 x 10^6 parameters: 8 is best (2.08 against 2.13 / 2.17 ms with 2 / 1)
@@ -942,8 +1185,7 @@ extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const doubl
     const int first = o->first ? 1 : 0, M1 = o->M1;
     hipLaunchKernelGGL(shard_finish_kernel, dim3(1), dim3(kLb), 0, s, o->A, gathered_dev, (int)world, 5 * M1 + kShardTail, M1, first,
                        (int)after_update, (int)want_direction, tol_grad, tol_change);
-    if (M1 - 1 <= kRecMax) hipLaunchKernelGGL(recursion_rank1_kernel, dim3(1), dim3(kRecT), 0, s, o->A, M1, lr, tol_change);
-    else hipLaunchKernelGGL(recursion_kernel, dim3(1), dim3(64), 0, s, o->A, M1, lr, tol_change);
+    launch_recursion(o, M1, lr, tol_change, s);
     const int per_dir = o->nb_chunk >= 1024 ? kLbPer : (o->n >= (1 << 20) ? (o->dtype == 0 ? 2 : 4) : 1);
     const int nb_dir = (int)((o->n + (int64_t)per_dir * kLb - 1) / ((int64_t)per_dir * kLb));
 #define HFEM_DIR(T, P) hipLaunchKernelGGL((direction_kernel<T, P>), dim3(nb_dir), dim3(kLb), 0, s, o->A, (const T *)g, (const T *)o->Sring, (const T *)o->Yring, (T *)o->d, o->n, M1, (T *)o->g_prev)

@@ -45,9 +45,11 @@ def _run(opt_cls, params, f, n_steps, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("history", [100, 5])
+@pytest.mark.parametrize("history", [100, 5, 64, 65, 128, 129, 300])
 def test_fused_lbfgs_matches_torch_on_a_quadratic(history):
-    """history 5 makes the ring wrap many times; two parameter tensors exercise the segment offsets."""
+    """history 5 makes the ring wrap many times; two parameter tensors exercise the segment offsets.  The other sizes sit on the
+    recursion kernels' boundaries (csrc/lbfgs.hip): 64 / 65 = one / two rows per lane of the one-wavefront form, 128 = its
+    largest history (129 KB of LDS for S^T Y), 129 = the 256-thread form, 300 = the reduction form."""
     from hidenn_fem_amd.optim import FusedLBFGS
     d = torch.device("cuda:0")
     params, f = _quadratic(d, F64)

@@ -1199,12 +1199,11 @@ extern "C" int hfem_lbfgs_shard_finish(hfem_lbfgs *o, const void *g, const doubl
         else HFEM_DIR(float, 1);
     }
 #undef HFEM_DIR
-    hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, nb_dir, o->status);
+    // enqueue only (status_host NULL; legal inside a hipGraph capture): the last kernel writes the record straight into the
+    // pinned, device-visible host buffer hfem_lbfgs_shard_status reads after its stream synchronisation -- no copy node behind it
+    hipLaunchKernelGGL(dmax_reduce_kernel, dim3(1), dim3(kLb), 0, s, o->A, nb_dir, status_host ? o->status : o->status_pinned);
     if (int rc = launch_status("hfem_lbfgs_shard_finish")) return rc;
-    if (!status_host) {                                         // enqueue only (legal inside a hipGraph capture): hfem_lbfgs_shard_status reads it
-        HFEM_HIP_CHECK(hipMemcpyAsync(o->status_pinned, o->status, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-        return 0;
-    }
+    if (!status_host) return 0;
     HFEM_HIP_CHECK(hipMemcpyAsync(status_host, o->status, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HFEM_HIP_CHECK(hipStreamSynchronize(s));
     if (!((int)status_host[1] & 16)) o->first = false;          // a direction exists from now on

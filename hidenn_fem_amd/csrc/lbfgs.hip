@@ -43,6 +43,9 @@ struct LbfgsState {                // one record in device memory
     double loss, prev_loss;
     double g_absmax, g_abssum, gg, d_absmax, ys, yy;
     double flags;                  // bit 0 opt_cond, 1 small step, 2 small loss change, 3 gtd break  (check_kernel)
+    int halt;                      // sharded flow, several iterations per captured graph: the PREVIOUS iteration ended the step (a
+                                   // break test fired, or g.d > -tolerance_change): this iteration's finish, recursion, direction and
+                                   // status write do nothing -- the state and the status record stay those of the iteration that ended it
 };
 
 struct LbfgsArrays {               // device pointers, by value to kernels
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(kLb) void multidot_reduce_kernel(LbfgsArrays A, int
 __global__ __launch_bounds__(kLb) void recursion_kernel(LbfgsArrays A, int M1, double lr, double tol_change) {
     __shared__ double red[kLb / 64];
     LbfgsState &S = *A.st;
-    if (S.skip) return;
+    if (S.skip || S.halt) return;
     const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x;
     const int nthr = blockDim.x;         // launched with ONE wave: the 2 x count sequential steps then sync at wave cost
     // Gram row / column of the new pair
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kRecT) void recursion_rank1_kernel(LbfgsArrays A, i
     __shared__ int slot_[kRecMax];
     __shared__ double red[kRecT / 64];
     LbfgsState &S = *A.st;
-    if (S.skip) return;
+    if (S.skip || S.halt) return;
     const int count = S.count, head = S.head, ns = S.new_slot, k = threadIdx.x;
     if (ns >= 0 && k < count) {                           // Gram row / column of the new pair
         const int j = (head + k) % M1;
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(kRecT) void recursion_wave_kernel(LbfgsArrays A, in
     extern __shared__ double SYl[];                       // [count][stride]: SYl[i * stride + k] = s_i . y_k, logical indices
     __shared__ double al_[kRecMax], v_[kRecMax];
     LbfgsState &S = *A.st;
-    if (S.skip) return;
+    if (S.skip || S.halt) return;
     const int count = S.count, head = S.head, ns = S.new_slot, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto slot_of = [&](int l) { const int x = head + l; return x >= M1 ? x - M1 : x; };      // l < M1, head < M1: no division
     if (ns >= 0 && tid < count) {                         // Gram row / column of the new pair
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *
                                                         const T *__restrict__ Yring, T *__restrict__ d, int64_t n, int M1,
                                                         T *__restrict__ g_prev = nullptr) {
     const LbfgsState &S = *A.st;
-    if (S.skip) return;
+    if (S.skip || S.halt) return;
     const int count = S.count, head = S.head;
     const int64_t base = (int64_t)blockIdx.x * (kLb * PER) + threadIdx.x;
     const double cg = S.cg;
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(kLb) void direction_kernel(LbfgsArrays A, const T *
 // status != NULL (sharded flow): the status record is written HERE, after the recursion -- g.d, t and the g.d break flag
 // (bit 3) are those of the direction just computed; bit 4: no direction was computed (break tests / the host's wish)
 __global__ __launch_bounds__(kLb) void dmax_reduce_kernel(LbfgsArrays A, int nb, double *__restrict__ status = nullptr) {
+    if (A.st->halt) return;                               // the status record stays that of the iteration that ended the step
     if (A.st->skip) {
         if (status && threadIdx.x == 0) {
             const LbfgsState &S = *A.st;
@@ -893,6 +897,10 @@ __global__ __launch_bounds__(kLb) void shard_finish_kernel(LbfgsArrays A, const 
     __syncthreads();
     if (threadIdx.x == 0) {
         LbfgsState &S = *A.st;
+        // an iteration replayed AFTER the one that ended the step (graphs of several iterations, optim.ShardedLBFGS): the host
+        // loop would have left before it -- nothing of it may count.  Its apply did nothing already (skip / stop_gtd).
+        if (after_update && (S.skip || S.stop_gtd)) { S.halt = 1; return; }
+        S.halt = 0;
         double ys = 0.0, yy = 0.0, gsum = 0.0, gg = 0.0, loss = 0.0, gmax = 0.0, dmax = 0.0;
         for (int r = 0; r < world; ++r) {
             const double *t = gathered + (int64_t)r * P + 5 * M1;

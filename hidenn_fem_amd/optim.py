@@ -440,7 +440,7 @@ class ShardedLBFGS:
     HIP evaluator only; fp64 and fp32 models; one ``step()`` = one ``optimizer.step(closure)`` of the reference's loop."""
 
     def __init__(self, sharded, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100,
-                 emulate: bool = False, graph: bool = True):
+                 emulate: bool = False, graph: bool = True, graph_iterations: int = 4):
         """``emulate=True`` (bench.py's one-GPU rehearsal of rank r of N; timing only): ``sharded`` plays one rank of a world
         that does not exist -- no interface exchange, and the payload "gather" is this rank's payload copied into every rank's
         slot, so the local passes, launches and the status read cost what they would on that rank."""
@@ -453,6 +453,11 @@ class ShardedLBFGS:
         # windows for the interface rows (torch.distributed collectives are not: those runs stay eager).
         self._graph_ok = bool(graph)
         self._graph = None
+        # ... and SEVERAL of them per graph (``graph_iterations``): the status read between two iterations costs the GPU ~25 us of
+        # idle time (stream drain, host, graph launch) -- a tenth of a sharded iteration.  An iteration replayed after the one
+        # that ended the step does nothing on the device (csrc/lbfgs.hip: LbfgsState.halt), so the host may look every k-th only.
+        self._batch = max(1, int(graph_iterations))
+        self._graph_k = None
         if not sh._hip:
             raise RuntimeError("ShardedLBFGS needs the HIP evaluator")
         if not hasattr(sh, "iface_rows"):
@@ -528,11 +533,13 @@ class ShardedLBFGS:
         sh = self.sh
         return self._graph_ok and (sh.world == 1 or self._emulate or sh.comm is not None)      # LibraryComm: in-library RCCL, capturable
 
-    def _iteration_graphed(self) -> int:
-        """apply + evaluate + reduce(after_update = 1, want_direction) of a steady-state iteration as one graph replay."""
+    def _iteration_graphed(self, k: int = 1):
+        """k x [apply + evaluate + reduce(after_update = 1, want_direction)] of steady-state iterations as ONE graph replay;
+        returns (flags, iterations that counted): an iteration behind the one that ended the step is a no-op on the device."""
         sh, L = self.sh, _lib.lib()
         dev = self._g.device
-        if self._graph is None:
+        n_dev = int(self._status[6])                             # the device's n_iter before the replay (every path reads the status)
+        if (self._graph if k == 1 else self._graph_k) is None:
             def body():
                 self._apply()
                 self._evaluate()
@@ -547,17 +554,25 @@ class ShardedLBFGS:
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g):
-                    body()
+                    for _ in range(k):
+                        body()
             except Exception:                                    # a transport that turned out not to be capturable: nothing of the
                 torch.cuda.synchronize()                         # body has RUN (a capture does not execute) -- this and every
-                self._graph_ok, self._graph = False, None        # later iteration take the eager launches
+                self._graph_ok, self._graph, self._graph_k = False, None, None      # later iteration take the eager launches
                 self._apply()
                 self._evaluate()
-                return self._reduce(1, True)
-            self._graph = g
-        self._graph.replay()
+                return self._reduce(1, True), 1
+            if k == 1:
+                self._graph = g
+            else:
+                self._graph_k = g
+        (self._graph if k == 1 else self._graph_k).replay()
         check(L.hfem_lbfgs_shard_status(self._h, self._status, stream_ptr(dev)), "hfem_lbfgs_shard_status")
-        return int(self._status[1])
+        flags = int(self._status[1])
+        # iterations that counted: every one that computed a direction bumped the device's n_iter; one that ended the step on a
+        # break test (bits 0-2) did not, but was evaluated
+        done = int(self._status[6]) - n_dev + (1 if flags & 7 else 0)
+        return flags, max(1, min(k, done))
 
     @torch.no_grad()
     def step(self) -> torch.Tensor:
@@ -581,9 +596,14 @@ class ShardedLBFGS:
                 break
             want = current_evals + 1 < self.max_eval
             if n_iter < self.max_iter and want and self._capturable():
-                flags = self._iteration_graphed()                # apply + energy + sums + exchange + finish: one graph replay
-                current_evals += 1
-                self.state["func_evals"] += 1
+                # apply + energy + sums + exchange + finish per iteration, `k` of them per graph replay when that many may
+                # follow one another (iteration numbers < max_iter, evaluations < max_eval) -- else one
+                k = min(self._batch, self.max_iter - n_iter, self.max_eval - 1 - current_evals)
+                flags, done = self._iteration_graphed(k if k == self._batch and k > 1 else 1)
+                n_iter += done - 1                               # this iteration was counted above
+                self.state["n_iter"] += done - 1
+                current_evals += done
+                self.state["func_evals"] += done
                 if flags & 7:
                     break
                 continue
